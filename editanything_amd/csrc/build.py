@@ -1,0 +1,87 @@
+"""Build the gfx950 HIP library (product) and, for the CPU test-suite only, the
+host emulation build of the same kernel sources.
+
+    python -m editanything_amd.csrc.build          # libeditanything_hip.so (hipcc, gfx950)
+    python -m editanything_amd.csrc.build --emu    # tests/emu/libeditanything_emu.so (host clang)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ["ea_gemm.hip", "ea_norm.hip", "ea_attn.hip", "ea_elem.hip"]
+HEADERS = ["ea_platform.h", "ea_gemm.h", os.path.join(ROOT, "include", "editanything_hip.h")]
+LIB = os.path.join(HERE, "libeditanything_hip.so")
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+EMU_LIB = os.path.join(EMU_DIR, "libeditanything_emu.so")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built")
+
+
+def build_hip(force=False, verbose=True):
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and not _newer(LIB, deps):
+        return LIB
+    objs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+               "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def _host_cxx():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("clang++ (for _Float16 / ext_vector_type host emulation) not found")
+
+
+def build_emu(force=False, verbose=True):
+    """TEST INFRASTRUCTURE: same kernels, host fibers instead of a GPU."""
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    emu_srcs = [os.path.join(EMU_DIR, "hip_emu.cpp")]
+    deps = srcs + emu_srcs + [os.path.join(EMU_DIR, "hip_emu.h")] + \
+        [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and not _newer(EMU_LIB, deps):
+        return EMU_LIB
+    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-I", EMU_DIR, "-I", HERE,
+           "-Wno-unknown-attributes", "-Wno-unused-value", "-o", EMU_LIB]
+    for s in srcs:
+        cmd += ["-x", "c++", s]
+    for s in emu_srcs:
+        cmd += ["-x", "c++", s]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    if "--emu" in sys.argv:
+        print(build_emu(force="--force" in sys.argv))
+    else:
+        print(build_hip(force="--force" in sys.argv))

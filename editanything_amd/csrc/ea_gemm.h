@@ -1,0 +1,409 @@
+// ea_gemm.h -- the one MFMA contraction kernel of the hot path.
+//
+//   C[M,N] = epilogue( A[M,K] * W[N,K]^T )        fp16 operands, fp32 accumulate
+//
+// A is either a dense row-major matrix (Linear layers; reference call sites
+// ldm/modules/attention.py:54,152-160,316-339) or the *implicit im2col* of an
+// NHWC fp16 activation for a 3x3 / 1x1 convolution (ResBlock convs
+// ldm/modules/diffusionmodules/openaimodel.py:200-231, Up/Downsample :108-152,
+// ControlNet zero-convs cldm/cldm.py:281-282, VAE convs
+// ldm/modules/diffusionmodules/model.py:68-149), optionally the channel-concat
+// of two tensors (decoder skip connections cldm/cldm.py:38-41, never
+// materialised) and optionally through a fused nearest-2x upsample.
+//
+// MI355X design: 256-thread workgroups (4 waves, one per SIMD), each wave owns a
+// 64x64 accumulator = 2x2 v_mfma_f32_32x32x16_f16 tiles (64 acc VGPRs).  K is
+// walked in 64-wide tiles, register-staged (16-B global loads issued a tile
+// ahead) into a double-buffered, XOR-swizzled LDS image so the ds_read_b128
+// fragment reads are bank-conflict free; one barrier per K-tile.  The epilogue
+// goes through LDS so every global store / residual load is a coalesced 16-B
+// access.  Small-M problems (8x8 / 16x16 UNet levels) use split-K into an fp32
+// workspace plus a reduce+epilogue kernel.  Tile ids are remapped so that the
+// tiles sharing an A row-panel land on the same XCD (private L2).
+#pragma once
+#include "ea_platform.h"
+
+#define EA_BK 64
+
+enum { EA_ACT_NONE = 0, EA_ACT_SILU = 1, EA_ACT_GELU = 2, EA_ACT_GEGLU = 3 };
+
+struct EaEpilogue {
+  const float* bias;      // [N] (or [M] if bias_per_row), nullable
+  int bias_per_row;
+  const float* rowvec;    // [groups][rowvec_ld], added per (m / rows_per_group, n), nullable
+  int rowvec_ld;
+  int rows_per_group;
+  int act;                // EA_ACT_*
+  float scale;            // applied after act
+  const float* row_scale; // [M] per-row multiplier (ControlNetModel2 scale map), nullable
+  const f16* residual;    // [M][ldr] fp16, nullable (added after scale)
+  const float* residual32;// [M][ldr] fp32, nullable
+  int ldr;
+  void* out;              // fp16 or fp32 [M][ldc]
+  int ldc;
+  int out_f32;
+  int M, N;               // logical output extent (N = N_gemm/2 for GEGLU)
+};
+
+struct EaGemmParams {
+  // ---- A operand
+  const f16* a1;
+  int c1;  // channels of source 1 (conv) / unused (dense)
+  const f16* a2;
+  int c2;
+  const f16* a2_add;  // optional addend on source 2 (skip + control)
+  int lda;            // dense: row stride in elements
+  int conv;           // 0 dense, 1 implicit conv
+  int ksize;          // 1 or 3
+  int Hin, Win, Hout, Wout;
+  int stride, pad, ups;
+  // ---- W operand [N][ldw]
+  const f16* w;
+  int ldw;
+  int M, N, K;
+  // ---- batching / split-K
+  int batch;
+  long long strideA, strideW, strideC, strideR;
+  int splits;
+  int ktiles_per_split;
+  float* partial;  // [batch*splits][M][N] fp32 when splits > 1
+  EaEpilogue epi;
+};
+
+// XCD-aware bijective remap of a linear workgroup id (guide T1): workgroups are
+// dealt round-robin to the 8 XCDs, so give each XCD a contiguous chunk.
+__device__ __forceinline__ int ea_xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8;
+  const int xcd = bid % 8, idx = bid / 8;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+// Store 8 consecutive outputs (row m, cols n..n+7) with the full epilogue.
+__device__ __forceinline__ void ea_epilogue_store8(const EaEpilogue& e, long long cbase, long long rbase,
+                                                   int m, int n, float v[8], bool apply_act_bias) {
+  if (m >= e.M || n >= e.N) return;
+  const int nvalid = (e.N - n) < 8 ? (e.N - n) : 8;
+  if (apply_act_bias) {
+    if (e.bias) {
+      if (e.bias_per_row) {
+        const float b = e.bias[m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += b;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (j < nvalid) v[j] += e.bias[n + j];
+      }
+    }
+    if (e.rowvec) {
+      const float* rv = e.rowvec + (long long)(m / e.rows_per_group) * e.rowvec_ld + n;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < nvalid) v[j] += rv[j];
+    }
+    if (e.act == EA_ACT_SILU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ea_silu(v[j]);
+    } else if (e.act == EA_ACT_GELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ea_gelu_erf(v[j]);
+    }
+  }
+  float sc = e.scale;
+  if (e.row_scale) sc *= e.row_scale[m];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= sc;
+  const long long roff = rbase + (long long)m * e.ldr + n;
+  const long long coff = cbase + (long long)m * e.ldc + n;
+  const bool vec = (nvalid == 8) && ((e.ldc & 7) == 0) && ((coff & 7) == 0);
+  if (e.residual) {
+    if (vec && ((e.ldr & 7) == 0) && ((roff & 7) == 0)) {
+      f16x8 r = ea_ld8(e.residual + roff);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+    } else {
+      for (int j = 0; j < nvalid; ++j) v[j] += (float)e.residual[roff + j];
+    }
+  }
+  if (e.residual32) {
+    for (int j = 0; j < nvalid; ++j) v[j] += e.residual32[roff + j];
+  }
+  if (e.out_f32) {
+    float* o = (float*)e.out + coff;
+    if (vec) {
+      f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(o) = lo;
+      *reinterpret_cast<f32x4*>(o + 4) = hi;
+    } else {
+      for (int j = 0; j < nvalid; ++j) o[j] = v[j];
+    }
+  } else {
+    f16* o = (f16*)e.out + coff;
+    if (vec) {
+      f16x8 h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) h[j] = (f16)v[j];
+      ea_st8(o, h);
+    } else {
+      for (int j = 0; j < nvalid; ++j) o[j] = (f16)v[j];
+    }
+  }
+}
+
+// WGM x WGN waves, each 64x64.  (2,2) -> 128x128 tile; (4,1) -> 256x64 tile.
+template <int WGM, int WGN>
+__global__ __launch_bounds__(256) void ea_gemm_kernel(EaGemmParams p) {
+  constexpr int BM = WGM * 64, BN = WGN * 64;
+  constexpr int A_VEC = BM / 32, B_VEC = BN / 32;  // 16-B vectors per thread per K-tile
+  constexpr int STAGE_BYTES = (BM + BN) * EA_BK * 2;
+  constexpr int EPI_LD = BN + 4;                   // fp32 words per staged row
+  EA_SMEM(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ntile = tiles_m * tiles_n;
+  const int tile = ea_xcd_remap(blockIdx.x, ntile);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z;
+  const int batch = bz / p.splits, split = bz % p.splits;
+
+  const int nk_total = (p.K + EA_BK - 1) / EA_BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+
+  const f16* a1 = p.a1 + batch * p.strideA;
+  const f16* a2 = p.a2 ? p.a2 + batch * p.strideA : nullptr;
+  const f16* a2_add = p.a2_add ? p.a2_add + batch * p.strideA : nullptr;
+  const f16* wp = p.w + batch * p.strideW;
+
+  // ---- per-thread load coordinates
+  const int chunk = tid & 7;   // which 8-element (16-B) K chunk of the 64-wide tile
+  const int lrow = tid >> 3;   // 0..31
+  const int ctot = p.c1 + p.c2;
+
+  // A rows
+  int a_b[A_VEC], a_y[A_VEC], a_x[A_VEC];
+  bool a_ok[A_VEC];
+#pragma unroll
+  for (int i = 0; i < A_VEC; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < p.M;
+    if (p.conv) {
+      const int hw = p.Hout * p.Wout;
+      const int mm = a_ok[i] ? m : 0;
+      const int b = mm / hw;
+      const int rem = mm - b * hw;
+      const int oy = rem / p.Wout;
+      a_b[i] = b;
+      a_y[i] = oy * p.stride - p.pad;
+      a_x[i] = (rem - oy * p.Wout) * p.stride - p.pad;
+    } else {
+      a_b[i] = m;
+      a_y[i] = 0;
+      a_x[i] = 0;
+    }
+  }
+  // current K position of this thread's chunk: k = kt*64 + chunk*8 -> (tap, cin)
+  int k_cur = kt_begin * EA_BK + chunk * 8;
+  int tap = 0, cin = k_cur;
+  if (p.conv) {
+    tap = k_cur / ctot;
+    cin = k_cur - tap * ctot;
+  }
+
+  f16x8 ra[A_VEC], rb[B_VEC];
+
+  auto load_tile = [&]() {
+    const bool kok = k_cur < p.K;
+    if (p.conv) {
+      const int ky = (p.ksize == 3) ? tap / 3 : 0;
+      const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
+      const f16* src;
+      const f16* src_add = nullptr;
+      int cs, coff;
+      if (cin < p.c1) {
+        src = a1; cs = p.c1; coff = cin;
+      } else {
+        src = a2; cs = p.c2; coff = cin - p.c1; src_add = a2_add;
+      }
+      const int hlim = p.ups ? 2 * p.Hin : p.Hin;
+      const int wlim = p.ups ? 2 * p.Win : p.Win;
+#pragma unroll
+      for (int i = 0; i < A_VEC; ++i) {
+        int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = kok && a_ok[i] && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+        if (ok) {
+          if (p.ups) { iy >>= 1; ix >>= 1; }
+          const long long off = (((long long)a_b[i] * p.Hin + iy) * p.Win + ix) * cs + coff;
+          f16x8 v = ea_ld8(src + off);
+          if (src_add) v = v + ea_ld8(src_add + off);
+          ra[i] = v;
+        } else {
+          ra[i] = ea_zero8();
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_VEC; ++i) {
+        if (kok && a_ok[i]) ra[i] = ea_ld8(a1 + (long long)a_b[i] * p.lda + k_cur);
+        else ra[i] = ea_zero8();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_VEC; ++i) {
+      const int n = n0 + lrow + 32 * i;
+      if (kok && n < p.N) rb[i] = ea_ld8(wp + (long long)n * p.ldw + k_cur);
+      else rb[i] = ea_zero8();
+    }
+    // advance to the next K tile
+    k_cur += EA_BK;
+    if (p.conv) {
+      cin += EA_BK;
+      while (cin >= ctot) { cin -= ctot; ++tap; }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + BM * EA_BK * 2;
+#pragma unroll
+    for (int i = 0; i < A_VEC; ++i) {
+      const int r = lrow + 32 * i;
+      *reinterpret_cast<f16x8*>(sa + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_VEC; ++i) {
+      const int r = lrow + 32 * i;
+      *reinterpret_cast<f16x8*>(sb + r * 128 + ((chunk ^ ((r >> 1) & 7)) << 4)) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) load_tile();
+      const char* sa = smem + cur * STAGE_BYTES;
+      const char* sb = sa + BM * EA_BK * 2;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int ch = 2 * ks + (lane >> 5);
+        f16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r = wm * 64 + i * 32 + (lane & 31);
+          fa[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = wn * 64 + j * 32 + (lane & 31);
+          fb[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ((r >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = ea_mfma_32x32x16(fa[i], fb[j], acc[i][j]);
+      }
+      if (kt + 1 < nk) store_tile(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------- epilogue
+  // Phase 1: accumulators -> LDS (fp32, padded rows).  Phase 2: each thread
+  // takes 8 consecutive columns of one row -> coalesced 16-B global accesses.
+  float* stg = reinterpret_cast<float*>(smem);
+  const EaEpilogue& e = p.epi;
+  const bool raw = p.splits > 1;
+  const bool geglu = (!raw) && e.act == EA_ACT_GEGLU;
+  const int col = lane & 31;
+  if (geglu) {
+    // value columns live in MFMA tile j=0, gate columns in j=1 (weights are packed that way).
+    const int nv = n0 + wn * 64 + col;
+    const float bv = (e.bias && nv < p.N) ? e.bias[nv] : 0.0f;
+    const float bg = (e.bias && nv + 32 < p.N) ? e.bias[nv + 32] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + ea_mfma_row(r, lane);
+        const float val = acc[i][0][r] + bv;
+        const float gate = acc[i][1][r] + bg;
+        stg[row * EPI_LD + wn * 32 + col] = val * ea_gelu_erf(gate);
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 64 + i * 32 + ea_mfma_row(r, lane);
+          stg[row * EPI_LD + wn * 64 + j * 32 + col] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  const int tile_cols = geglu ? BN / 2 : BN;
+  const int ncol0 = geglu ? n0 / 2 : n0;
+  constexpr int VEC_PER_ROW_MAX = BN / 8;
+  const int vec_per_row = tile_cols / 8;
+  (void)VEC_PER_ROW_MAX;
+  for (int idx = tid; idx < BM * vec_per_row; idx += 256) {
+    const int row = idx / vec_per_row;
+    const int cv = (idx - row * vec_per_row) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = stg[row * EPI_LD + cv + j];
+    const int m = m0 + row, n = ncol0 + cv;
+    if (raw) {
+      if (m < p.M && n < p.N) {
+        float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
+        const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+        for (int j = 0; j < nvalid; ++j) dst[j] = v[j];
+      }
+    } else {
+      ea_epilogue_store8(e, batch * p.strideC, batch * p.strideR, m, n, v, !geglu);
+    }
+  }
+}
+
+// Reduce split-K partials and run the epilogue.  One thread per 8 outputs.
+__global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
+  const long long vec_per_row = (p.N + 7) / 8;
+  const long long total = (long long)p.batch * p.M * vec_per_row;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int batch = (int)(idx / (p.M * vec_per_row));
+    const long long rem = idx - (long long)batch * p.M * vec_per_row;
+    const int m = (int)(rem / vec_per_row);
+    const int n = (int)(rem - (long long)m * vec_per_row) * 8;
+    const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.0f;
+    for (int s = 0; s < p.splits; ++s) {
+      const float* src = p.partial + ((long long)(batch * p.splits + s) * p.M + m) * p.N + n;
+      for (int j = 0; j < nvalid; ++j) v[j] += src[j];
+    }
+    ea_epilogue_store8(p.epi, batch * p.strideC, batch * p.strideR, m, n, v, true);
+  }
+}

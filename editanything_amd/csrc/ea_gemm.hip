@@ -1,0 +1,170 @@
+// ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
+#include "ea_gemm.h"
+#include "../../include/editanything_hip.h"
+
+namespace {
+
+struct TilePlan {
+  int wide;    // 1: 128x128 tile, 0: 256x64 tile
+  int bm, bn;
+  int tiles;
+  int splits;
+  int ktiles_per_split;
+};
+
+static TilePlan plan_tiles(int M, int N, int K, int batch, int allow_split) {
+  TilePlan t;
+  const int pad128 = ((N + 127) / 128) * 128;
+  const int pad64 = ((N + 63) / 64) * 64;
+  t.wide = (pad64 < pad128) ? 0 : 1;
+  t.bm = t.wide ? 128 : 256;
+  t.bn = t.wide ? 128 : 64;
+  t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
+  const int nk = (K + EA_BK - 1) / EA_BK;
+  int splits = 1;
+  const long long blocks = (long long)t.tiles * batch;
+  if (allow_split && blocks < 256 && nk >= 8) {
+    splits = (int)((512 + blocks - 1) / blocks);
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  t.ktiles_per_split = (nk + splits - 1) / splits;
+  t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
+  return t;
+}
+
+static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
+  if (!epi || !epi->out) return EA_ERR_BAD_ARG;
+  e.bias = epi->bias;
+  e.bias_per_row = epi->bias_per_row;
+  e.rowvec = epi->rowvec;
+  e.rowvec_ld = epi->rowvec_ld;
+  e.rows_per_group = epi->rows_per_group > 0 ? epi->rows_per_group : 1;
+  e.act = epi->act;
+  e.scale = epi->scale;
+  e.row_scale = epi->row_scale;
+  e.residual = (const f16*)epi->residual;
+  e.residual32 = epi->residual32;
+  e.ldr = epi->ldr;
+  e.out = epi->out;
+  e.ldc = epi->ldc;
+  e.out_f32 = epi->out_f32;
+  e.M = M;
+  e.N = (epi->act == EA_ACT_GEGLU) ? N / 2 : N;
+  if (epi->act < 0 || epi->act > EA_ACT_GEGLU) return EA_ERR_BAD_ARG;
+  if (epi->act == EA_ACT_GEGLU && (N % 64) != 0) return EA_ERR_BAD_SHAPE;
+  if (epi->act == EA_ACT_GEGLU && epi->bias_per_row) return EA_ERR_UNSUPPORTED;
+  if (e.ldc < e.N) return EA_ERR_BAD_SHAPE;
+  if ((e.residual || e.residual32) && e.ldr < e.N) return EA_ERR_BAD_SHAPE;
+  return EA_OK;
+}
+
+static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
+  const int allow_split = (p.epi.act != EA_ACT_GEGLU);
+  TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);
+  p.splits = t.splits;
+  p.ktiles_per_split = t.ktiles_per_split;
+  p.partial = nullptr;
+  if (t.splits > 1) {
+    const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
+    if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
+  }
+  dim3 grid(t.tiles, 1, p.batch * t.splits);
+  dim3 block(256, 1, 1);
+  if (t.wide) {
+    auto kfn = ea_gemm_kernel<2, 2>;
+    const int main_b = 2 * (128 + 128) * EA_BK * 2, epi_b = 128 * (128 + 4) * 4;
+    const int smem = main_b > epi_b ? main_b : epi_b;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+  } else {
+    auto kfn = ea_gemm_kernel<4, 1>;
+    const int main_b = 2 * (256 + 64) * EA_BK * 2, epi_b = 256 * (64 + 4) * 4;
+    const int smem = main_b > epi_b ? main_b : epi_b;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+  }
+  int st = ea_launch_status();
+  if (st != EA_OK) return st;
+  if (t.splits > 1) {
+    const long long total = (long long)p.batch * p.M * ((p.N + 7) / 8);
+    long long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    auto rfn = ea_splitk_reduce_kernel;
+    EA_LAUNCH(rfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
+    st = ea_launch_status();
+  }
+  return st;
+}
+
+}  // namespace
+
+extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
+  TilePlan t = plan_tiles(M, N, K, batch, 1);
+  if (t.splits <= 1) return 0;
+  return (size_t)batch * t.splits * M * N * sizeof(float);
+}
+
+extern "C" int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
+                           long long strideA, long long strideW, long long strideC, long long strideR,
+                           const ea_epilogue* epi, void* workspace, size_t ws_bytes, void* stream) {
+  if (!A || !W) return EA_ERR_BAD_ARG;
+  if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return EA_ERR_BAD_SHAPE;
+  if ((K & 7) || (lda & 7) || (ldw & 7) || lda < K || ldw < K) return EA_ERR_BAD_SHAPE;
+  if ((strideA & 7) || (strideW & 7)) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return EA_ERR_BAD_ARG;
+  EaGemmParams p;
+  memset(&p, 0, sizeof(p));
+  int st = fill_epilogue(p.epi, epi, M, N);
+  if (st != EA_OK) return st;
+  p.a1 = (const f16*)A;
+  p.lda = lda;
+  p.conv = 0;
+  p.w = (const f16*)W;
+  p.ldw = ldw;
+  p.M = M; p.N = N; p.K = K;
+  p.batch = batch;
+  p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideR = strideR;
+  return launch_gemm(p, workspace, ws_bytes, stream);
+}
+
+static int setup_conv(EaGemmParams& p, const ea_conv_src* s, const void* W, int Cout, const ea_epilogue* epi) {
+  if (!s || !s->x1 || !W) return EA_ERR_BAD_ARG;
+  if (s->ksize != 1 && s->ksize != 3) return EA_ERR_UNSUPPORTED;
+  if (s->stride != 1 && s->stride != 2) return EA_ERR_UNSUPPORTED;
+  if (s->B <= 0 || s->Hin <= 0 || s->Win <= 0 || s->Hout <= 0 || s->Wout <= 0 || Cout <= 0) return EA_ERR_BAD_SHAPE;
+  if (s->c1 <= 0 || (s->c1 & 7) || (s->c2 & 7) || s->c2 < 0) return EA_ERR_BAD_SHAPE;
+  if (s->c2 > 0 && !s->x2) return EA_ERR_BAD_ARG;
+  if (((uintptr_t)s->x1 & 15) || ((uintptr_t)s->x2 & 15) || ((uintptr_t)s->x2_add & 15) || ((uintptr_t)W & 15))
+    return EA_ERR_BAD_ARG;
+  const long long M = (long long)s->B * s->Hout * s->Wout;
+  if (M > 0x7fffffffLL) return EA_ERR_BAD_SHAPE;
+  const int ctot = s->c1 + s->c2;
+  memset(&p, 0, sizeof(p));
+  int st = fill_epilogue(p.epi, epi, (int)M, Cout);
+  if (st != EA_OK) return st;
+  p.a1 = (const f16*)s->x1; p.c1 = s->c1;
+  p.a2 = s->c2 > 0 ? (const f16*)s->x2 : nullptr; p.c2 = s->c2;
+  p.a2_add = s->c2 > 0 ? (const f16*)s->x2_add : nullptr;
+  p.conv = 1;
+  p.ksize = s->ksize;
+  p.Hin = s->Hin; p.Win = s->Win; p.Hout = s->Hout; p.Wout = s->Wout;
+  p.stride = s->stride; p.pad = s->pad; p.ups = s->ups;
+  p.w = (const f16*)W;
+  p.K = s->ksize * s->ksize * ctot;
+  p.ldw = p.K;
+  p.M = (int)M; p.N = Cout;
+  p.batch = 1;
+  return EA_OK;
+}
+
+extern "C" int ea_conv2d_f16(const ea_conv_src* src, const void* W, int Cout, const ea_epilogue* epi,
+                             void* workspace, size_t ws_bytes, void* stream) {
+  EaGemmParams p;
+  int st = setup_conv(p, src, W, Cout, epi);
+  if (st != EA_OK) return st;
+  return launch_gemm(p, workspace, ws_bytes, stream);
+}

@@ -1,0 +1,160 @@
+/* editanything_hip.h -- C ABI of libeditanything_hip.so (gfx950 / MI355X).
+ *
+ * The reference (sail-sg/EditAnything) is 100 % Python and has no FFI; its
+ * operator swap points are the ones SURVEY.md section 8(b) "B3" lists.  Each entry
+ * point below is what a binding for that swap point calls:
+ *
+ *   ea_attention_f16          <- xformers.ops.memory_efficient_attention(q,k,v)
+ *                                ldm/modules/attention.py:223-233, the einsum path
+ *                                :163-194, cldm/hack.py:72-111; SAM Attention.forward
+ *                                (segment_anything, 3rd party) with decomposed rel-pos
+ *   ea_relpos_tables_f16      <- segment_anything add_decomposed_rel_pos (3rd party)
+ *   ea_groupnorm_f16          <- GroupNorm32 + SiLU, ldm/modules/diffusionmodules/util.py:217-219,
+ *                                openaimodel.py:200-204,221-224; attention.py:88-89; model.py:46-47
+ *   ea_conv2d_f16             <- conv_nd 3x3/1x1 in ResBlock / Upsample / Downsample
+ *                                openaimodel.py:108-152,200-231,254-274; model.py:68-149;
+ *                                ControlNet hint block + zero-convs cldm/cldm.py:147-163,281-305
+ *   ea_groupnorm_silu_conv3x3 <- ResBlock in_layers / out_layers as one call (openaimodel.py:254-274)
+ *   ea_layernorm_f16, ea_gemm_f16, ea_ln_gemm_f16
+ *                             <- BasicTransformerBlock / GEGLU / SpatialTransformer Linears
+ *                                ldm/modules/attention.py:49-76,152-160,263-275,316-339
+ *   ea_cfg_ddim_step          <- DDIMSampler.p_sample_ddim, cldm/ddim_hacked.py:187-231
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (PyTorch
+ * allocates; the library never allocates, frees or synchronises); activations
+ * are fp16 NHWC ("channels last": [B,H,W,C] == tokens [B,H*W,C]); weights are
+ * fp16 [N][K] with K contiguous (conv: K = (ky*3+kx)*Cin + cin); biases fp32.
+ * `stream` is a hipStream_t.  Return 0 on success, a negative EA_ERR_* code on
+ * bad shapes / unsupported configs / launch failure; nothing throws.
+ * Stateless and re-entrant: one process per GPU, any number of streams.
+ */
+#ifndef EDITANYTHING_HIP_H
+#define EDITANYTHING_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EA_OK 0
+#define EA_ERR_BAD_SHAPE (-1)
+#define EA_ERR_BAD_ARG (-2)
+#define EA_ERR_UNSUPPORTED (-3)
+#define EA_ERR_WORKSPACE (-4)
+#define EA_ERR_LAUNCH (-5)
+
+#define EA_ACT_NONE 0
+#define EA_ACT_SILU 1
+#define EA_ACT_GELU 2  /* exact erf GELU */
+#define EA_ACT_GEGLU 3 /* weight rows packed [32 value | 32 gate] per 64; N_out = N/2 */
+
+/* Fused GEMM/conv epilogue: out = residual + scale*row_scale[m]*act(acc + bias + rowvec[m/rows_per_group]) */
+typedef struct ea_epilogue {
+  const float* bias;      /* [N] (or [M] if bias_per_row); may be NULL */
+  int32_t bias_per_row;
+  const float* rowvec;    /* [groups][rowvec_ld] e.g. time-embedding projection; may be NULL */
+  int32_t rowvec_ld;
+  int32_t rows_per_group; /* rows (pixels) per sample */
+  int32_t act;            /* EA_ACT_* */
+  float scale;            /* ControlNet conditioning scale; 1.0 otherwise */
+  const float* row_scale; /* [M] spatial scale map (ControlNetModel2), may be NULL */
+  const void* residual;   /* fp16 [M][ldr], may be NULL, may alias out */
+  const float* residual32;/* fp32 [M][ldr], may be NULL, may alias out */
+  int32_t ldr;
+  void* out;              /* fp16 (out_f32=0) or fp32 [M][ldc] */
+  int32_t ldc;
+  int32_t out_f32;
+} ea_epilogue;
+
+/* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and
+ * optional x2 (c2 ch, optionally + x2_add), never materialised. */
+typedef struct ea_conv_src {
+  const void* x1; int32_t c1;
+  const void* x2; int32_t c2;
+  const void* x2_add;
+  int32_t B, Hin, Win;
+  int32_t ksize;   /* 1 or 3 */
+  int32_t stride;  /* 1 or 2 */
+  int32_t pad;     /* low-side zero padding (high side is implied by Hout/Wout) */
+  int32_t ups;     /* 1: conv reads the nearest-2x upsampled input */
+  int32_t Hout, Wout;
+} ea_conv_src;
+
+/* library / device info */
+int ea_version(void);
+int ea_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
+
+/* Bytes of fp32 workspace ea_gemm_f16 / ea_conv2d_f16 need for this problem (split-K). */
+size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch);
+
+/* C[b] = epilogue(A[b] (MxK, lda) * W[b]^T (NxK, ldw)), b < batch. */
+int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
+                long long strideA, long long strideW, long long strideC, long long strideR,
+                const ea_epilogue* epi, void* workspace, size_t ws_bytes, void* stream);
+
+/* Implicit-GEMM convolution; M = B*Hout*Wout, K = ksize^2*(c1+c2), W [Cout][K]. */
+int ea_conv2d_f16(const ea_conv_src* src, const void* W, int Cout, const ea_epilogue* epi,
+                  void* workspace, size_t ws_bytes, void* stream);
+
+/* GroupNorm (+ optional SiLU) on NHWC fp16, statistics in fp32.
+ * workspace: ea_groupnorm_workspace_bytes(B, HW, C, groups). */
+size_t ea_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
+int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, const void* x2_add,
+                     const float* gamma, const float* beta, void* out, int B, int HW, int groups,
+                     float eps, int silu, void* workspace, size_t ws_bytes, void* stream);
+
+/* ResBlock half: out = epilogue(conv3x3(silu(groupnorm(cat(x1,x2+x2_add))))) -- one call.
+ * `norm_out` is caller scratch [B*Hin*Win*(c1+c2)] fp16 for the normalised activation. */
+int ea_groupnorm_silu_conv3x3(const ea_conv_src* src, const float* gamma, const float* beta, int groups,
+                              float eps, void* norm_out, const void* W, int Cout, const ea_epilogue* epi,
+                              void* workspace, size_t ws_bytes, void* stream);
+
+/* LayerNorm over the last dim of [M][C]; in_f32 selects an fp32 input (residual stream). Output fp16. */
+int ea_layernorm_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
+                     int M, int C, float eps, void* stream);
+
+/* LayerNorm followed by GEMM (BasicTransformerBlock norm -> to_q / GEGLU proj). `ln_out` scratch [M][K] fp16. */
+int ea_ln_gemm_f16(const void* x, int in_f32, const float* gamma, const float* beta, float eps, void* ln_out,
+                   const void* W, int ldw, int M, int N, int K, const ea_epilogue* epi,
+                   void* workspace, size_t ws_bytes, void* stream);
+
+/* Flash-style attention.  q/k/v element (b, i, h, d) at ptr + b*s_b + i*s_n + h*D + d (fp16).
+ * out [B][Nq][H*D] fp16 (row stride o_sn).  Optional decomposed rel-pos bias (SAM):
+ * bias_h/bias_w fp32 [B*H][Nq][S]; key j -> (j / S, j % S); S = 0 disables. D in {40,64,80,160}. */
+int ea_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk,
+                     int D, long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb,
+                     long long v_sn, long long o_sb, long long o_sn, float scale, const float* bias_h,
+                     const float* bias_w, int S, void* stream);
+
+/* SAM decomposed rel-pos tables: bias_h[bh][q][kh] = sum_c q[bh,q,c]*Rh[qh - kh + S - 1][c] (same for w),
+ * q strided like ea_attention_f16, rel_h/rel_w fp16 [2S-1][D], tokens q = qh*S + qw. */
+int ea_relpos_tables_f16(const void* q, int B, int H, int S, int D, long long q_sb, long long q_sn,
+                         const void* rel_h, const void* rel_w, float* bias_h, float* bias_w, void* stream);
+
+/* Row softmax on fp32 [rows][cols] -> fp16 (VAE single-head d=512 attention path). */
+int ea_softmax_rows_f32_f16(const float* x, void* out, int rows, int cols, float scale, void* stream);
+
+/* One fused elementwise kernel per sampler step (cldm/ddim_hacked.py:187-231):
+ *   eps = eps_u + g*(eps_c - eps_u);  [v-pred: eps = sqrt(a_t)*v + sqrt(1-a_t)*x]
+ *   x0 = (x - sqrt(1-a_t)*eps)/sqrt(a_t); x_prev = sqrt(a_prev)*x0 + sqrt(1-a_prev-sigma^2)*eps + sigma*noise
+ *   optional inpaint blend: x_prev = mask*x_prev + (1-mask)*(sqrt(a_prev)*x_orig + sqrt(1-a_prev)*noise_orig)
+ * All tensors fp32 [n]; eps_u may be NULL (no CFG); coef = {a_t, a_prev, sigma, guidance, vpred}. */
+int ea_cfg_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise,
+                     const float* coef, const float* mask, const float* x_orig, const float* noise_orig,
+                     float* x_prev, float* pred_x0, long long n, void* stream);
+
+/* Layout plumbing on device: NCHW fp32 -> NHWC fp16 with channel padding, and back. */
+int ea_nchw_f32_to_nhwc_f16(const float* x, void* out, int B, int C, int H, int W, int Cpad, float mul,
+                            float add, void* stream);
+int ea_nhwc_f16_to_nchw_f32(const void* x, float* out, int B, int C, int H, int W, int Cstride,
+                            float mul, float add, void* stream);
+
+/* y = silu(x) on fp32 -> fp16 / fp32 small vectors (time-embedding MLP). */
+int ea_silu_f32(const float* x, float* out, long long n, void* stream);
+/* out = a + b (fp16), n % 8 == 0. */
+int ea_add_f16(const void* a, const void* b, void* out, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

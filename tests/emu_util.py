@@ -1,0 +1,55 @@
+"""Helpers shared by the emulation tests: numpy <-> C-ABI argument plumbing."""
+import numpy as np
+
+from editanything_amd import _lib as L
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual32=None, ldr=None, rowvec=None,
+             rows_per_group=1, row_scale=None, bias_per_row=0):
+    e = L.Epilogue()
+    e.bias = ptr(bias)
+    e.bias_per_row = bias_per_row
+    e.rowvec = ptr(rowvec)
+    e.rowvec_ld = 0 if rowvec is None else rowvec.shape[-1]
+    e.rows_per_group = rows_per_group
+    e.act = act
+    e.scale = scale
+    e.row_scale = ptr(row_scale)
+    e.residual = ptr(residual)
+    e.residual32 = ptr(residual32)
+    n = out.shape[-1]
+    e.ldr = n if ldr is None else ldr
+    e.out = ptr(out)
+    e.ldc = n if ldc is None else ldc
+    e.out_f32 = int(out.dtype == np.float32)
+    return e
+
+
+def conv_src(x1, x2=None, x2_add=None, ksize=3, stride=1, pad=1, ups=0, hout=None, wout=None):
+    B, H, W, c1 = x1.shape
+    s = L.ConvSrc()
+    s.x1 = ptr(x1)
+    s.c1 = c1
+    s.x2 = ptr(x2)
+    s.c2 = 0 if x2 is None else x2.shape[-1]
+    s.x2_add = ptr(x2_add)
+    s.B, s.Hin, s.Win = B, H, W
+    s.ksize, s.stride, s.pad, s.ups = ksize, stride, pad, ups
+    hl, wl = (2 * H, 2 * W) if ups else (H, W)
+    s.Hout = hout if hout is not None else (hl + 2 * pad - ksize) // stride + 1
+    s.Wout = wout if wout is not None else (wl + 2 * pad - ksize) // stride + 1
+    return s
+
+
+def workspace(nbytes):
+    return np.zeros(max(int(nbytes), 16) // 4 + 4, np.float32)
+
+
+def relerr(got, ref):
+    got = np.asarray(got, np.float32)
+    ref = np.asarray(ref, np.float32)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
