@@ -14,9 +14,26 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def emu():
+def emu_lib():
     """Host emulation build of the HIP kernels (tests/emu) bound through the same ctypes prototypes."""
     from editanything_amd.csrc import build
     from editanything_amd import _lib
     path = build.build_emu(verbose=False)
     return _lib.bind(path)
+
+
+@pytest.fixture(params=["emu", pytest.param("gpu", marks=pytest.mark.gpu)])
+def kb(request):
+    """Kernel backend: the same op tests run on the CPU emulation and (with -m gpu) on the MI355X."""
+    import emu_util
+    if request.param == "emu":
+        be = emu_util.HostBackend(request.getfixturevalue("emu_lib"))
+    else:
+        import torch
+        assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+        from editanything_amd import _lib
+        be = emu_util.GpuBackend(_lib.lib())
+    emu_util.BACKEND = be
+    yield be
+    be.keep.clear()
+    emu_util.BACKEND = None

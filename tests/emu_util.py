@@ -4,8 +4,76 @@ import numpy as np
 from editanything_amd import _lib as L
 
 
+class HostBackend:
+    """numpy buffers + the emulation library (tests/emu)."""
+    name = "emu"
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.keep = []
+        self.stream = None
+
+    def up(self, a):
+        a = np.ascontiguousarray(a)
+        self.keep.append(a)
+        return a
+
+    def zeros(self, shape, dtype):
+        return self.up(np.zeros(shape, dtype))
+
+    def down(self, a):
+        return a
+
+    def sync(self):
+        pass
+
+
+class GpuBackend:
+    """torch device buffers + the real gfx950 library."""
+    name = "gpu"
+
+    def __init__(self, lib):
+        import torch
+        self.torch = torch
+        self.lib = lib
+        self.keep = []
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def up(self, a):
+        t = self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        self.keep.append(t)
+        return t
+
+    def zeros(self, shape, dtype):
+        return self.up(np.zeros(shape, dtype))
+
+    def down(self, a):
+        self.torch.cuda.synchronize()
+        return a.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+BACKEND = None
+
+
 def ptr(a):
-    return None if a is None else a.ctypes.data
+    """Device/host address of a buffer; numpy inputs are uploaded (and kept alive) on the GPU backend."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        if BACKEND is not None and BACKEND.name == "gpu":
+            return BACKEND.up(a).data_ptr()
+        if BACKEND is not None:
+            BACKEND.keep.append(a)
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+def _is_f32(a):
+    return "float32" in str(a.dtype)
 
 
 def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual32=None, ldr=None, rowvec=None,
@@ -25,7 +93,7 @@ def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual
     e.ldr = n if ldr is None else ldr
     e.out = ptr(out)
     e.ldc = n if ldc is None else ldc
-    e.out_f32 = int(out.dtype == np.float32)
+    e.out_f32 = int(_is_f32(out))
     return e
 
 
