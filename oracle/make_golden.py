@@ -1,0 +1,222 @@
+"""ORACLE -- TEST INFRASTRUCTURE.  Generate tests/golden/*.npz from the REAL reference code.
+
+Run in the build container (where /root/reference exists):   python -m oracle.make_golden
+
+For each piece of the hot path it instantiates the reference's own class (imported from /root/reference,
+oracle/ref_import.py) at a CPU-sized configuration (editanything_amd.arch.TINY_*), loads the seeded synthetic
+state dict (editanything_amd.synth, zero-modules re-randomised), runs the reference forward on seeded inputs and
+stores inputs + outputs.  It also asserts that oracle/ldm_oracle.py / sam_oracle.py / host_oracle.py reproduce
+the reference to fp32 round-off -- this is what pins the oracle.
+SAM: segment_anything is absent; the pin is transformers' SamVisionEncoder (independent port).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from editanything_amd import arch, synth  # noqa: E402  (data only: shapes + seeded weights)
+from oracle import host_oracle, ldm_oracle, ref_import, sam_oracle  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SEED = 7
+
+
+def rnd(shape, seed, scale=1.0):
+    return torch.from_numpy((np.random.default_rng(seed).standard_normal(shape) * scale).astype(np.float32))
+
+
+def tiny_inputs():
+    x = rnd((2, 4, 16, 16), 101)
+    # id-map style hint: ch0 = id % 256, ch1 = id // 256, ch2 = 0, values 0..255 un-normalised (sam2image.py:110-112,158)
+    rng = np.random.default_rng(102)
+    ids = rng.integers(0, 40, size=(2, 8, 8)).repeat(16, 1).repeat(16, 2)
+    hint = np.zeros((2, 3, 128, 128), np.float32)
+    hint[:, 0] = ids % 256
+    hint[:, 1] = ids // 256
+    t = torch.tensor([601, 401], dtype=torch.long)
+    ctx = rnd((2, 77, arch.TINY_UNET["context_dim"]), 103)
+    return x, torch.from_numpy(hint), t, ctx
+
+
+def close(a, b, tol, what):
+    err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    print(f"  oracle vs reference [{what}]: rel-max {err:.2e}")
+    assert err < tol, what
+    return err
+
+
+def gen_ldm(ns):
+    torch.manual_seed(0)
+    cn_cfg, un_cfg = arch.TINY_CONTROLNET, arch.TINY_UNET
+    common = dict(image_size=32, use_checkpoint=False, use_spatial_transformer=True, legacy=False)
+    ref_cn = ns.ControlNet(**{k: v for k, v in cn_cfg.items() if k != "out_channels"}, **common).eval()
+    ref_un = ns.ControlledUnetModel(**un_cfg, **common).eval()
+    cn_shapes = arch.unet_param_shapes(cn_cfg, controlnet=True)
+    un_shapes = arch.unet_param_shapes(un_cfg)
+    # the arch tables must equal the reference's own state dicts (names AND shapes)
+    for shapes, mod, name in ((cn_shapes, ref_cn, "ControlNet"), (un_shapes, ref_un, "UNet")):
+        rs = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        assert rs == {k: tuple(v) for k, v in shapes.items()}, f"{name} state-dict table mismatch"
+    cn_sd = synth.synth_state_dict_torch(cn_shapes, SEED)
+    un_sd = synth.synth_state_dict_torch(un_shapes, SEED + 1)
+    ref_cn.load_state_dict(cn_sd)
+    ref_un.load_state_dict(un_sd)
+    x, hint, t, ctx = tiny_inputs()
+    with torch.no_grad():
+        ctrl = ref_cn(x=x, hint=hint, timesteps=t, context=ctx)
+        scales = [0.825 ** (12 - i) for i in range(len(ctrl))]     # tools/sam2image_ori_version.py:142-143
+        eps_ctrl = ref_un(x=x, timesteps=t, context=ctx, control=[c * s for c, s in zip(ctrl, scales)],
+                          only_mid_control=False)
+        eps_plain = ref_un(x=x, timesteps=t, context=ctx, control=None, only_mid_control=False)
+        o_ctrl = ldm_oracle.controlnet_forward(cn_sd, cn_cfg, x, hint, t, ctx)
+        for i, (a, b) in enumerate(zip(o_ctrl, ctrl)):
+            close(a, b, 2e-4, f"controlnet out {i}")
+        o_eps = ldm_oracle.controlled_unet_forward(un_sd, un_cfg, x, t, ctx, [c * s for c, s in zip(ctrl, scales)])
+        close(o_eps, eps_ctrl, 2e-4, "unet eps (control)")
+        close(ldm_oracle.controlled_unet_forward(un_sd, un_cfg, x, t, ctx, None), eps_plain, 2e-4, "unet eps (plain)")
+    np.savez_compressed(os.path.join(GOLD, "ldm_tiny_eval.npz"), x=x.numpy(), hint=hint.numpy(), t=t.numpy(),
+                        ctx=ctx.numpy(), scales=np.asarray(scales, np.float32), eps_ctrl=eps_ctrl.numpy(),
+                        eps_plain=eps_plain.numpy(), **{f"ctrl_{i}": c.numpy() for i, c in enumerate(ctrl)})
+
+    # ---- DDIM: the reference sampler class driving the reference networks (4 steps, CFG 9, eta 0)
+    class Model:   # the attributes DDIMSampler reads from ControlLDM (ddpm.py:138-192)
+        parameterization = "eps"
+        num_timesteps = 1000
+        device = torch.device("cpu")
+
+        def __init__(self):
+            betas = ns.util.make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)
+            ac = np.cumprod(1.0 - betas, axis=0)
+            f = lambda a: torch.tensor(a, dtype=torch.float32)
+            self.betas = f(betas)
+            self.alphas_cumprod = f(ac)
+            self.alphas_cumprod_prev = f(np.append(1.0, ac[:-1]))
+
+        def apply_model(self, x_noisy, t_, cond):   # == ControlLDM.apply_model, cldm/cldm.py:328-341
+            txt = torch.cat(cond["c_crossattn"], 1)
+            if cond["c_concat"] is None:
+                return ref_un(x=x_noisy, timesteps=t_, context=txt, control=None, only_mid_control=False)
+            c = ref_cn(x=x_noisy, hint=torch.cat(cond["c_concat"], 1), timesteps=t_, context=txt)
+            return ref_un(x=x_noisy, timesteps=t_, context=txt, control=[ci * 1.0 for ci in c], only_mid_control=False)
+
+    class CpuSampler(ns.DDIMSampler):
+        def register_buffer(self, name, attr):   # the reference forces .cuda() here (ddim_hacked.py:17-21)
+            setattr(self, name, attr)
+
+    model = Model()
+    sampler = CpuSampler(model)
+    un_ctx = rnd((2, 77, arch.TINY_UNET["context_dim"]), 104)
+    cond = {"c_concat": [hint], "c_crossattn": [ctx]}
+    uncond = {"c_concat": [hint], "c_crossattn": [un_ctx]}
+    x_T = rnd((2, 4, 16, 16), 105)
+    with torch.no_grad():
+        samples, _ = sampler.sample(4, 2, (4, 16, 16), cond, verbose=False, eta=0.0, x_T=x_T,
+                                    unconditional_guidance_scale=9.0, unconditional_conditioning=uncond)
+
+        def model_fn(xx, tt, c):
+            return ldm_oracle.apply_model(un_sd, un_cfg, cn_sd, cn_cfg, xx, tt, c["ctx"], c["hint"])
+        o = ldm_oracle.ddim_sample(model_fn, x_T, dict(ctx=ctx, hint=hint), dict(ctx=un_ctx, hint=hint), 4, 9.0, 0.0)
+        close(o, samples, 1e-3, "4-step DDIM latents")
+    sch = ldm_oracle.make_ddim_schedule(4, 0.0)
+    assert np.array_equal(sch["timesteps"], sampler.ddim_timesteps)
+    assert np.allclose(sch["alphas"], np.asarray(sampler.ddim_alphas), rtol=1e-6)
+    assert np.allclose(sch["alphas_prev"], np.asarray(sampler.ddim_alphas_prev), rtol=1e-6)
+    np.savez_compressed(os.path.join(GOLD, "ldm_tiny_ddim.npz"), x_T=x_T.numpy(), hint=hint.numpy(), ctx=ctx.numpy(),
+                        un_ctx=un_ctx.numpy(), samples=samples.numpy(), ddim_timesteps=sampler.ddim_timesteps,
+                        ddim_alphas=np.asarray(sampler.ddim_alphas), ddim_alphas_prev=np.asarray(sampler.ddim_alphas_prev))
+    # 20-step schedule of BASELINE config 2
+    s20 = CpuSampler(model)
+    s20.make_schedule(20, ddim_eta=0.0, verbose=False)
+    np.savez_compressed(os.path.join(GOLD, "ddim_schedule_20.npz"), timesteps=s20.ddim_timesteps,
+                        alphas=np.asarray(s20.ddim_alphas), alphas_prev=np.asarray(s20.ddim_alphas_prev),
+                        sigmas=np.asarray(s20.ddim_sigmas))
+
+
+def gen_vae(ns):
+    cfg = arch.TINY_VAE
+    dd = dict(ch=cfg["ch"], out_ch=cfg["out_ch"], ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"],
+              attn_resolutions=[], in_channels=cfg["in_channels"], resolution=64, z_channels=cfg["z_channels"],
+              double_z=True)
+    enc, dec = ns.Encoder(**dd).eval(), ns.Decoder(**dd).eval()
+    shapes = arch.vae_param_shapes(cfg)
+    sd = synth.synth_state_dict_torch(shapes, SEED + 2)
+    for pfx, mod in (("encoder.", enc), ("decoder.", dec)):
+        rs = {pfx + k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        assert rs == {k: tuple(v) for k, v in shapes.items() if k.startswith(pfx)}, "VAE table mismatch"
+        mod.load_state_dict({k[len(pfx):]: v for k, v in sd.items() if k.startswith(pfx)})
+    z = rnd((2, 4, 8, 8), 201)
+    img = rnd((2, 3, 64, 64), 202, 0.5)
+    import torch.nn.functional as F
+    with torch.no_grad():
+        d = dec(F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]))      # autoencoder.py:87-91
+        moments = F.conv2d(enc(img), sd["quant_conv.weight"], sd["quant_conv.bias"])          # autoencoder.py:82-86
+        close(ldm_oracle.vae_decode(sd, cfg, z), d, 2e-4, "vae decode")
+        mean, logvar = ldm_oracle.vae_encode_moments(sd, cfg, img)
+        close(torch.cat([mean, logvar], 1), torch.cat([moments[:, :4], moments[:, 4:].clamp(-30, 20)], 1), 2e-4, "vae enc")
+    np.savez_compressed(os.path.join(GOLD, "ldm_tiny_vae.npz"), z=z.numpy(), img=img.numpy(), decoded=d.numpy(),
+                        moments=moments.numpy())
+
+
+def gen_sam():
+    from transformers.models.sam.configuration_sam import SamVisionConfig
+    from transformers.models.sam.modeling_sam import SamVisionEncoder
+    cfg = arch.TINY_SAM
+    hf_cfg = SamVisionConfig(hidden_size=cfg["embed_dim"], output_channels=cfg["out_chans"], num_hidden_layers=cfg["depth"],
+                             num_attention_heads=cfg["num_heads"], num_channels=3, image_size=cfg["img_size"],
+                             patch_size=cfg["patch_size"], hidden_act="gelu", layer_norm_eps=1e-6, qkv_bias=True,
+                             mlp_ratio=float(cfg["mlp_ratio"]), use_abs_pos=True, use_rel_pos=True,
+                             window_size=cfg["window_size"], global_attn_indexes=list(cfg["global_attn_indexes"]),
+                             mlp_dim=int(cfg["embed_dim"] * cfg["mlp_ratio"]))
+    enc = SamVisionEncoder(hf_cfg).eval()
+    shapes = arch.sam_encoder_param_shapes(cfg)
+    sd = synth.synth_state_dict_torch(shapes, SEED + 3)
+    ren = {"patch_embed.proj": "patch_embed.projection", "neck.0": "neck.conv1", "neck.1": "neck.layer_norm1",
+           "neck.2": "neck.conv2", "neck.3": "neck.layer_norm2"}
+    hf_sd = {}
+    for k, v in sd.items():
+        nk = k
+        for a, b in ren.items():
+            if nk.startswith(a + "."):
+                nk = b + nk[len(a):]
+        nk = nk.replace("blocks.", "layers.").replace(".norm1.", ".layer_norm1.").replace(".norm2.", ".layer_norm2.")
+        hf_sd[nk] = v
+    missing, unexpected = enc.load_state_dict(hf_sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    img = np.random.default_rng(301).integers(0, 256, size=(cfg["img_size"], cfg["img_size"], 3)).astype(np.uint8)
+    x = sam_oracle.preprocess(img, cfg["img_size"])
+    with torch.no_grad():
+        ref = enc(x)
+        ref = ref[0] if isinstance(ref, (tuple, list)) else ref.last_hidden_state
+        close(sam_oracle.image_encoder(sd, cfg, x), ref, 2e-4, "SAM tiny encoder vs HF port")
+    np.savez_compressed(os.path.join(GOLD, "sam_tiny_encoder.npz"), image=img, embedding=ref.numpy())
+
+
+def gen_host():
+    show_anns = ref_import.extract_function("sam2image.py", "show_anns")
+    rng = np.random.default_rng(401)
+    h = w = 48
+    anns = []
+    for i in range(300):                       # > 255 ids: exercises the // 256 byte
+        m = np.zeros((h, w), bool)
+        y0, x0 = rng.integers(0, h - 4), rng.integers(0, w - 4)
+        m[y0:y0 + rng.integers(1, 12), x0:x0 + rng.integers(1, 12)] = True
+        anns.append({"segmentation": m, "area": int(m.sum())})
+    _, res = show_anns(anns)
+    mine = host_oracle.show_anns_idmap(anns)
+    assert np.array_equal(res, mine), "show_anns id-map mismatch"
+    segs = np.stack([a["segmentation"] for a in anns]).astype(np.uint8)
+    np.savez_compressed(os.path.join(GOLD, "host_show_anns.npz"), segs=segs, res=res.astype(np.uint16))
+    print("  show_anns: bit-exact on", len(anns), "masks")
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    print("SAM ..."); gen_sam()          # before the import stubs (transformers probes for a real torchvision)
+    ns = ref_import.load()
+    print("LDM (ControlNet/UNet/DDIM) ..."); gen_ldm(ns)
+    print("VAE ..."); gen_vae(ns)
+    print("host ..."); gen_host()
+    print("golden vectors written to", GOLD)
