@@ -33,12 +33,14 @@ struct AttnParams {
   long long q_sb, q_sn, k_sb, k_sn, v_sb, v_sn, o_sb, o_sn;
   float scale;
   const float* bias_h; const float* bias_w;
+  int S;            // rel-pos grid side (key j -> (j / S, j % S)); 0 = no bias
+  unsigned magic;   // ceil(2^22 / S): j / S == (j * magic) >> 22 exactly for j < 16384, S <= 128
 };
 
 constexpr int ATT_BQ = 128;  // queries per workgroup
 constexpr int ATT_BK = 64;   // keys per tile
 
-template <int D, int S>
+template <int D, bool BIAS>
 __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
   constexpr int NKS = DQK / 16;
@@ -151,10 +153,10 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
         float sv = sacc[t][r] * sc2;
-        if (S > 0) {
+        if (BIAS) {
           if (key < p.Nk) {
-            const long long brow = ((long long)bh * p.Nq + q_ld) * (S > 0 ? S : 1);
-            const int kh = key / (S > 0 ? S : 1), kw = key - kh * (S > 0 ? S : 1);
+            const long long brow = ((long long)bh * p.Nq + q_ld) * p.S;
+            const int kh = (int)(((unsigned)key * p.magic) >> 22), kw = key - kh * p.S;
             sv += (p.bias_h[brow + kh] + p.bias_w[brow + kw]) * 1.4426950408889634f;
           }
         }
@@ -226,12 +228,12 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   }
 }
 
-template <int D, int S>
+template <int D, bool BIAS>
 static int launch_attn(const AttnParams& p, void* stream) {
   constexpr int DQK = (D + 15) / 16 * 16;
   constexpr int NDT = (D + 31) / 32;
   constexpr int smem = ATT_BK * (DQK * 2 + 16) + NDT * 32 * (ATT_BK * 2 + 8);
-  auto kfn = ea_attn_kernel<D, S>;
+  auto kfn = ea_attn_kernel<D, BIAS>;
   ea_allow_big_lds(kfn, smem);
   dim3 grid((p.Nq + ATT_BQ - 1) / ATT_BQ, p.B * p.H, 1);
   EA_LAUNCH(kfn, grid, dim3(256), smem, stream, p);
@@ -292,28 +294,23 @@ extern "C" int ea_attention_f16(const void* q, const void* k, const void* v, voi
   p.q_sb = q_sb; p.q_sn = q_sn; p.k_sb = k_sb; p.k_sn = k_sn; p.v_sb = v_sb; p.v_sn = v_sn;
   p.o_sb = o_sb; p.o_sn = o_sn;
   p.scale = scale; p.bias_h = bias_h; p.bias_w = bias_w;
+  p.S = S;
+  p.magic = S > 0 ? (unsigned)(((1u << 22) + S - 1) / S) : 0u;
   if (S == 0) {
     switch (D) {
-      case 40: return launch_attn<40, 0>(p, stream);
-      case 64: return launch_attn<64, 0>(p, stream);
-      case 80: return launch_attn<80, 0>(p, stream);
-      case 160: return launch_attn<160, 0>(p, stream);
-      default: return EA_ERR_UNSUPPORTED;
-    }
-  } else if (S == 14) {
-    switch (D) {
-      case 64: return launch_attn<64, 14>(p, stream);
-      case 80: return launch_attn<80, 14>(p, stream);
-      default: return EA_ERR_UNSUPPORTED;
-    }
-  } else if (S == 64) {
-    switch (D) {
-      case 64: return launch_attn<64, 64>(p, stream);
-      case 80: return launch_attn<80, 64>(p, stream);
+      case 40: return launch_attn<40, false>(p, stream);
+      case 64: return launch_attn<64, false>(p, stream);
+      case 80: return launch_attn<80, false>(p, stream);
+      case 160: return launch_attn<160, false>(p, stream);
       default: return EA_ERR_UNSUPPORTED;
     }
   }
-  return EA_ERR_UNSUPPORTED;
+  if (S > 128) return EA_ERR_UNSUPPORTED;
+  switch (D) {
+    case 64: return launch_attn<64, true>(p, stream);
+    case 80: return launch_attn<80, true>(p, stream);
+    default: return EA_ERR_UNSUPPORTED;
+  }
 }
 
 extern "C" int ea_relpos_tables_f16(const void* q, int B, int H, int S, int D, long long q_sb, long long q_sn,

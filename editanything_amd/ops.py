@@ -1,0 +1,259 @@
+"""Thin torch-tensor wrappers over the C ABI (include/editanything_hip.h).
+
+PyTorch is only the allocator / stream provider here: every op below is one call into
+libeditanything_hip.so on `torch.cuda.current_stream()`.  Activations are NHWC fp16
+([B, H, W, C] == tokens [B, H*W, C]); weights are pre-packed fp16 [N][K]; biases / norm affine fp32.
+There is no eager/CPU fallback: tensors must live on the MI355X.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = L.ACT_NONE, L.ACT_SILU, L.ACT_GELU, L.ACT_GEGLU
+
+_WS_BYTES = 384 << 20
+_ws = {}
+
+
+def _lib():
+    return L.lib()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(device):
+    """One persistent fp32 scratch buffer per device (split-K partials, GroupNorm partial sums).
+    Allocated once, before any HIP-graph capture; ops on one stream use it serially."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _ws:
+        _ws[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+    return _ws[key]
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _check_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("editanything_amd ops run on the MI355X only (tensor is on %s)" % t.device)
+
+
+def _epilogue(out, n_out, bias=None, act=ACT_NONE, scale=1.0, residual=None, rowvec=None, rows_per_group=1,
+              row_scale=None, bias_per_row=False):
+    e = L.Epilogue()
+    e.bias = _p(bias)
+    e.bias_per_row = int(bias_per_row)
+    e.rowvec = _p(rowvec)
+    e.rowvec_ld = rowvec.stride(0) if rowvec is not None else 0
+    e.rows_per_group = rows_per_group
+    e.act = act
+    e.scale = float(scale)
+    e.row_scale = _p(row_scale)
+    if residual is not None:
+        if residual.dtype == torch.float32:
+            e.residual32 = _p(residual)
+        else:
+            e.residual = _p(residual)
+        e.ldr = n_out
+    e.out = _p(out)
+    e.ldc = n_out
+    e.out_f32 = int(out.dtype == torch.float32)
+    return e
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
+         rows_per_group=1, row_scale=None, bias_per_row=False):
+    """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor."""
+    _check_dev(a, w)
+    K = a.shape[-1]
+    M = a.numel() // K
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (n_out,), dtype=out_dtype, device=a.device)
+    ws = workspace(a.device)
+    e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
+    st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
+    L.check(st, f"ea_gemm_f16 M{M} N{N} K{K}")
+    return out
+
+
+def gemm_batched(a, w, out, M, N, K, batch, stride_a, stride_w, stride_c, lda=None, ldw=None, bias=None,
+                 bias_per_row=False, scale=1.0):
+    """Strided-batched GEMM on raw buffers (VAE single-head attention path)."""
+    ws = workspace(a.device)
+    e = _epilogue(out, N, bias, ACT_NONE, scale, None, None, 1, None, bias_per_row)
+    st = _lib().ea_gemm_f16(_p(a), lda or K, _p(w), ldw or K, M, N, K, batch, stride_a, stride_w, stride_c, 0, C.byref(e),
+                            _p(ws), ws.numel(), _stream())
+    L.check(st, "ea_gemm_f16(batched)")
+    return out
+
+
+def _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout):
+    B, H, W, c1 = x1.shape
+    s = L.ConvSrc()
+    s.x1 = _p(x1)
+    s.c1 = c1
+    s.x2 = _p(x2)
+    s.c2 = x2.shape[-1] if x2 is not None else 0
+    s.x2_add = _p(x2_add)
+    s.B, s.Hin, s.Win = B, H, W
+    s.ksize, s.stride, s.pad, s.ups = ksize, stride, pad, int(ups)
+    hl, wl = (2 * H, 2 * W) if ups else (H, W)
+    s.Hout = hout if hout is not None else (hl + 2 * pad - ksize) // stride + 1
+    s.Wout = wout if wout is not None else (wl + 2 * pad - ksize) // stride + 1
+    return s
+
+
+def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
+           residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None):
+    """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin)."""
+    _check_dev(x1, w)
+    s = _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout)
+    cout = w.shape[0]
+    if out is None:
+        out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
+    ws = workspace(x1.device)
+    e = _epilogue(out, cout, bias, act, scale, residual, rowvec, s.Hout * s.Wout, row_scale)
+    st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
+    L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
+    return out
+
+
+def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=None, out=None):
+    _check_dev(x1, gamma)
+    B = x1.shape[0]
+    c1 = x1.shape[-1]
+    c2 = x2.shape[-1] if x2 is not None else 0
+    HW = x1.numel() // (B * c1)
+    if out is None:
+        out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=torch.float16, device=x1.device)
+    ws = workspace(x1.device)
+    st = _lib().ea_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(x2_add), _p(gamma), _p(beta), _p(out), B, HW, groups, eps,
+                                 int(silu), _p(ws), ws.numel(), _stream())
+    L.check(st, "ea_groupnorm_f16")
+    return out
+
+
+def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=None, x2_add=None, stride=1, pad=1,
+                           ups=False, residual=None, rowvec=None, scale=1.0, out_dtype=torch.float16):
+    """ResBlock half (openaimodel.py:254-274) as ONE C-ABI call."""
+    _check_dev(x1, w)
+    s = _conv_src(x1, x2, x2_add, 3, stride, pad, ups, None, None)
+    cout = w.shape[0]
+    ctot = s.c1 + s.c2
+    norm = torch.empty((s.B, s.Hin, s.Win, ctot), dtype=torch.float16, device=x1.device)
+    out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
+    ws = workspace(x1.device)
+    e = _epilogue(out, cout, bias, ACT_NONE, scale, residual, rowvec, s.Hout * s.Wout)
+    st = _lib().ea_groupnorm_silu_conv3x3(C.byref(s), _p(gamma), _p(beta), groups, eps, _p(norm), _p(w), cout, C.byref(e),
+                                          _p(ws), ws.numel(), _stream())
+    L.check(st, "ea_groupnorm_silu_conv3x3")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _check_dev(x, gamma)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    st = _lib().ea_layernorm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), _p(out), M, Cc, eps, _stream())
+    L.check(st, "ea_layernorm_f16")
+    return out
+
+
+def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None, out_dtype=torch.float16):
+    """LayerNorm -> Linear as one C-ABI call (BasicTransformerBlock norm -> to_q / GEGLU proj)."""
+    _check_dev(x, w)
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_GEGLU else N
+    ln_out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    out = torch.empty(x.shape[:-1] + (n_out,), dtype=out_dtype, device=x.device)
+    ws = workspace(x.device)
+    e = _epilogue(out, n_out, bias, act, 1.0, residual)
+    st = _lib().ea_ln_gemm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), eps, _p(ln_out), _p(w),
+                               w.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream())
+    L.check(st, "ea_ln_gemm_f16")
+    return out
+
+
+def attention(q, k, v, heads, dim_head, scale=None, bias_h=None, bias_w=None, S=0, out=None):
+    """q/k/v: [B, N, >=heads*dim_head] fp16 views (last-dim stride 1; row/batch strides free, e.g. slices of a fused
+    QKV buffer).  Returns [B, Nq, heads*dim_head]."""
+    _check_dev(q, k, v)
+    B, Nq = q.shape[0], q.shape[1]
+    Nk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, heads * dim_head), dtype=torch.float16, device=q.device)
+    scale = dim_head ** -0.5 if scale is None else scale
+    st = _lib().ea_attention_f16(_p(q), _p(k), _p(v), _p(out), B, heads, Nq, Nk, dim_head, q.stride(0), q.stride(1),
+                                 k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                 float(scale), _p(bias_h), _p(bias_w), S, _stream())
+    L.check(st, f"ea_attention_f16 B{B} H{heads} Nq{Nq} Nk{Nk} D{dim_head}")
+    return out
+
+
+def relpos_tables(q, heads, dim_head, S, rel_h, rel_w):
+    B = q.shape[0]
+    bh = torch.empty((B * heads, S * S, S), dtype=torch.float32, device=q.device)
+    bw = torch.empty_like(bh)
+    st = _lib().ea_relpos_tables_f16(_p(q), B, heads, S, dim_head, q.stride(0), q.stride(1), _p(rel_h), _p(rel_w), _p(bh),
+                                     _p(bw), _stream())
+    L.check(st, "ea_relpos_tables_f16")
+    return bh, bw
+
+
+def softmax_rows(x, scale):
+    rows, cols = x.shape[-2] * (x.numel() // (x.shape[-1] * x.shape[-2])), x.shape[-1]
+    out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    L.check(_lib().ea_softmax_rows_f32_f16(_p(x), _p(out), rows, cols, float(scale), _stream()), "ea_softmax_rows")
+    return out
+
+
+def cfg_ddim_step(x, eps_c, eps_u, coef, noise=None, mask=None, x_orig=None, noise_orig=None, x_prev=None, pred_x0=None):
+    if x_prev is None:
+        x_prev = torch.empty_like(x)
+    st = _lib().ea_cfg_ddim_step(_p(x), _p(eps_c), _p(eps_u), _p(noise), _p(coef), _p(mask), _p(x_orig), _p(noise_orig),
+                                 _p(x_prev), _p(pred_x0), x.numel(), _stream())
+    L.check(st, "ea_cfg_ddim_step")
+    return x_prev
+
+
+def nchw_to_nhwc(x, cpad=None, mul=1.0, add=0.0):
+    """fp32 NCHW (reference API) -> fp16 NHWC with channels zero-padded to `cpad`."""
+    _check_dev(x)
+    x = x.contiguous().float()
+    B, Cc, H, W = x.shape
+    cpad = cpad or Cc
+    out = torch.empty((B, H, W, cpad), dtype=torch.float16, device=x.device)
+    L.check(_lib().ea_nchw_f32_to_nhwc_f16(_p(x), _p(out), B, Cc, H, W, cpad, mul, add, _stream()), "nchw->nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, channels=None, mul=1.0, add=0.0):
+    _check_dev(x)
+    B, H, W, Cs = x.shape
+    Cc = channels or Cs
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    L.check(_lib().ea_nhwc_f16_to_nchw_f32(_p(x), _p(out), B, Cc, H, W, Cs, mul, add, _stream()), "nhwc->nchw")
+    return out
+
+
+def silu_f32(x):
+    out = torch.empty_like(x)
+    L.check(_lib().ea_silu_f32(_p(x), _p(out), x.numel(), _stream()), "ea_silu_f32")
+    return out
+
+
+def add_f16(a, b):
+    out = torch.empty_like(a)
+    L.check(_lib().ea_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "ea_add_f16")
+    return out

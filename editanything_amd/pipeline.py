@@ -1,0 +1,340 @@
+"""diffusers-style ControlNet (+inpaint) pipeline on the MI355X denoiser.
+
+Call surface of `StableDiffusionControlNetInpaintPipeline.__call__`
+(utils/stable_diffusion_controlnet_inpaint.py:1131-1703) and of the generation pipeline
+`StableDiffusionControlNetPipeline2.__call__` (utils/stable_diffusion_controlnet.py:347-662):
+same keyword names, same validation errors (`check_inputs` :792-979), `output_type` "pil" | "np" | "latent",
+`callback(i, t, latents)`, `[uncond || cond]` CFG batch layout (:701), CPU-generator noise (:1005-1007),
+4-channel vs 9-channel (SD2-inpainting) UNets, latent blending with `alignment_ratio` (:1647-1664),
+list-valued `controlnet_conditioning_image` / `controlnet_conditioning_scale` for several ControlNets.
+
+What is different underneath: the per-step work is `ControlledDenoiser.eps` (NHWC fp16 HIP kernels) plus ONE
+fused CFG + sampler-step (+ inpaint blend) kernel, and the whole step is captured once in a HIP graph and
+replayed (several hundred launches per step otherwise).  Sampler: DDIM in the reference LDM convention
+(cldm/ddim_hacked.py); UniPC exists only inside diffusers (absent) and is not provided.
+Text encoding is outside the hot path: pass `prompt_embeds` / `negative_prompt_embeds`, or give
+the pipeline a `text_encoder` callable (list[str] -> [B, 77, ctx_dim]).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import host, ops
+from .scheduler import DDIMScheduler
+from .unet import ControlledDenoiser
+
+
+class StableDiffusionPipelineOutput:
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+    def __iter__(self):
+        return iter((self.images, self.nsfw_content_detected))
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
+    """diffusers.utils.randn_tensor semantics: a CPU generator draws on the CPU, then the sample moves."""
+    gdev = generator.device.type if generator is not None else "cpu"
+    if gdev == "cpu":
+        return torch.randn(shape, generator=generator, dtype=dtype).to(device)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+class StableDiffusionControlNetInpaintPipeline:
+    vae_scale_factor = 8
+
+    def __init__(self, vae, unet, controlnet, scheduler=None, text_encoder=None, tokenizer=None, device="cuda",
+                 use_graph=True):
+        self.vae, self.unet = vae, unet
+        self.controlnet = controlnet
+        self.controlnets = list(controlnet) if isinstance(controlnet, (list, tuple)) else [controlnet]
+        self.scheduler = scheduler or DDIMScheduler()
+        self.text_encoder, self.tokenizer = text_encoder, tokenizer
+        self.device = torch.device(device)
+        self.denoiser = ControlledDenoiser(unet, self.controlnets)
+        self.use_graph = use_graph
+        self._graphs = {}
+
+    # ---- no-op compatibility shims of the reference's pipeline object (sam2image.py:44-46, editany_lora.py:385-387)
+    def to(self, device):
+        return self
+
+    def enable_xformers_memory_efficient_attention(self):
+        pass
+
+    def enable_model_cpu_offload(self):
+        pass
+
+    # ------------------------------------------------------------------ input handling
+    def check_inputs(self, prompt, image, mask_image, cond_images, height, width, callback_steps, negative_prompt,
+                     prompt_embeds, negative_prompt_embeds, cond_scale):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps}.")
+        if prompt is not None and prompt_embeds is not None:
+            raise ValueError("Cannot forward both `prompt` and `prompt_embeds`.")
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`.")
+        if prompt is not None and not isinstance(prompt, (str, list)):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if negative_prompt is not None and negative_prompt_embeds is not None:
+            raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`.")
+        if prompt_embeds is not None and negative_prompt_embeds is not None and \
+                prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape.")
+        n = len(self.controlnets)
+        if n == 1:
+            if isinstance(cond_scale, (list, tuple)):
+                raise TypeError("For single controlnet: `controlnet_conditioning_scale` must be type `float`.")
+        else:
+            if not isinstance(cond_images, (list, tuple)) or len(cond_images) != n:
+                raise ValueError("For multiple controlnets: `controlnet_conditioning_image` must be a list with one "
+                                 "entry per controlnet.")
+            if isinstance(cond_scale, (list, tuple)) and len(cond_scale) != n:
+                raise ValueError("For multiple controlnets: `controlnet_conditioning_scale` must have one entry per "
+                                 "controlnet.")
+        if (image is None) != (mask_image is None):
+            raise ValueError("`image` and `mask_image` must be given together (inpainting) or both omitted.")
+
+    def _encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds):
+        """…inpaint.py:551-703: -> [uncond || cond] embeddings, each repeated num_images_per_prompt times."""
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise ValueError("This pipeline has no text encoder (outside the hot path): pass `prompt_embeds`.")
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            prompt_embeds = self.text_encoder(prompts)
+            if do_cfg and negative_prompt_embeds is None:
+                neg = negative_prompt if negative_prompt is not None else ""
+                negs = [neg] * len(prompts) if isinstance(neg, str) else list(neg)
+                if len(negs) != len(prompts):
+                    raise ValueError("`negative_prompt` batch size must match `prompt`.")
+                negative_prompt_embeds = self.text_encoder(negs)
+        prompt_embeds = prompt_embeds.to(self.device, torch.float32)
+        b, L, _ = prompt_embeds.shape
+        prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(b * num_images_per_prompt, L, -1)
+        if do_cfg:
+            if negative_prompt_embeds is None:
+                raise ValueError("Classifier-free guidance needs `negative_prompt_embeds` (or a text encoder).")
+            ne = negative_prompt_embeds.to(self.device, torch.float32)
+            ne = ne.repeat(1, num_images_per_prompt, 1).view(b * num_images_per_prompt, L, -1)
+            prompt_embeds = torch.cat([ne, prompt_embeds])
+        return prompt_embeds
+
+    def _prepare_cond_image(self, img, width, height, batch, do_cfg):
+        """prepare_controlnet_conditioning_image (…inpaint.py:190-243).  Tensors pass through unscaled (the SAM id-map
+        control is fed as float 0..255, sam2image.py:158-177); PIL / uint8 arrays are scaled to [0, 1]."""
+        if not isinstance(img, torch.Tensor):
+            arr = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)
+            if arr.ndim == 3:
+                arr = arr[None]
+            img = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+        img = img.float()
+        if img.ndim == 3:
+            img = img[None]
+        if img.shape[-2:] != (height, width):
+            img = F.interpolate(img, size=(height, width), mode="bilinear", align_corners=False)
+        if img.shape[0] != batch:
+            img = img.repeat(batch // img.shape[0], 1, 1, 1)
+        img = img.to(self.device)
+        return torch.cat([img] * 2) if do_cfg else img
+
+    def prepare_latents(self, batch, channels, height, width, generator, latents=None):
+        shape = (batch, channels, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch}.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([randn_tensor((1,) + shape[1:], g, self.device) for g in generator])
+            else:
+                latents = randn_tensor(shape, generator, self.device)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+            latents = latents.to(self.device, torch.float32)
+        return latents * self.scheduler.init_noise_sigma
+
+    def decode_latents(self, latents):
+        """…inpaint.py:718-724 -> float32 NHWC numpy in [0, 1]."""
+        img = self.vae.decode_nhwc(latents / self.vae.scale_factor)
+        img = (img / 2 + 0.5).clamp(0, 1)
+        return img.cpu().float().numpy()
+
+    # ------------------------------------------------------------------ the step
+    def _step(self, st):
+        lat = st["lat"]
+        x2 = torch.cat([lat] * 2) if st["cfg"] else lat
+        if st["extra"] is not None:                               # 9-ch inpaint UNet: latents || mask || masked latents
+            x2 = torch.cat([x2, st["extra"]], dim=1)
+        eps = self.denoiser.eps(x2, st["t"])
+        if st["cfg"]:
+            e_u, e_c = eps.chunk(2)
+        else:
+            e_u, e_c = None, eps
+        ops.cfg_ddim_step(lat, e_c.contiguous(), None if e_u is None else e_u.contiguous(), st["coef"], noise=st["noise"],
+                          mask=st["blend_mask"], x_orig=st["x_orig"], noise_orig=st["noise_orig"], x_prev=st["lat_out"])
+        lat.copy_(st["lat_out"])
+
+    # ------------------------------------------------------------------ __call__
+    @torch.no_grad()
+    def __call__(self, prompt=None, image=None, mask_image=None, controlnet_conditioning_image=None, height=None,
+                 width=None, num_inference_steps=50, guidance_scale=7.5, negative_prompt=None,
+                 num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
+                 cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
+                 guess_mode=False, controlnet_conditioning_scale_map=None, **unused):
+        if controlnet_conditioning_image is None and "control_image" in unused:
+            controlnet_conditioning_image = unused.pop("control_image")
+        cond_images = controlnet_conditioning_image
+        if not isinstance(cond_images, (list, tuple)):
+            cond_images = [cond_images]
+        ref = cond_images[0]
+        if height is None or width is None:
+            if isinstance(ref, torch.Tensor):
+                height, width = height or ref.shape[-2], width or ref.shape[-1]
+            else:
+                arr = np.asarray(ref)
+                height, width = height or arr.shape[0], width or arr.shape[1]
+        self.check_inputs(prompt, image, mask_image, controlnet_conditioning_image, height, width, callback_steps,
+                          negative_prompt, prompt_embeds, negative_prompt_embeds, controlnet_conditioning_scale)
+        if prompt is not None:
+            batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        else:
+            batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0
+        n_img = batch_size * num_images_per_prompt
+        embeds = self._encode_prompt(prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds,
+                                     negative_prompt_embeds)
+        hints = [self._prepare_cond_image(ci, width, height, n_img, do_cfg) for ci in cond_images]
+        n_out = len(self.unet.plan["input"]) + 1
+        scales = controlnet_conditioning_scale
+        if not isinstance(scales, (list, tuple)):
+            scales = [scales] * len(self.controlnets)
+        per_net = []
+        for s in scales:
+            if guess_mode:      # logspace ramp 0.1 .. 1 (utils/stable_diffusion_controlnet.py:777-783)
+                ramp = torch.logspace(-1, 0, n_out).tolist()
+                per_net.append([float(s) * r for r in ramp])
+            else:
+                per_net.append([float(s)] * n_out)
+        if controlnet_conditioning_scale_map is not None:
+            per_net[0] = self._scale_map_rows(controlnet_conditioning_scale_map, per_net[0], height, width,
+                                              2 * n_img if do_cfg else n_img)
+
+        sch = self.scheduler
+        timesteps = sch.set_timesteps(num_inference_steps, eta=eta)
+        nsteps = len(timesteps)
+        lat = self.prepare_latents(n_img, 4, height, width, generator, latents)
+        noise0 = lat.clone()
+        unet_in = self.unet.cfg["in_channels"]
+        extra = blend_mask = x_orig = None
+        if image is not None:
+            img = host.prepare_image(image).to(self.device)
+            msk = host.prepare_mask_image(mask_image).to(self.device)
+            if img.shape[-2:] != (height, width):
+                img = F.interpolate(img, size=(height, width), mode="bilinear", align_corners=False)
+                msk = F.interpolate(msk, size=(height, width), mode="nearest")
+            h8, w8 = height // 8, width // 8
+            if unet_in != 4:    # SD2-inpainting 9-channel UNet (…inpaint.py:1448-1468, 1550-1558)
+                masked = img * (msk < 0.5)
+                m_lat = F.interpolate(msk, size=(h8, w8))
+                vnoise = randn_tensor((masked.shape[0], 4, h8, w8), generator if not isinstance(generator, list) else generator[0], self.device)
+                mi_lat = self.vae.encode(masked, vnoise)
+                rep = n_img // m_lat.shape[0]
+                m_lat, mi_lat = m_lat.repeat(rep, 1, 1, 1), mi_lat.repeat(n_img // mi_lat.shape[0], 1, 1, 1)
+                extra = torch.cat([m_lat, mi_lat], dim=1)
+                extra = torch.cat([extra] * 2) if do_cfg else extra
+            else:               # 4-channel UNet: blend with the re-noised original (…inpaint.py:1469-1489, 1647-1664)
+                vnoise = randn_tensor((img.shape[0], 4, h8, w8), generator if not isinstance(generator, list) else generator[0], self.device)
+                x_orig = self.vae.encode(img, vnoise)
+                x_orig = x_orig.repeat(n_img // x_orig.shape[0], 1, 1, 1).contiguous()
+                keep = 1 - F.interpolate(msk, size=(h8, w8), mode="nearest")
+                keep = keep.repeat(n_img // keep.shape[0], 4, 1, 1).contiguous()
+                blend_mask = (1 - keep).contiguous()         # 1 where the sample is generated
+        self.denoiser.only_mid_control = False
+        self.denoiser.prepare(embeds, hints, per_net)
+        coef_table = sch.coef_table(guidance_scale, self.device)
+        t_table = torch.as_tensor(timesteps.astype(np.int64), device=self.device)
+        nb = 2 * n_img if do_cfg else n_img
+        st = dict(lat=lat.contiguous(), lat_out=torch.empty_like(lat), t=torch.zeros(nb, dtype=torch.long, device=self.device),
+                  coef=coef_table[0].clone(), cfg=do_cfg, extra=extra, noise=None, blend_mask=None, x_orig=x_orig,
+                  noise_orig=noise0 if x_orig is not None else None)
+        step_noise = eta > 0
+        in_loop_blend = x_orig is not None and alignment_ratio is not None
+        graph = None
+        for i in range(nsteps):
+            st["t"].fill_(int(timesteps[i]))
+            st["coef"].copy_(coef_table[i])
+            st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
+                if step_noise else None
+            blend_now = in_loop_blend and i < nsteps * alignment_ratio and i + 1 < nsteps
+            st["blend_mask"] = blend_mask if blend_now else None
+            if self.use_graph and not step_noise and not in_loop_blend:
+                if graph is None:
+                    graph = self._capture(st)
+                graph.replay()
+            else:
+                self._step(st)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, int(timesteps[i]), st["lat"])
+        lat = st["lat"]
+        if x_orig is not None and (alignment_ratio is None or alignment_ratio == 1.0):
+            lat = x_orig * (1 - blend_mask) + lat * blend_mask     # fill the kept region with the original
+        if output_type == "latent":
+            images = lat
+        else:
+            images = self.decode_latents(lat)
+            if output_type == "pil":
+                images = host.numpy_to_pil(images)
+        if not return_dict:
+            return images, None
+        return StableDiffusionPipelineOutput(images, None)
+
+    def _capture(self, st):
+        """Warm up once on a side stream (restoring the latents), then capture ONE step into a HIP graph."""
+        saved = st["lat"].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step(st)
+        torch.cuda.current_stream().wait_stream(s)
+        st["lat"].copy_(saved)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step(st)
+        st["lat"].copy_(saved)
+        return g
+
+    def _scale_map_rows(self, scale_map, base, height, width, nb):
+        """ControlNetModel2 spatial scale map (utils/stable_diffusion_controlnet.py:785-802): per output level a
+        bilinear resize of the [H, W] map -> one fp32 multiplier per output row (pixel)."""
+        sm = torch.as_tensor(scale_map, dtype=torch.float32, device=self.device)
+        sm = sm.reshape(1, 1, *sm.shape[-2:])
+        rows = []
+        res = [(height // 8) >> k for k in (0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3)][:len(base) - 1]
+        sizes = []
+        h8, w8 = height // 8, width // 8
+        ds = 1
+        for blk in self.unet.plan["input"]:
+            if blk[0][0] == "down":
+                ds *= 2
+            sizes.append((h8 // ds, w8 // ds))
+        sizes.append(sizes[-1])
+        del res
+        for (hh, ww), b in zip(sizes, base):
+            m = F.interpolate(sm, size=(hh, ww), mode="bilinear", align_corners=False).reshape(-1) * b
+            rows.append(m.repeat(nb).contiguous())
+        return rows
+
+
+class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline):
+    """Generation variant (sam2image.py:168-177 calls `pipe(prompt=..., image=control, ...)`): here `image` IS the
+    ControlNet conditioning image, as in diffusers' StableDiffusionControlNetPipeline."""
+
+    def __call__(self, prompt=None, image=None, **kw):
+        if "controlnet_conditioning_image" not in kw:
+            kw["controlnet_conditioning_image"] = image
+            image = None
+        return super().__call__(prompt=prompt, image=None, mask_image=None, **kw)

@@ -1,0 +1,118 @@
+"""`sam2image.py` call surface (reference sam2image.py:20-180) on the MI355X hot path.
+
+`create_demo(...)` returns an object whose `.process(...)` has the reference's 15-argument signature and return value
+`([full_segmask_PIL] + n PIL images, prompt)`.  Differences that are deliberate and documented:
+  * device-agnostic where the reference hard-codes `.cuda()` (:159);
+  * the pipeline denoises `num_samples` latents, not the reference's accidental n^2 (prompt list x
+    num_images_per_prompt, :169-171) of which only the first n are returned -- the first n outputs are identical
+    because samples are independent and the seeded CPU noise stream is consumed in the same order;
+  * BLIP2 auto-prompting is outside the hot path (`enable_auto_prompt` needs a user-supplied `captioner`);
+  * SAM: the ViT image encoder (the expensive part of `SamAutomaticMaskGenerator.generate`) runs on the HIP
+    kernels; the prompt-encoder / mask-decoder / AMG post-processing (segment_anything, absent here; SURVEY.md
+    section 8f item 1) is injected as `mask_generator` -- any object with `.generate(image, image_embedding=None)`.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import host
+
+config_dict = OrderedDict([('SAM Pretrained(v0-1)', 'shgao/edit-anything-v0-1-1'),
+                           ('LAION Pretrained(v0-3)', 'shgao/edit-anything-v0-3'),
+                           ('LAION Pretrained(v0-4)', 'shgao/edit-anything-v0-4-sd21')])
+
+
+class SyntheticMaskGenerator:
+    """Stand-in for SamAutomaticMaskGenerator when segment_anything is not installed (benchmarks / smoke):
+    K seeded axis-aligned rectangles in SAM's output format (SURVEY.md 8d synthetic inputs)."""
+
+    def __init__(self, k=32, seed=0):
+        self.k, self.seed = k, seed
+
+    def generate(self, image, image_embedding=None):
+        h, w = image.shape[:2]
+        rng = np.random.default_rng(self.seed)
+        anns = []
+        for _ in range(self.k):
+            y0, x0 = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+            hh, ww = int(rng.integers(8, max(9, h // 2))), int(rng.integers(8, max(9, w // 2)))
+            m = np.zeros((h, w), bool)
+            m[y0:y0 + hh, x0:x0 + ww] = True
+            anns.append({"segmentation": m, "area": int(m.sum()), "bbox": [x0, y0, ww, hh], "predicted_iou": 1.0,
+                         "stability_score": 1.0, "point_coords": [[x0, y0]], "crop_box": [0, 0, w, h]})
+        return anns
+
+
+class Demo:
+    def __init__(self, pipe_factory, sam_encoder=None, mask_generator=None, captioner=None, device="cuda"):
+        self.pipe_factory = pipe_factory
+        self.pipes = {}
+        self.default_controlnet_path = config_dict['LAION Pretrained(v0-4)']
+        self.sam_encoder = sam_encoder
+        self.mask_generator = mask_generator or SyntheticMaskGenerator()
+        self.captioner = captioner
+        self.device = torch.device(device)
+        self.last_embedding = None
+
+    def _pipe(self, path):
+        if path not in self.pipes:
+            self.pipes[path] = self.pipe_factory(path)
+        return self.pipes[path]
+
+    def get_sam_control(self, image):
+        """sam2image.py:117-120: SAM image encoding (HIP) -> masks -> id-map control."""
+        emb = None
+        if self.sam_encoder is not None:
+            S = self.sam_encoder.cfg["img_size"]
+            im = image
+            if max(im.shape[:2]) != S:          # ResizeLongestSide(S)
+                from PIL import Image
+                k = S / max(im.shape[:2])
+                im = np.asarray(Image.fromarray(im).resize((int(im.shape[1] * k + 0.5), int(im.shape[0] * k + 0.5)),
+                                                           Image.BILINEAR))
+            emb = self.sam_encoder.encode_image(im)
+            self.last_embedding = emb
+        try:
+            masks = self.mask_generator.generate(image, image_embedding=emb)
+        except TypeError:
+            masks = self.mask_generator.generate(image)
+        return host.show_anns(masks)
+
+    def process(self, condition_model, input_image, enable_auto_prompt, prompt, a_prompt, n_prompt, num_samples,
+                image_resolution, detect_resolution, ddim_steps, guess_mode, strength, scale, seed, eta,
+                prompt_embeds=None, negative_prompt_embeds=None):
+        path = config_dict.get(condition_model, condition_model)
+        pipe = self._pipe(path)
+        with torch.no_grad():
+            if enable_auto_prompt or (len(prompt) == 0 and prompt_embeds is None):
+                if self.captioner is None:
+                    raise ValueError("auto-prompting needs a `captioner` (BLIP2 is outside the hot path)")
+                cap = self.captioner(input_image)
+                prompt = cap + ',' + prompt if len(prompt) > 0 else cap
+            input_image = host.HWC3(input_image)
+            img = host.resize_image(input_image, image_resolution)
+            H, W, _ = img.shape
+            full_segmask, detected_map = self.get_sam_control(host.resize_image(input_image, detect_resolution))
+            control = host.make_control(detected_map, H, W, num_samples, self.device)
+            seed, generator = host.resolve_seed(seed)
+            kw = {}
+            if prompt_embeds is not None:
+                kw = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+            else:
+                kw = dict(prompt=[prompt + ', ' + a_prompt] * 1, negative_prompt=[n_prompt] * 1)
+            # NOTE scale / strength / guess_mode / eta are accepted but NOT forwarded, exactly like the reference
+            # (sam2image.py:168-177): guidance stays at the pipeline default 7.5.
+            x_samples = pipe(num_images_per_prompt=num_samples, num_inference_steps=ddim_steps, generator=generator,
+                             height=H, width=W, controlnet_conditioning_image=control, **kw).images
+            results = [x_samples[i] for i in range(num_samples)]
+        return [full_segmask] + results, prompt
+
+
+def create_demo(pipe_factory=None, sam_encoder=None, mask_generator=None, captioner=None, device="cuda"):
+    """pipe_factory(controlnet_path) -> pipeline.  Default: seeded synthetic SD2.1 + ControlNet weights (no
+    checkpoints exist in this environment)."""
+    if pipe_factory is None:
+        from . import models
+        pipe_factory = lambda path: models.synthetic_pipeline("sd21", device=device, inpaint=False)
+    return Demo(pipe_factory, sam_encoder, mask_generator, captioner, device)

@@ -1,0 +1,356 @@
+"""ControlNet + ControlledUnetModel on the MI355X kernels, behind the reference's network API.
+
+Mirrors (same constructor config keys, same state-dict names, same forward signatures):
+  * cldm/cldm.py:22-45    ControlledUnetModel.forward(x, timesteps, context, control, only_mid_control)
+  * cldm/cldm.py:284-305  ControlNet.forward(x, hint, timesteps, context) -> list of 13 residuals
+  * cldm/cldm.py:328-341  ControlLDM.apply_model  (-> `ControlledDenoiser.apply_model`)
+built from ldm/modules/diffusionmodules/openaimodel.py (ResBlock/Upsample/Downsample/UNetModel) and
+ldm/modules/attention.py (SpatialTransformer/BasicTransformerBlock/CrossAttention/GEGLU).
+
+MI355X-first data flow (not the reference's NCHW module tree):
+  * activations stay NHWC fp16 in HBM, so `b c h w -> b (h w) c` is free and every conv is an implicit GEMM
+    whose K (= tap x channel) is contiguous;
+  * a ResBlock is two `ea_groupnorm_silu_conv3x3` calls (bias, time-embedding row-vector, skip add fused);
+  * the decoder never materialises `torch.cat([h, hs.pop()])`: GroupNorm and the convs read two sources;
+  * ControlNet zero-convs write `skip += scale * (W h + b)` straight into the UNet skip tensors
+    (zero-conv + control scale + residual add = one epilogue), so `control` lists are never materialised on
+    the fused path;
+  * q/k/v come from ONE fused projection GEMM and are consumed in place by the attention kernel; text K/V
+    projections and the ControlNet hint encoder are step-invariant and computed once per call;
+  * all 22 (10) time-embedding projections of the ResBlocks are one GEMM per step.
+"""
+import math
+
+import torch
+
+from . import arch, ops
+
+
+def _f16(t, device):
+    return t.to(device=device, dtype=torch.float16).contiguous()
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_conv(w, device):
+    """[Cout, Cin, k, k] -> fp16 [Cout, k*k*Cin8] with K = (ky*k + kx)*Cin8 + cin (Cin zero-padded to x8)."""
+    cout, cin, k, _ = w.shape
+    w = w.permute(0, 2, 3, 1)
+    cin8 = (cin + 7) // 8 * 8
+    if cin8 != cin:
+        w = torch.nn.functional.pad(w, (0, cin8 - cin))
+    return _f16(w.reshape(cout, k * k * cin8), device)
+
+
+def pack_geglu(w, b):
+    """ff.net.0.proj [8C, C]: rows [0,4C) are values, [4C,8C) gates -> interleave as [32 value | 32 gate] per 64
+    rows so the GEMM epilogue finds value and gate of one output in the same lane (EA_ACT_GEGLU)."""
+    half = w.shape[0] // 2
+    wv, wg = w[:half].reshape(half // 32, 32, -1), w[half:].reshape(half // 32, 32, -1)
+    bv, bg = b[:half].reshape(half // 32, 32), b[half:].reshape(half // 32, 32)
+    return torch.cat([wv, wg], 1).reshape(2 * half, -1), torch.cat([bv, bg], 1).reshape(2 * half)
+
+
+class _Res:
+    def __init__(self, sd, p, device, cin, cout, split=None):
+        self.cin, self.cout = cin, cout
+        self.g1w, self.g1b = _f32(sd[p + "in_layers.0.weight"], device), _f32(sd[p + "in_layers.0.bias"], device)
+        w1 = sd[p + "in_layers.2.weight"]
+        self.w1, self.b1 = pack_conv(w1, device), _f32(sd[p + "in_layers.2.bias"], device)
+        self.g2w, self.g2b = _f32(sd[p + "out_layers.0.weight"], device), _f32(sd[p + "out_layers.0.bias"], device)
+        self.w2, self.b2 = pack_conv(sd[p + "out_layers.3.weight"], device), _f32(sd[p + "out_layers.3.bias"], device)
+        self.emb_w, self.emb_b = sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"]
+        self.emb_off = 0
+        self.skip_w = None
+        if (p + "skip_connection.weight") in sd:
+            self.skip_w = pack_conv(sd[p + "skip_connection.weight"], device)
+            self.skip_b = _f32(sd[p + "skip_connection.bias"], device)
+
+    def forward(self, x1, x2, emb_all):
+        rowvec = emb_all[:, self.emb_off:self.emb_off + self.cout]
+        h = ops.groupnorm_silu_conv3x3(x1, self.g1w, self.g1b, self.w1, self.b1, x2=x2, rowvec=rowvec)
+        if self.skip_w is not None:
+            res = ops.conv2d(x1, self.skip_w, self.skip_b, ksize=1, pad=0, x2=x2)
+        else:
+            res = x1
+        return ops.groupnorm_silu_conv3x3(h, self.g2w, self.g2b, self.w2, self.b2, residual=res)
+
+
+class _Attn:
+    """SpatialTransformer with one BasicTransformerBlock (attention.py:278-340, 246-275)."""
+
+    def __init__(self, sd, p, device, ch, heads, dim_head):
+        self.ch, self.heads, self.d = ch, heads, dim_head
+        inner = heads * dim_head
+        self.inner = inner
+        self.nw, self.nb = _f32(sd[p + "norm.weight"], device), _f32(sd[p + "norm.bias"], device)
+        self.pin_w = _f16(sd[p + "proj_in.weight"].reshape(inner, ch), device)
+        self.pin_b = _f32(sd[p + "proj_in.bias"], device)
+        t = p + "transformer_blocks.0."
+        self.ln = [(_f32(sd[t + f"norm{i}.weight"], device), _f32(sd[t + f"norm{i}.bias"], device)) for i in (1, 2, 3)]
+        self.wqkv = _f16(torch.cat([sd[t + "attn1.to_q.weight"], sd[t + "attn1.to_k.weight"], sd[t + "attn1.to_v.weight"]], 0), device)
+        self.wo1, self.bo1 = _f16(sd[t + "attn1.to_out.0.weight"], device), _f32(sd[t + "attn1.to_out.0.bias"], device)
+        self.wq2 = _f16(sd[t + "attn2.to_q.weight"], device)
+        self.wkv2 = _f16(torch.cat([sd[t + "attn2.to_k.weight"], sd[t + "attn2.to_v.weight"]], 0), device)
+        self.wo2, self.bo2 = _f16(sd[t + "attn2.to_out.0.weight"], device), _f32(sd[t + "attn2.to_out.0.bias"], device)
+        gw, gb = pack_geglu(sd[t + "ff.net.0.proj.weight"], sd[t + "ff.net.0.proj.bias"])
+        self.wff1, self.bff1 = _f16(gw, device), _f32(gb, device)
+        self.wff2, self.bff2 = _f16(sd[t + "ff.net.2.weight"], device), _f32(sd[t + "ff.net.2.bias"], device)
+        self.pout_w = _f16(sd[p + "proj_out.weight"].reshape(ch, inner), device)
+        self.pout_b = _f32(sd[p + "proj_out.bias"], device)
+
+    def project_context(self, ctx16):
+        """Text K/V are step-invariant: [B, L, ctx] -> [B, L, 2*inner] once per call."""
+        return ops.gemm(ctx16, self.wkv2)
+
+    def forward(self, x, kv):
+        B, H, W, Cc = x.shape
+        inner = self.inner
+        xt = x.view(B, H * W, Cc)
+        xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False)
+        h = ops.gemm(xn, self.pin_w, self.pin_b)
+        qkv = ops.ln_gemm(h, self.ln[0][0], self.ln[0][1], self.wqkv)
+        a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
+        h = ops.gemm(a, self.wo1, self.bo1, residual=h)
+        q = ops.ln_gemm(h, self.ln[1][0], self.ln[1][1], self.wq2)
+        a = ops.attention(q, kv[..., :inner], kv[..., inner:], self.heads, self.d)
+        h = ops.gemm(a, self.wo2, self.bo2, residual=h)
+        f = ops.ln_gemm(h, self.ln[2][0], self.ln[2][1], self.wff1, self.bff1, act=ops.ACT_GEGLU)
+        h = ops.gemm(f, self.wff2, self.bff2, residual=h)
+        return ops.gemm(h, self.pout_w, self.pout_b, residual=xt).view(B, H, W, Cc)
+
+
+class _Conv:
+    def __init__(self, sd, p, device, stride=1, ups=False):
+        self.w, self.b = pack_conv(sd[p + "weight"], device), _f32(sd[p + "bias"], device)
+        self.stride, self.ups = stride, ups
+
+    def forward(self, x, residual=None, act=ops.ACT_NONE):
+        return ops.conv2d(x, self.w, self.b, stride=self.stride, ups=self.ups, residual=residual, act=act)
+
+
+class _UNetBase:
+    """Shared encoder/middle machinery of UNetModel and ControlNet."""
+
+    def __init__(self, cfg, state_dict, device, controlnet):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        self.plan = arch.unet_plan(cfg, controlnet)
+        sd = state_dict
+        missing = [k for k in arch.unet_param_shapes(cfg, controlnet) if k not in sd]
+        if missing:
+            raise KeyError(f"state dict lacks {len(missing)} keys, e.g. {missing[:3]}")
+        dev = self.device
+        self.mc = cfg["model_channels"]
+        self.te0_w, self.te0_b = _f16(sd["time_embed.0.weight"], dev), _f32(sd["time_embed.0.bias"], dev)
+        self.te2_w, self.te2_b = _f16(sd["time_embed.2.weight"], dev), _f32(sd["time_embed.2.bias"], dev)
+        self._res = []
+        self._attn = []
+        self.input_blocks = [self._build_block(sd, f"input_blocks.{i}.", blk) for i, blk in enumerate(self.plan["input"])]
+        self.middle_block = self._build_block(sd, "middle_block.", self.plan["middle"])
+        half = self.mc // 2
+        self.freqs = torch.exp(-math.log(10000.0) * torch.arange(0, half, dtype=torch.float32) / half).to(dev)
+
+    def _build_block(self, sd, prefix, blk):
+        mods = []
+        for j, op in enumerate(blk):
+            p = f"{prefix}{j}."
+            if op[0] == "conv_in":
+                mods.append(("conv_in", _Conv(sd, p, self.device)))
+            elif op[0] == "res":
+                r = _Res(sd, p, self.device, op[1], op[2])
+                self._res.append(r)
+                mods.append(("res", r))
+            elif op[0] == "attn":
+                a = _Attn(sd, p, self.device, op[1], op[2], op[3])
+                self._attn.append(a)
+                mods.append(("attn", a))
+            elif op[0] == "down":
+                mods.append(("down", _Conv(sd, p + "op.", self.device, stride=2)))
+            elif op[0] == "up":
+                mods.append(("up", _Conv(sd, p + "conv.", self.device, ups=True)))
+        return mods
+
+    def _finalize_emb(self):
+        """Concatenate every ResBlock's emb_layers Linear into one [sum(Cout), temb] GEMM."""
+        off = 0
+        ws, bs = [], []
+        for r in self._res:
+            r.emb_off = off
+            off += r.cout
+            ws.append(r.emb_w)
+            bs.append(r.emb_b)
+            r.emb_w = r.emb_b = None
+        self.emb_w_all = _f16(torch.cat(ws, 0), self.device)
+        self.emb_b_all = _f32(torch.cat(bs, 0), self.device)
+
+    # -- per-step / per-call precomputation
+    def time_embedding(self, timesteps):
+        """timestep_embedding (util.py:154-174) -> time_embed MLP -> SiLU -> all emb_layers: fp32 [B, sum(Cout)]."""
+        args = timesteps.to(self.device).float()[:, None] * self.freqs[None]
+        t_emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1).half()
+        e = ops.gemm(t_emb, self.te0_w, self.te0_b, act=ops.ACT_SILU)
+        e = ops.gemm(e, self.te2_w, self.te2_b, act=ops.ACT_SILU)       # SiLU of emb_layers[0] fused here
+        return ops.gemm(e, self.emb_w_all, self.emb_b_all, out_dtype=torch.float32)
+
+    def project_context(self, context):
+        """context [B, L, ctx_dim] (any float dtype) -> per-attention-layer K/V projections (step-invariant)."""
+        ctx16 = context.to(self.device, torch.float16).contiguous()
+        return [a.project_context(ctx16) for a in self._attn]
+
+    def _run(self, mods, h, x2, emb_all, kvs, residual=None):
+        for kind, m in mods:
+            if kind == "conv_in":
+                h = m.forward(h, residual=residual)
+            elif kind == "res":
+                h = m.forward(h, x2, emb_all)
+                x2 = None
+            elif kind == "attn":
+                h = m.forward(h, kvs[self._attn_index[id(m)]])
+            else:
+                h = m.forward(h)
+        return h
+
+    def _index_attn(self):
+        self._attn_index = {id(a): i for i, a in enumerate(self._attn)}
+
+    def to_nhwc(self, x):
+        cin8 = (self.cfg["in_channels"] + 7) // 8 * 8
+        return ops.nchw_to_nhwc(x.to(self.device), cpad=cin8)
+
+
+class ControlledUnetModel(_UNetBase):
+    """cldm/cldm.py:21-45 over openaimodel.py:412-786.  `forward` keeps the reference signature (NCHW in/out)."""
+
+    def __init__(self, cfg, state_dict, device="cuda"):
+        super().__init__(cfg, state_dict, device, controlnet=False)
+        sd = state_dict
+        self.output_blocks = [self._build_block(sd, f"output_blocks.{i}.", blk) for i, blk in enumerate(self.plan["output"])]
+        self.out_gw, self.out_gb = _f32(sd["out.0.weight"], self.device), _f32(sd["out.0.bias"], self.device)
+        self.out_w, self.out_b = pack_conv(sd["out.2.weight"], self.device), _f32(sd["out.2.bias"], self.device)
+        self._finalize_emb()
+        self._index_attn()
+
+    def encode(self, x_nhwc, emb_all, kvs):
+        hs = []
+        h = x_nhwc
+        for mods in self.input_blocks:
+            h = self._run(mods, h, None, emb_all, kvs)
+            hs.append(h)
+        h = self._run(self.middle_block, h, None, emb_all, kvs)
+        return hs, h
+
+    def decode(self, h, hs, emb_all, kvs):
+        hs = list(hs)
+        for mods in self.output_blocks:
+            h = self._run(mods, h, hs.pop(), emb_all, kvs)      # concat-free: two sources
+        out = ops.groupnorm_silu_conv3x3(h, self.out_gw, self.out_gb, self.out_w, self.out_b, out_dtype=torch.float32)
+        return out.permute(0, 3, 1, 2).contiguous()             # tiny [B,4,h,w] layout change back to the API's NCHW
+
+    def forward(self, x, timesteps=None, context=None, control=None, only_mid_control=False, **kwargs):
+        """Reference-API path: `control` is a list of NCHW tensors consumed from the end (cldm.py:34-41)."""
+        emb_all = self.time_embedding(timesteps)
+        kvs = self.project_context(context)
+        hs, h = self.encode(self.to_nhwc(x), emb_all, kvs)
+        if control is not None:
+            control = list(control)
+            h = ops.add_f16(h, ops.nchw_to_nhwc(control.pop()))
+            if not only_mid_control:
+                hs = [ops.add_f16(s, ops.nchw_to_nhwc(c)) for s, c in zip(hs, control)]
+        return self.decode(h, hs, emb_all, kvs)
+
+
+class ControlNet(_UNetBase):
+    """cldm/cldm.py:48-305."""
+
+    def __init__(self, cfg, state_dict, device="cuda"):
+        super().__init__(cfg, state_dict, device, controlnet=True)
+        sd, dev = state_dict, self.device
+        self.hint = [(pack_conv(sd[f"input_hint_block.{2 * i}.weight"], dev), _f32(sd[f"input_hint_block.{2 * i}.bias"], dev),
+                      arch.HINT_STRIDES[i]) for i in range(8)]
+        n = len(self.plan["input"])
+        self.zero = [(pack_conv(sd[f"zero_convs.{i}.0.weight"], dev), _f32(sd[f"zero_convs.{i}.0.bias"], dev)) for i in range(n)]
+        self.zero.append((pack_conv(sd["middle_block_out.0.weight"], dev), _f32(sd["middle_block_out.0.bias"], dev)))
+        self._finalize_emb()
+        self._index_attn()
+
+    def encode_hint(self, hint):
+        """input_hint_block (cldm.py:147-163): step-invariant, run once per call.  hint: NCHW float, values 0..255."""
+        h = ops.nchw_to_nhwc(hint.to(self.device), cpad=(self.cfg["hint_channels"] + 7) // 8 * 8)
+        for i, (w, b, s) in enumerate(self.hint):
+            h = ops.conv2d(h, w, b, stride=s, act=ops.ACT_SILU if i != 7 else ops.ACT_NONE)
+        return h
+
+    def _features(self, x_nhwc, emb_all, kvs, guided_hint):
+        feats = []
+        h = x_nhwc
+        for i, mods in enumerate(self.input_blocks):
+            h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint if i == 0 else None)
+            feats.append(h)
+        feats.append(self._run(self.middle_block, h, None, emb_all, kvs))
+        return feats
+
+    def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales):
+        """Fused path: skips[i] += scales[i] * zero_conv_i(h_i); mid += scales[-1] * middle_block_out(h_mid)
+        (cldm.py:300-303 + :338 + :34-41 in one epilogue per tensor).  `scales[i]` may be a float or a per-pixel
+        fp32 row-scale tensor (ControlNetModel2 scale map, utils/stable_diffusion_controlnet.py:777-802)."""
+        feats = self._features(x_nhwc, emb_all, kvs, guided_hint)
+        targets = list(skips) + [mid]
+        for f, (w, b), tgt, s in zip(feats, self.zero, targets, scales):
+            if torch.is_tensor(s):
+                ops.conv2d(f, w, b, ksize=1, pad=0, row_scale=s, residual=tgt, out=tgt)
+            else:
+                ops.conv2d(f, w, b, ksize=1, pad=0, scale=float(s), residual=tgt, out=tgt)
+
+    def forward(self, x, hint, timesteps, context, **kwargs):
+        """Reference-API path: returns the list of len(input_blocks)+1 residual tensors (NCHW fp32, unscaled)."""
+        emb_all = self.time_embedding(timesteps)
+        kvs = self.project_context(context)
+        feats = self._features(self.to_nhwc(x), emb_all, kvs, self.encode_hint(hint))
+        return [ops.nhwc_to_nchw(ops.conv2d(f, w, b, ksize=1, pad=0)) for f, (w, b) in zip(feats, self.zero)]
+
+
+class ControlledDenoiser:
+    """ControlLDM.apply_model (cldm/cldm.py:328-341) for a fixed (context, hint): the per-call invariants
+    (text K/V of every attention layer, ControlNet hint features) are prepared once, then `eps(x, t)` is the
+    per-step hot function: UNet encoder -> ControlNet (accumulating into the skips) -> UNet decoder."""
+
+    def __init__(self, unet, controlnets=()):
+        self.unet = unet
+        self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
+        self.control_scales = None
+        self.only_mid_control = False
+
+    def prepare(self, context, hints=None, control_scales=None):
+        self.kv_u = self.unet.project_context(context)
+        self.kv_c, self.hints = [], []
+        hints = [] if hints is None else (hints if isinstance(hints, (list, tuple)) else [hints])
+        for cn, hint in zip(self.controlnets, hints):
+            self.kv_c.append(cn.project_context(context))
+            self.hints.append(None if hint is None else cn.encode_hint(hint))
+        n = len(self.unet.plan["input"]) + 1
+        if control_scales is None:
+            control_scales = [[1.0] * n for _ in self.controlnets]
+        elif not isinstance(control_scales[0], (list, tuple)):
+            control_scales = [list(control_scales) for _ in self.controlnets]
+        self.control_scales = control_scales
+
+    def eps(self, x, timesteps):
+        """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32."""
+        u = self.unet
+        emb_u = u.time_embedding(timesteps)
+        xin = u.to_nhwc(x)
+        hs, mid = u.encode(xin, emb_u, self.kv_u)
+        for cn, kv, gh, sc in zip(self.controlnets, self.kv_c, self.hints, self.control_scales):
+            if gh is None:
+                continue
+            emb_c = cn.time_embedding(timesteps)
+            x_cn = xin if cn.cfg["in_channels"] == u.cfg["in_channels"] else cn.to_nhwc(x[:, :cn.cfg["in_channels"]])
+            if self.only_mid_control:
+                sc = [0.0] * (len(sc) - 1) + [sc[-1]]
+            cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc)
+        return u.decode(mid, hs, emb_u, self.kv_u)
+
+    apply_model = eps
