@@ -15,6 +15,23 @@ ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = L.ACT_NONE, L.ACT_SILU, L.ACT_GELU, L.
 
 _WS_BYTES = 384 << 20
 _ws = {}
+# bench.py's roofline leg: when a list, every MFMA GEMM/conv launch appends (algorithmic flops, start, end events)
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, flops):
+    if e0 is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((flops, e0, e1))
 
 
 def _lib():
@@ -79,7 +96,9 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
         out = torch.empty(a.shape[:-1] + (n_out,), dtype=out_dtype, device=a.device)
     ws = workspace(a.device)
     e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
+    ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
+    _prof_end(ev, 2.0 * M * N * K)
     L.check(st, f"ea_gemm_f16 M{M} N{N} K{K}")
     return out
 
@@ -121,7 +140,9 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
         out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
     ws = workspace(x1.device)
     e = _epilogue(out, cout, bias, act, scale, residual, rowvec, s.Hout * s.Wout, row_scale)
+    ev = _prof_begin()
     st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
+    _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1])
     L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
     return out
 
@@ -145,6 +166,9 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
                            ups=False, residual=None, rowvec=None, scale=1.0, out_dtype=torch.float16):
     """ResBlock half (openaimodel.py:254-274) as ONE C-ABI call."""
     _check_dev(x1, w)
+    if PROFILE is not None:     # roofline leg: same kernels, launched separately so events bracket only the MFMA kernel
+        n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add)
+        return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype)
     s = _conv_src(x1, x2, x2_add, 3, stride, pad, ups, None, None)
     cout = w.shape[0]
     ctot = s.c1 + s.c2
@@ -171,6 +195,8 @@ def layernorm(x, gamma, beta, eps=1e-5):
 def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None, out_dtype=torch.float16):
     """LayerNorm -> Linear as one C-ABI call (BasicTransformerBlock norm -> to_q / GEGLU proj)."""
     _check_dev(x, w)
+    if PROFILE is not None:
+        return gemm(layernorm(x, gamma, beta, eps), w, bias, act, residual, out_dtype=out_dtype)
     K = x.shape[-1]
     M = x.numel() // K
     N = w.shape[0]

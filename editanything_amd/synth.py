@@ -14,25 +14,31 @@ import numpy as np
 
 def _param(key, shape, seed):
     rng = np.random.default_rng([seed, zlib.crc32(key.encode())])
+    n = lambda: rng.standard_normal(shape, dtype=np.float32)
     leaf = key.rsplit(".", 1)[-1]
     if key == "pos_embed":
-        return rng.standard_normal(shape) * 0.02
+        return n() * np.float32(0.02)
     if leaf in ("rel_pos_h", "rel_pos_w"):
-        return rng.standard_normal(shape) * 0.1
+        return n() * np.float32(0.1)
     if len(shape) == 1:
         is_norm = any(t in key for t in ("norm", "in_layers.0", "out_layers.0", "out.0", "neck.1", "neck.3"))
         if leaf == "weight" and is_norm:
-            return 1.0 + 0.1 * rng.standard_normal(shape)
+            return np.float32(1.0) + np.float32(0.1) * n()
         if leaf == "bias" and is_norm:
-            return 0.05 * rng.standard_normal(shape)
-        return 0.02 * rng.standard_normal(shape)
+            return np.float32(0.05) * n()
+        return np.float32(0.02) * n()
     fan_in = int(np.prod(shape[1:]))
-    return rng.standard_normal(shape) / np.sqrt(fan_in)
+    return n() * np.float32(1.0 / np.sqrt(fan_in))
 
 
 def synth_state_dict(shapes, seed=0, dtype=np.float32):
-    """{key: numpy array} for an ordered {key: shape} table (editanything_amd.arch.*_param_shapes)."""
-    return {k: _param(k, tuple(s), seed).astype(dtype) for k, s in shapes.items()}
+    """{key: numpy array} for an ordered {key: shape} table (editanything_amd.arch.*_param_shapes).
+    Per-key independent streams -> generated in parallel (numpy releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    items = list(shapes.items())
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        vals = list(ex.map(lambda kv: _param(kv[0], tuple(kv[1]), seed).astype(dtype, copy=False), items))
+    return {k: v for (k, _), v in zip(items, vals)}
 
 
 def synth_state_dict_torch(shapes, seed=0):
