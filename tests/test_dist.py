@@ -1,0 +1,103 @@
+"""Multi-process (world_size 2, gloo, CPU) coverage of the N>1 path: the only collective of the job is the weight
+broadcast; after it ranks are independent and take disjoint image shards.
+
+Spawned with `python -m torch.distributed.run`-style env vars set by hand (rendezvous on 127.0.0.1)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys, json, hashlib
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch
+    from editanything_amd import arch, dist as eadist, synth
+    rank, world, local = eadist.init_from_env(backend="gloo")
+    assert world == 2
+    shapes = arch.unet_param_shapes(arch.TINY_CONTROLNET, True)
+    if rank == 0:
+        sd = synth.synth_state_dict_torch(shapes, 5)
+        sd["_half"] = torch.arange(17, dtype=torch.float16)          # second dtype bucket
+    else:
+        sd = {{k: torch.empty(tuple(s)) for k, s in shapes.items()}}
+        sd["_half"] = torch.empty(17, dtype=torch.float16)
+    out = eadist.broadcast_state_dict(sd, 0, bucket_bytes=64 << 10)   # small buckets -> many flushes
+    ref = synth.synth_state_dict_torch(shapes, 5)
+    ok = all(torch.equal(out[k], ref[k]) for k in ref) and torch.equal(out["_half"], torch.arange(17, dtype=torch.float16))
+    units = eadist.shard_indices(11, rank, world)
+    gathered = eadist.gather_host_objects(units, 0)
+    mx = eadist.max_over_ranks(1.0 + rank)
+    eadist.barrier()
+    h = hashlib.sha1(b"".join(out[k].numpy().tobytes() for k in sorted(ref))).hexdigest()
+    print("RESULT " + json.dumps(dict(rank=rank, ok=bool(ok), units=units, gathered=gathered, mx=mx, sha=h)), flush=True)
+""")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(world, script):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o))
+    return outs
+
+
+def test_weight_broadcast_and_sharding_world2_gloo():
+    import json
+    outs = _spawn(2, WORKER.format(root=ROOT))
+    res = {}
+    for rc, o in outs:
+        assert rc == 0, o
+        line = [l for l in o.splitlines() if l.startswith("RESULT ")][-1]
+        d = json.loads(line[7:])
+        res[d["rank"]] = d
+    assert res[0]["ok"] and res[1]["ok"]
+    assert res[0]["sha"] == res[1]["sha"]                       # identical weights on both ranks after the broadcast
+    assert res[0]["units"] == [0, 2, 4, 6, 8, 10] and res[1]["units"] == [1, 3, 5, 7, 9]
+    assert sorted(res[0]["units"] + res[1]["units"]) == list(range(11))      # disjoint + complete
+    assert res[0]["gathered"] == [res[0]["units"], res[1]["units"]]   # host-side gather on rank 0 only
+    assert res[1]["gathered"] is None
+    assert res[0]["mx"] == 2.0 and res[1]["mx"] == 2.0          # bench.py's max-over-ranks timing
+
+
+@pytest.mark.parametrize("n,world", [(0, 2), (1, 2), (32, 8), (7, 3)])
+def test_shard_indices_partition(n, world):
+    from editanything_amd import dist as eadist
+    parts = [eadist.shard_indices(n, r, world) for r in range(world)]
+    flat = sorted(i for p in parts for i in p)
+    assert flat == list(range(n))
+    assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_single_process_paths_are_noops():
+    import torch
+    from editanything_amd import dist as eadist
+    sd = {"a": torch.ones(3)}
+    assert eadist.broadcast_state_dict(sd)["a"] is sd["a"]
+    assert eadist.gather_host_objects([1, 2]) == [[1, 2]]
+    assert eadist.max_over_ranks(3.5) == 3.5
+    eadist.barrier()
