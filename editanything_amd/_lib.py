@@ -28,7 +28,7 @@ class Epilogue(C.Structure):
         ("rowvec", _vp), ("rowvec_ld", C.c_int32), ("rows_per_group", C.c_int32),
         ("act", C.c_int32), ("scale", C.c_float), ("row_scale", _vp),
         ("residual", _vp), ("residual32", _vp), ("ldr", C.c_int32),
-        ("out", _vp), ("ldc", C.c_int32), ("out_f32", C.c_int32),
+        ("out", _vp), ("ldc", C.c_int32), ("out_f32", C.c_int32), ("geglu_block", C.c_int32),
     ]
 
 

@@ -42,6 +42,7 @@ struct EaEpilogue {
   void* out;              // fp16 or fp32 [M][ldc]
   int ldc;
   int out_f32;
+  int geglu_block;        // GEGLU packing granule (64 or 160)
   int M, N;               // logical output extent (N = N_gemm/2 for GEGLU)
 };
 

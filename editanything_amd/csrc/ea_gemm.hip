@@ -1,5 +1,5 @@
 // ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
-#include "ea_gemm.h"
+#include "ea_gemm2.h"
 #include "../../include/editanything_hip.h"
 
 namespace {
@@ -50,17 +50,110 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
   e.out = epi->out;
   e.ldc = epi->ldc;
   e.out_f32 = epi->out_f32;
+  e.geglu_block = epi->geglu_block > 0 ? epi->geglu_block : 64;
   e.M = M;
   e.N = (epi->act == EA_ACT_GEGLU) ? N / 2 : N;
   if (epi->act < 0 || epi->act > EA_ACT_GEGLU) return EA_ERR_BAD_ARG;
-  if (epi->act == EA_ACT_GEGLU && (N % 64) != 0) return EA_ERR_BAD_SHAPE;
+  if (epi->act == EA_ACT_GEGLU && e.geglu_block != 64 && e.geglu_block != 160) return EA_ERR_UNSUPPORTED;
+  if (epi->act == EA_ACT_GEGLU && (N % e.geglu_block) != 0) return EA_ERR_BAD_SHAPE;
   if (epi->act == EA_ACT_GEGLU && epi->bias_per_row) return EA_ERR_UNSUPPORTED;
   if (e.ldc < e.N) return EA_ERR_BAD_SHAPE;
   if ((e.residual || e.residual32) && e.ldr < e.N) return EA_ERR_BAD_SHAPE;
   return EA_OK;
 }
 
+// ---- fast path (ea_gemm2.h): plan + eligibility
+struct Plan2 {
+  int bn;
+  int tiles;
+  int splits;
+  int ktiles_per_split;
+};
+
+static bool fast_eligible(const EaGemmParams& p) {
+  if (p.K % EA_BK) return false;
+  if (p.N < 64 || p.M < 32) return false;
+  // LDS-DMA goes through 2 GiB buffer descriptors with 32-bit per-lane byte offsets
+  const long long lim = 0x7fffffffLL - 4096;
+  if ((long long)p.N * p.ldw * 2 > lim) return false;
+  if (p.conv) {
+    if ((p.c1 % EA_BK) || (p.c2 % EA_BK) || p.a2_add) return false;
+    const long long cmax = p.c1 > p.c2 ? p.c1 : p.c2;
+    if ((long long)(p.M / (p.Hout * p.Wout) + 1) * p.Hin * p.Win * cmax * 2 > lim) return false;
+  } else {
+    if ((long long)p.M * p.lda * 2 > lim) return false;
+  }
+  if (p.epi.act == EA_ACT_GEGLU) return p.epi.geglu_block == 160 && (p.N % 160) == 0;
+  return true;
+}
+
+// Cost model (microseconds) used to pick the split-K factor: MFMA time of the busiest CU + the fp32 partial
+// round trip and the extra launch.  Constants are measured ballparks, only their ratios matter.
+static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split) {
+  Plan2 t;
+  t.bn = (N % 160 == 0) ? 160 : 128;
+  t.tiles = ((M + 127) / 128) * ((N + t.bn - 1) / t.bn);
+  const int nk = K / EA_BK;
+  const double blocks = (double)t.tiles * batch;
+  const double t_kt = 0.42 * t.bn / 160.0;      // us per 128 x bn x 64 K tile at ~0.6 of the MFMA rate of one CU
+  double best = 1e30;
+  int best_s = 1;
+  const int smax = allow_split ? 16 : 1;
+  for (int s = 1; s <= smax; ++s) {
+    if (s > 1 && nk / s < 4) break;
+    const int kps = (nk + s - 1) / s;
+    const int s_eff = (nk + kps - 1) / kps;
+    const double per_cu = ceil(blocks * s_eff / 256.0);
+    double cost = per_cu * (kps * t_kt + 1.0);
+    if (s_eff > 1) cost += 4.0 + (double)M * N * batch * 4.0 * (2.0 * s_eff + 1.0) / 3.0e6;
+    if (cost < best - 1e-9) { best = cost; best_s = s_eff; }
+  }
+  t.ktiles_per_split = (nk + best_s - 1) / best_s;
+  t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
+  return t;
+}
+
+static int launch_reduce(EaGemmParams& p, void* stream) {
+  const long long total = (long long)p.batch * p.M * ((p.N + 7) / 8);
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  auto rfn = ea_splitk_reduce_kernel;
+  EA_LAUNCH(rfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  return ea_launch_status();
+}
+
+static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
+  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU);
+  p.splits = t.splits;
+  p.ktiles_per_split = t.ktiles_per_split;
+  p.partial = nullptr;
+  if (t.splits > 1) {
+    const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
+    if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
+  }
+  dim3 grid(t.tiles, 1, p.batch * t.splits);
+  dim3 block(256, 1, 1);
+  if (t.bn == 160) {
+    auto kfn = ea_gemm2_kernel<128, 160, 2, 2>;
+    const int smem = 2 * (128 + 160) * 128;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+  } else {
+    auto kfn = ea_gemm2_kernel<128, 128, 2, 2>;
+    const int smem = 2 * (128 + 128) * 128;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+  }
+  int st = ea_launch_status();
+  if (st != EA_OK) return st;
+  if (t.splits > 1) st = launch_reduce(p, stream);
+  return st;
+}
+
 static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
+  if (fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
+  if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
   TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);
   p.splits = t.splits;
@@ -88,14 +181,7 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   }
   int st = ea_launch_status();
   if (st != EA_OK) return st;
-  if (t.splits > 1) {
-    const long long total = (long long)p.batch * p.M * ((p.N + 7) / 8);
-    long long nb = (total + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    auto rfn = ea_splitk_reduce_kernel;
-    EA_LAUNCH(rfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
-    st = ea_launch_status();
-  }
+  if (t.splits > 1) st = launch_reduce(p, stream);
   return st;
 }
 
@@ -104,8 +190,13 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;
   TilePlan t = plan_tiles(M, N, K, batch, 1);
-  if (t.splits <= 1) return 0;
-  return (size_t)batch * t.splits * M * N * sizeof(float);
+  int splits = t.splits;
+  if (K % EA_BK == 0) {
+    Plan2 f = plan_fast(M, N, K, batch, 1);
+    if (f.splits > splits) splits = f.splits;
+  }
+  if (splits <= 1) return 0;
+  return (size_t)batch * splits * M * N * sizeof(float);
 }
 
 extern "C" int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,

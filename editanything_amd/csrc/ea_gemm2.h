@@ -1,0 +1,310 @@
+// ea_gemm2.h -- the fast MFMA contraction kernel (LDS-DMA staged, 160-wide tiles).
+//
+// Same contract as ea_gemm.h's kernel (C = epilogue(A W^T), A dense or the implicit
+// im2col of an NHWC activation) for the aligned shapes the hot path is made of:
+// K % 64 == 0 and, for convolutions, channel counts that are multiples of 64 -- i.e.
+// every ResBlock / Up / Downsample conv (openaimodel.py:108-152,200-231), zero-conv
+// (cldm/cldm.py:281-305) and transformer Linear (attention.py:54,152-160,316-339) of
+// SD2.1/SD1.5, the SAM ViT Linears and the VAE convs.  ea_gemm.h stays as the generic
+// path (ragged K, Cin = 4/8/16/96, x2_add).
+//
+// MI355X design (cdna_hip_programming.md section 5 / T2 / rule 21):
+//  * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave
+//    instruction, no VGPR round trip, no ds_write pass).  The LDS image of a wave
+//    instruction is lane-linear, so the bank-conflict XOR swizzle is applied on the
+//    per-lane SOURCE chunk and again on the fragment read (the same involution).
+//    Buffer descriptors give the zero fill for free: convolution padding and ragged
+//    M / N edges use an out-of-range per-lane offset, which the hardware returns as 0.
+//  * the im2col address is tracked incrementally: K is ordered (tap, cin), a 64-wide
+//    K tile never straddles a tap or a concat source, so per K tile only the scalar
+//    offset moves (no vector ALU work at all in the steady state); per-lane pixel
+//    offsets + validity are recomputed when the tap or the concat source changes.
+//  * 160-wide N tiles: every channel count of the UNet/ControlNet (320/640/1280 and
+//    their 3x/8x products) is a multiple of 160, so 128x160 tiles cover
+//    [32768 x 320] with exactly 512 workgroups = 2 per CU and [8192 x 640] with 256.
+//    v_mfma_f32_16x16x32_f16, 4 waves as 2x2, wave tile 64x80 (4x5 MFMA tiles, 80
+//    accumulator VGPRs); 2-stage LDS ring (72 KiB) -> two workgroups per CU, whose
+//    barriers / DMA waits overlap each other's MFMA phases.
+//  * epilogue staged through LDS (fp32) one 64-row half at a time so every global
+//    access is a 16-byte coalesced one; GEGLU pairs column c with c + BN/2 there.
+#pragma once
+#include "ea_gemm.h"
+
+#define EA_OOB 0xFFFFFFF0u  // per-lane byte offset beyond any descriptor: the DMA writes zeros
+#define EA_BUF_BYTES 0x80000000u
+
+#ifdef EA_EMU
+__device__ __forceinline__ f32x4 ea_mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+  char* s = ea_emu::wave_scratch();
+  int l = ea_emu::lane_id();
+  memcpy(s + l * 64, &a, 16);
+  memcpy(s + l * 64 + 16, &b, 16);
+  ea_emu::wave_sync();
+  const int col = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int row = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 32; ++k) {
+      f16 av, bv;
+      memcpy(&av, s + (row + 16 * (k >> 3)) * 64 + (k & 7) * 2, 2);
+      memcpy(&bv, s + (col + 16 * (k >> 3)) * 64 + 16 + (k & 7) * 2, 2);
+      acc += (float)av * (float)bv;
+    }
+    c[r] = acc;
+  }
+  ea_emu::wave_sync();
+  return c;
+}
+typedef const char* ea_rsrc;
+__device__ __forceinline__ ea_rsrc ea_make_rsrc(const void* p) { return (const char*)p; }
+// LDS-DMA: lane l's 16 bytes land at (wave-uniform) lds_base + 16*l; out-of-range lanes get zeros
+__device__ __forceinline__ void ea_dma16(ea_rsrc r, unsigned voff, unsigned soff, char* lds_base) {
+  char* dst = lds_base + 16 * ea_emu::lane_id();
+  if (voff >= EA_BUF_BYTES) memset(dst, 0, 16);
+  else memcpy(dst, r + voff + soff, 16);
+}
+__device__ __forceinline__ int ea_uniform(int v) { return v; }
+#else
+// v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8*(l >> 4) + j], B[k = 8*(l >> 4) + j][n = l & 15],
+// C/D reg r < 4: col = l & 15, row = 4*(l >> 4) + r.
+__device__ __forceinline__ f32x4 ea_mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+typedef __amdgpu_buffer_rsrc_t ea_rsrc;
+__device__ __forceinline__ ea_rsrc ea_make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, EA_BUF_BYTES, 0x00020000);
+}
+__device__ __forceinline__ void ea_dma16(ea_rsrc r, unsigned voff, unsigned soff, char* lds_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ int ea_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
+// 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
+__device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
+  constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int EPI_LD = BN + 4;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile shape");
+  EA_SMEM(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = ea_uniform(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
+  const int tile = ea_xcd_remap(blockIdx.x, ntile);
+  // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
+  // (K position, descriptors, scalar offsets) stays in SGPRs -- otherwise every DMA is wrapped in a waterfall loop (T20)
+  const int tm = ea_uniform(tile / tiles_n), tn = tile - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int bz = blockIdx.z;
+  const int batch = ea_uniform(bz / p.splits), split = bz - batch * p.splits;
+
+  const int nk_total = p.K / EA_BK;
+  const int kt_begin = split * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > nk_total) kt_end = nk_total;
+  const int nk = kt_end - kt_begin;
+
+  const ea_rsrc rs_a1 = ea_make_rsrc(p.a1 + batch * p.strideA);
+  const ea_rsrc rs_a2 = ea_make_rsrc(p.a2 ? p.a2 + batch * p.strideA : p.a1);
+  const ea_rsrc rs_w = ea_make_rsrc(p.w + batch * p.strideW);
+
+  // ---- per-lane DMA coordinates: instruction j of this wave covers LDS rows (j*NW + wave)*8 .. +7
+  const int lrow = lane >> 3, slot = lane & 7;
+  int a_y[A_PW], a_x[A_PW];   // conv: input-space origin of the row's pixel
+  int a_base[A_PW];           // conv: b*Hin*Win (pixel index of the sample), -1 = row out of range
+  unsigned a_chunk[A_PW];     // element offset of the (swizzled) 16-B chunk this lane fetches
+  unsigned a_voff[A_PW];      // per-lane byte offset of the DMA (EA_OOB -> zeros)
+#pragma unroll
+  for (int j = 0; j < A_PW; ++j) {
+    const int r = (j * NW + wave) * 8 + lrow;
+    a_chunk[j] = (unsigned)((slot ^ ea_swz(r)) * 8);
+    const int m = m0 + r;
+    const bool ok = (r < BM) && (m < p.M);
+    a_y[j] = a_x[j] = 0;
+    a_base[j] = -1;
+    a_voff[j] = EA_OOB;
+    if (ok) {
+      if (p.conv) {
+        const int hw = p.Hout * p.Wout;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wout;
+        a_base[j] = b * p.Hin * p.Win;
+        a_y[j] = oy * p.stride - p.pad;
+        a_x[j] = (rem - oy * p.Wout) * p.stride - p.pad;
+      } else {
+        a_voff[j] = ((unsigned)m * (unsigned)p.lda + a_chunk[j]) * 2u;
+      }
+    }
+  }
+  unsigned b_voff[B_PW];
+#pragma unroll
+  for (int j = 0; j < B_PW; ++j) {
+    const int r = (j * NW + wave) * 8 + lrow;
+    const int n = n0 + r;
+    b_voff[j] = (r < BN && n < p.N) ? ((unsigned)n * (unsigned)p.ldw + (unsigned)((slot ^ ea_swz(r)) * 8)) * 2u : EA_OOB;
+  }
+
+  const int ctot = p.c1 + p.c2;
+  int k_cur = kt_begin * EA_BK;  // first K element of the next tile to stage
+  int tap = 0, cin = 0;
+  // conv: per-lane offsets for the current (tap, concat source); runs when either changes (every >= c/64 K tiles)
+  auto set_voff = [&]() {
+    const int ky = (p.ksize == 3) ? tap / 3 : 0;
+    const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
+    const int hlim = p.ups ? 2 * p.Hin : p.Hin;
+    const int wlim = p.ups ? 2 * p.Win : p.Win;
+    const unsigned cs = (unsigned)(cin >= p.c1 ? p.c2 : p.c1);
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+      int iy = a_y[j] + ky, ix = a_x[j] + kx;
+      const bool ok = a_base[j] >= 0 && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+      if (p.ups) { iy >>= 1; ix >>= 1; }
+      a_voff[j] = ok ? ((unsigned)(a_base[j] + iy * p.Win + ix) * cs + a_chunk[j]) * 2u : EA_OOB;
+    }
+  };
+  if (p.conv) {
+    tap = ea_uniform(k_cur / ctot);
+    cin = k_cur - tap * ctot;
+    set_voff();
+  }
+
+  auto issue_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE_BYTES;
+    char* sb = sa + BM * 128;
+    k_cur = ea_uniform(k_cur);   // loop-carried scalars: keep them provably wave-uniform (SGPR descriptors / offsets)
+    cin = ea_uniform(cin);
+    tap = ea_uniform(tap);
+    const bool second = p.conv && cin >= p.c1;
+    const ea_rsrc rs_a = second ? rs_a2 : rs_a1;
+    const unsigned soff_a = (unsigned)(p.conv ? (second ? cin - p.c1 : cin) : k_cur) * 2u;
+    const unsigned soff_b = (unsigned)k_cur * 2u;
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j)
+      if (A_INSTR % NW == 0 || j * NW + wave < A_INSTR) ea_dma16(rs_a, a_voff[j], soff_a, sa + (j * NW + wave) * 1024);
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j)
+      if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff_b, sb + (j * NW + wave) * 1024);
+    k_cur += EA_BK;
+    if (p.conv) {
+      cin += EA_BK;
+      if (cin >= ctot) {
+        cin = 0;
+        ++tap;
+        set_voff();
+      } else if (cin == p.c1) {
+        set_voff();
+      }
+    }
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+  // fragment read coordinates: row (lane & 15) of a 16-row MFMA tile, 16-B chunk (lane >> 4) of a 32-wide K step
+  const int frow = lane & 15, fq = lane >> 4;
+  if (nk > 0) issue_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // waits for this wave's own LDS-DMA (vmcnt) and then for everyone's: tile kt is complete in LDS and every wave
+    // has finished reading the buffer tile kt+1 is about to overwrite.
+    __syncthreads();
+    if (kt + 1 < nk) issue_tile((kt + 1) & 1);
+    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+    const char* sb = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = ks * 4 + fq;
+      f16x8 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WTM + i * 16 + frow;
+        fa[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int r = wn * WTN + j * 16 + frow;
+        fb[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = ea_mfma_16x16x32(fa[i], fb[j], acc[i][j]);
+    }
+  }
+
+  // ------------------------------------------------------------- epilogue
+  // One WTM-row slab (the waves with wm == pass) at a time through LDS: fp32 [WTM][BN + 4].
+  float* stg = reinterpret_cast<float*>(smem);
+  const EaEpilogue& e = p.epi;
+  const bool raw = p.splits > 1;
+  const bool geglu = (!raw) && e.act == EA_ACT_GEGLU;
+  const int tile_cols = geglu ? BN / 2 : BN;
+  const int ncol0 = geglu ? n0 / 2 : n0;
+  const int vec_per_row = tile_cols / 8;
+#pragma unroll 1
+  for (int pass = 0; pass < WM; ++pass) {
+    __syncthreads();  // K loop (pass 0) / previous slab fully consumed
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stg[(i * 16 + fq * 4 + r) * EPI_LD + wn * WTN + j * 16 + frow] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < WTM * vec_per_row; idx += NT) {
+      const int row = idx / vec_per_row;
+      const int cv = (idx - row * vec_per_row) * 8;
+      const int m = m0 + pass * WTM + row, n = ncol0 + cv;
+      float v[8];
+      if (geglu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float val = stg[row * EPI_LD + cv + j], gate = stg[row * EPI_LD + BN / 2 + cv + j];
+          if (e.bias) {
+            val += e.bias[n0 + cv + j];
+            gate += e.bias[n0 + BN / 2 + cv + j];
+          }
+          v[j] = val * ea_gelu_erf(gate);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = stg[row * EPI_LD + cv + j];
+      }
+      if (raw) {
+        if (m < p.M && n < p.N) {
+          float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
+          const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
+          if (nvalid == 8 && (p.N & 3) == 0) {
+            f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+            *reinterpret_cast<f32x4*>(dst) = lo;
+            *reinterpret_cast<f32x4*>(dst + 4) = hi;
+          } else {
+            for (int j = 0; j < nvalid; ++j) dst[j] = v[j];
+          }
+        }
+      } else {
+        ea_epilogue_store8(e, batch * p.strideC, batch * p.strideR, m, n, v, !geglu);
+      }
+    }
+  }
+}

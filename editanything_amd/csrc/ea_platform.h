@@ -50,8 +50,11 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   ea_emu::launch((grid), (block), (smem), [&]() { kfn(__VA_ARGS__); })
 static inline int ea_launch_status() { return EA_OK; }
 #else
+// hipGetLastError() is per-thread and sticky: the host runtime around us (PyTorch's caching allocators poll
+// hipEventQuery, which records hipErrorNotReady) can leave a stale code behind, so it is cleared right before each
+// launch and ea_launch_status() then reports only this launch's own outcome.
 #define EA_LAUNCH(kfn, grid, block, smem, stream, ...) \
-  kfn<<<(grid), (block), (smem), (hipStream_t)(stream)>>>(__VA_ARGS__)
+  do { (void)hipGetLastError(); kfn<<<(grid), (block), (smem), (hipStream_t)(stream)>>>(__VA_ARGS__); } while (0)
 static inline int ea_launch_status() {
   return hipGetLastError() == hipSuccess ? EA_OK : EA_ERR_LAUNCH;
 }

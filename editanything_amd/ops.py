@@ -81,6 +81,7 @@ def _epilogue(out, n_out, bias=None, act=ACT_NONE, scale=1.0, residual=None, row
     e.out = _p(out)
     e.ldc = n_out
     e.out_f32 = int(out.dtype == torch.float32)
+    e.geglu_block = 0
     return e
 
 
@@ -96,6 +97,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
         out = torch.empty(a.shape[:-1] + (n_out,), dtype=out_dtype, device=a.device)
     ws = workspace(a.device)
     e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
+    if act == ACT_GEGLU:
+        e.geglu_block = 160 if (N % 160 == 0 and K % 64 == 0) else 64      # must match unet.pack_geglu
     ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
     _prof_end(ev, 2.0 * M * N * K)
@@ -205,6 +208,8 @@ def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None,
     out = torch.empty(x.shape[:-1] + (n_out,), dtype=out_dtype, device=x.device)
     ws = workspace(x.device)
     e = _epilogue(out, n_out, bias, act, 1.0, residual)
+    if act == ACT_GEGLU:
+        e.geglu_block = 160 if (N % 160 == 0 and K % 64 == 0) else 64
     st = _lib().ea_ln_gemm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), eps, _p(ln_out), _p(w),
                                w.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream())
     L.check(st, "ea_ln_gemm_f16")

@@ -44,12 +44,19 @@ def pack_conv(w, device):
     return _f16(w.reshape(cout, k * k * cin8), device)
 
 
+def geglu_block(n_gemm, k):
+    """Packing granule of the EA_ACT_GEGLU weight rows: 160 when the fast 160-wide-tile kernel applies
+    (every SD2.1/SD1.5 width), else the generic kernel's 64."""
+    return 160 if (n_gemm % 160 == 0 and k % 64 == 0) else 64
+
+
 def pack_geglu(w, b):
-    """ff.net.0.proj [8C, C]: rows [0,4C) are values, [4C,8C) gates -> interleave as [32 value | 32 gate] per 64
-    rows so the GEMM epilogue finds value and gate of one output in the same lane (EA_ACT_GEGLU)."""
+    """ff.net.0.proj [8C, C]: rows [0,4C) are values, [4C,8C) gates -> interleave as [G/2 value | G/2 gate] per G
+    rows so the GEMM epilogue finds value and gate of one output in the same workgroup tile (EA_ACT_GEGLU)."""
     half = w.shape[0] // 2
-    wv, wg = w[:half].reshape(half // 32, 32, -1), w[half:].reshape(half // 32, 32, -1)
-    bv, bg = b[:half].reshape(half // 32, 32), b[half:].reshape(half // 32, 32)
+    g2 = geglu_block(w.shape[0], w.shape[1]) // 2
+    wv, wg = w[:half].reshape(half // g2, g2, -1), w[half:].reshape(half // g2, g2, -1)
+    bv, bg = b[:half].reshape(half // g2, g2), b[half:].reshape(half // g2, g2)
     return torch.cat([wv, wg], 1).reshape(2 * half, -1), torch.cat([bv, bg], 1).reshape(2 * half)
 
 

@@ -46,7 +46,7 @@ extern "C" {
 #define EA_ACT_NONE 0
 #define EA_ACT_SILU 1
 #define EA_ACT_GELU 2  /* exact erf GELU */
-#define EA_ACT_GEGLU 3 /* weight rows packed [32 value | 32 gate] per 64; N_out = N/2 */
+#define EA_ACT_GEGLU 3 /* weight rows packed [G/2 value | G/2 gate] per G = geglu_block rows; N_out = N/2 */
 
 /* Fused GEMM/conv epilogue: out = residual + scale*row_scale[m]*act(acc + bias + rowvec[m/rows_per_group]) */
 typedef struct ea_epilogue {
@@ -64,6 +64,7 @@ typedef struct ea_epilogue {
   void* out;              /* fp16 (out_f32=0) or fp32 [M][ldc] */
   int32_t ldc;
   int32_t out_f32;
+  int32_t geglu_block;    /* EA_ACT_GEGLU packing granule G: 64 (0 means 64) or 160 (N % 160 == 0, K % 64 == 0) */
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and

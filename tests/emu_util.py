@@ -77,7 +77,7 @@ def _is_f32(a):
 
 
 def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual32=None, ldr=None, rowvec=None,
-             rows_per_group=1, row_scale=None, bias_per_row=0):
+             rows_per_group=1, row_scale=None, bias_per_row=0, geglu_block=0):
     e = L.Epilogue()
     e.bias = ptr(bias)
     e.bias_per_row = bias_per_row
@@ -94,6 +94,7 @@ def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual
     e.out = ptr(out)
     e.ldc = n if ldc is None else ldc
     e.out_f32 = int(_is_f32(out))
+    e.geglu_block = geglu_block
     return e
 
 

@@ -79,6 +79,79 @@ def test_gemm(kb, M, N, K, batch, act, res, f32out):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,batch,act,res,f32out,gb", [
+    (200, 160, 128, 1, 0, True, False, 0),     # 128x160 tile, ragged M
+    (128, 320, 64, 1, 3, True, False, 160),    # GEGLU, 160-row packing (value | gate per workgroup tile)
+    (130, 192, 192, 1, 2, False, True, 0),     # 128x128 tile, ragged M and N, fp32 out
+    (128, 160, 2048, 1, 0, True, False, 0),    # split-K through the LDS-DMA kernel + reduce
+    (96, 160, 64, 2, 1, False, False, 0),      # batched
+])
+def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
+    """ea_gemm2.h (LDS-DMA staged, 16x16x32 MFMA): selected for K % 64 == 0, N >= 64."""
+    A, W = f16(batch, M, K), f16(batch, N, K, scale=0.2)
+    bias = f32(N)
+    No = N // 2 if act == 3 else N
+    R = f16(batch, M, No) if res else None
+    out = kb.zeros((batch, M, No), np.float32 if f32out else np.float16)
+    e = epilogue(out, bias=bias, act=act, residual=R, geglu_block=gb)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, batch))
+    st = kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, batch, M * K, N * K, M * No, M * No, C.byref(e), ptr(ws),
+                            ws_nbytes(ws), kb.stream)
+    assert st == 0
+    ref = torch.einsum("bmk,bnk->bmn", t(A), t(W)) + t(bias)
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    elif act == 3:
+        r = ref.reshape(batch, M, N // gb, 2, gb // 2)
+        ref = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(batch, M, No)
+    if res:
+        ref = ref + t(R)
+    assert relerr(kb.down(out), ref.numpy()) < 2e-3
+
+
+def test_gemm_geglu_160_needs_fast_path(kb):
+    """geglu_block = 160 exists only in the LDS-DMA kernel: a K that is not a multiple of 64 is refused, not mis-paired."""
+    M, N, K = 64, 160, 72
+    out = kb.zeros((M, N // 2), np.float16)
+    e = epilogue(out, act=3, geglu_block=160)
+    A, W = f16(M, K), f16(N, K)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == -3
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,ksize,stride,ups,pad,asym", [
+    (2, 8, 8, 64, 0, 160, 3, 1, 0, 1, False),    # ResBlock conv, 160-wide tile
+    (1, 9, 7, 64, 64, 64, 3, 1, 0, 1, False),    # concat(h, skip) never materialised, ragged spatial
+    (2, 8, 8, 128, 0, 64, 3, 2, 0, 1, False),    # Downsample
+    (1, 6, 6, 64, 0, 128, 3, 1, 1, 1, False),    # Upsample (nearest 2x fused into the im2col address)
+    (1, 8, 8, 64, 0, 64, 3, 2, 0, 0, True),      # VAE Downsample pad (0,1,0,1)
+    (2, 6, 6, 64, 128, 160, 1, 1, 0, 0, False),  # 1x1 skip_connection over two sources
+])
+def test_conv_fast_path(kb, B, H, W, c1, c2, cout, ksize, stride, ups, pad, asym):
+    x1 = f16(B, H, W, c1)
+    x2 = f16(B, H, W, c2) if c2 else None
+    w = f16(cout, c1 + c2, ksize, ksize, scale=0.1)
+    bias = f32(cout)
+    xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    if asym:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), t(w), t(bias), stride=2, padding=0)
+    else:
+        ref = F.conv2d(xin, t(w), t(bias), stride=stride, padding=pad)
+    ho, wo = ref.shape[2], ref.shape[3]
+    src = conv_src(x1, x2, None, ksize, stride, pad, ups, ho, wo)
+    out = kb.zeros((B, ho, wo, cout), np.float16)
+    e = epilogue(out.reshape(-1, cout), bias=bias)
+    wp = pack_conv_w(w)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(B * ho * wo, cout, ksize * ksize * (c1 + c2), 1))
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(wp), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    assert relerr(kb.down(out), ref.permute(0, 2, 3, 1).numpy()) < 3e-3
+
+
 def test_gemm_rowvec_rowscale_bias_per_row(kb):
     M, N, K, hw = 96, 72, 64, 32
     A, W = f16(M, K), f16(N, K)
