@@ -1,5 +1,6 @@
 // ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
 #include "ea_gemm2.h"
+#include <stdlib.h>
 #include "../../include/editanything_hip.h"
 
 namespace {
@@ -64,7 +65,7 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
 
 // ---- fast path (ea_gemm2.h): plan + eligibility
 struct Plan2 {
-  int bn;
+  int bm, bn, stages;
   int tiles;
   int splits;
   int ktiles_per_split;
@@ -87,29 +88,52 @@ static bool fast_eligible(const EaGemmParams& p) {
   return true;
 }
 
-// Cost model (microseconds) used to pick the split-K factor: MFMA time of the busiest CU + the fp32 partial
-// round trip and the extra launch.  Constants are measured ballparks, only their ratios matter.
+// Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
+//   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
+//   EA_GEMM2_VARIANT=0|1|2|3   0 auto, 1: 128-row tiles 2-stage, 2: 128-row tiles 3-stage, 3: 256-row tiles 3-stage
+static int g_force_generic = 0, g_variant = 0;
+static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
+  const char* f = getenv("EA_GEMM_FORCE");
+  g_force_generic = (f && !strcmp(f, "generic")) ? 1 : 0;
+  const char* v = getenv("EA_GEMM2_VARIANT");
+  g_variant = (v && *v) ? atoi(v) : 0;
+}
+
+// Cost model (microseconds) used to pick the tile height and the split-K factor: MFMA time of the busiest CU + the
+// fp32 partial round trip and the extra launch.  Constants are measured ballparks, only their ratios matter.
+static double plan_cost(int bm, int bn, int M, int N, int K, int batch, int s, int* kps_out, int* s_eff_out) {
+  const int nk = K / EA_BK;
+  const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
+  const int kps = (nk + s - 1) / s;
+  const int s_eff = (nk + kps - 1) / kps;
+  const double t_kt = 0.42 * (bm / 128.0) * (bn / 160.0) * (bm == 256 ? 0.85 : 1.0);  // us per K tile per workgroup
+  const double per_cu = ceil(tiles * s_eff / 256.0);
+  double cost = per_cu * (kps * t_kt + 1.5);
+  if (s_eff > 1) cost += 4.0 + (double)M * N * batch * 4.0 * (2.0 * s_eff + 1.0) / 3.0e6;
+  *kps_out = kps;
+  *s_eff_out = s_eff;
+  return cost;
+}
+
 static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split) {
+  read_env();
   Plan2 t;
   t.bn = (N % 160 == 0) ? 160 : 128;
-  t.tiles = ((M + 127) / 128) * ((N + t.bn - 1) / t.bn);
   const int nk = K / EA_BK;
-  const double blocks = (double)t.tiles * batch;
-  const double t_kt = 0.42 * t.bn / 160.0;      // us per 128 x bn x 64 K tile at ~0.6 of the MFMA rate of one CU
   double best = 1e30;
-  int best_s = 1;
-  const int smax = allow_split ? 16 : 1;
-  for (int s = 1; s <= smax; ++s) {
-    if (s > 1 && nk / s < 4) break;
-    const int kps = (nk + s - 1) / s;
-    const int s_eff = (nk + kps - 1) / kps;
-    const double per_cu = ceil(blocks * s_eff / 256.0);
-    double cost = per_cu * (kps * t_kt + 1.0);
-    if (s_eff > 1) cost += 4.0 + (double)M * N * batch * 4.0 * (2.0 * s_eff + 1.0) / 3.0e6;
-    if (cost < best - 1e-9) { best = cost; best_s = s_eff; }
+  t.bm = 128; t.splits = 1; t.ktiles_per_split = nk;
+  const int bm_lo = (g_variant == 3) ? 256 : 128, bm_hi = (g_variant == 1 || g_variant == 2) ? 128 : 256;
+  for (int bm = bm_lo; bm <= bm_hi; bm *= 2) {
+    const int smax = allow_split ? 16 : 1;
+    for (int s = 1; s <= smax; ++s) {
+      if (s > 1 && nk / s < 4) break;
+      int kps, s_eff;
+      const double c = plan_cost(bm, t.bn, M, N, K, batch, s, &kps, &s_eff);
+      if (c < best - 1e-9) { best = c; t.bm = bm; t.splits = s_eff; t.ktiles_per_split = kps; }
+    }
   }
-  t.ktiles_per_split = (nk + best_s - 1) / best_s;
-  t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
+  t.stages = (t.bm == 256 || g_variant == 2) ? 3 : 2;
+  t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
 
@@ -133,18 +157,24 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     p.partial = (float*)workspace;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
-  dim3 block(256, 1, 1);
-  if (t.bn == 160) {
-    auto kfn = ea_gemm2_kernel<128, 160, 2, 2>;
-    const int smem = 2 * (128 + 160) * 128;
-    ea_allow_big_lds(kfn, smem);
-    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_)                                         \
+  do {                                                                                \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_>;                              \
+    const int smem = ST_ * (BM_ + BN_) * 128;                                         \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64, 1, 1), smem, stream, p);                \
+  } while (0)
+  if (t.bm == 256) {
+    if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3);
+    else EA_LAUNCH_G2(256, 128, 4, 2, 3);
+  } else if (t.stages == 3) {
+    if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3);
+    else EA_LAUNCH_G2(128, 128, 2, 2, 3);
   } else {
-    auto kfn = ea_gemm2_kernel<128, 128, 2, 2>;
-    const int smem = 2 * (128 + 128) * 128;
-    ea_allow_big_lds(kfn, smem);
-    EA_LAUNCH(kfn, grid, block, smem, stream, p);
+    if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2);
+    else EA_LAUNCH_G2(128, 128, 2, 2, 2);
   }
+#undef EA_LAUNCH_G2
   int st = ea_launch_status();
   if (st != EA_OK) return st;
   if (t.splits > 1) st = launch_reduce(p, stream);
@@ -152,7 +182,8 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 }
 
 static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
-  if (fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
+  read_env();
+  if (!g_force_generic && fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
   if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
   TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);

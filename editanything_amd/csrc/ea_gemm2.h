@@ -64,6 +64,8 @@ __device__ __forceinline__ void ea_dma16(ea_rsrc r, unsigned voff, unsigned soff
   else memcpy(dst, r + voff + soff, 16);
 }
 __device__ __forceinline__ int ea_uniform(int v) { return v; }
+template <int N> __device__ __forceinline__ void ea_wait_dma() {}
+__device__ __forceinline__ void ea_raw_barrier() { ea_emu::block_sync(); }
 #else
 // v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8*(l >> 4) + j], B[k = 8*(l >> 4) + j][n = l & 15],
 // C/D reg r < 4: col = l & 15, row = 4*(l >> 4) + r.
@@ -78,12 +80,23 @@ __device__ __forceinline__ void ea_dma16(ea_rsrc r, unsigned voff, unsigned soff
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
 }
 __device__ __forceinline__ int ea_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Counted wait: returns when at most N of this wave's LDS-DMA instructions are still in flight (they complete in
+// order), so younger tiles keep streaming across the barrier (guide T3+T4; never __syncthreads() here: its fence
+// would drain vmcnt to 0).
+template <int N> __device__ __forceinline__ void ea_wait_dma() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void ea_raw_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 #endif
 
 // 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
 __device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int STAGES>
 __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -220,13 +233,8 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
 
   // fragment read coordinates: row (lane & 15) of a 16-row MFMA tile, 16-B chunk (lane >> 4) of a 32-wide K step
   const int frow = lane & 15, fq = lane >> 4;
-  if (nk > 0) issue_tile(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    // waits for this wave's own LDS-DMA (vmcnt) and then for everyone's: tile kt is complete in LDS and every wave
-    // has finished reading the buffer tile kt+1 is about to overwrite.
-    __syncthreads();
-    if (kt + 1 < nk) issue_tile((kt + 1) & 1);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+  auto compute_tile = [&](int buf) {
+    const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -246,6 +254,40 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = ea_mfma_16x16x32(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
+  if (STAGES == 2) {
+    if (nk > 0) issue_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
+      // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
+      __syncthreads();
+      if (kt + 1 < nk) issue_tile((kt + 1) & 1);
+      compute_tile(kt & 1);
+    }
+  } else {
+    // 3-deep ring, two tiles in flight: at iteration kt wait until only tile kt+1's DMA group is outstanding (counted
+    // vmcnt), barrier (tile kt visible to all waves; all waves are past compute(kt-1), whose buffer tile kt+2 reuses),
+    // issue tile kt+2, compute tile kt.
+    constexpr int B_EXTRA = B_INSTR % NW;   // waves [0, B_EXTRA) issue one more B instruction per tile
+    constexpr int A_EXTRA = A_INSTR % NW;
+    static_assert(A_EXTRA == 0, "A rows must divide evenly over the waves");
+    constexpr int PER_TILE_LO = A_PW + B_INSTR / NW;
+    if (nk > 0) issue_tile(0);
+    if (nk > 1) issue_tile(1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        if (B_EXTRA != 0 && wave < B_EXTRA) ea_wait_dma<PER_TILE_LO + 1>();
+        else ea_wait_dma<PER_TILE_LO>();
+      } else {
+        ea_wait_dma<0>();
+      }
+      ea_raw_barrier();
+      if (kt + 2 < nk) issue_tile(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
+      compute_tile(cur);
+      cur = (cur == 2) ? 0 : cur + 1;
     }
   }
 

@@ -111,6 +111,47 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("M,N,K,act,gb", [(300, 160, 512, 0, 0), (256, 320, 192, 3, 160), (260, 128, 64, 1, 0),
+                                          (128, 160, 2048, 0, 0)])
+def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
+    """3-stage counted-vmcnt ring (variant 2: 128-row tiles, 3: 256-row / 8-wave tiles) against the same reference."""
+    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
+    bias = f32(N)
+    No = N // 2 if act == 3 else N
+    R = f16(1, M, No)
+    out = kb.zeros((1, M, No), np.float16)
+    e = epilogue(out, bias=bias, act=act, residual=R, geglu_block=gb)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws),
+                              kb.stream) == 0
+    ref = torch.einsum("bmk,bnk->bmn", t(A), t(W)) + t(bias)
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 3:
+        r = ref.reshape(1, M, N // gb, 2, gb // 2)
+        ref = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(1, M, No)
+    ref = ref + t(R)
+    assert relerr(kb.down(out), ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_conv_fast_path_variants(kb, variant, monkeypatch):
+    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    B, H, W_, c1, c2, cout = 2, 12, 12, 64, 64, 160
+    x1, x2 = f16(B, H, W_, c1), f16(B, H, W_, c2)
+    w, bias = f16(cout, c1 + c2, 3, 3, scale=0.1), f32(cout)
+    ref = F.conv2d(torch.cat([t(x1), t(x2)], -1).permute(0, 3, 1, 2), t(w), t(bias), padding=1)
+    src = conv_src(x1, x2, None, 3, 1, 1, 0, H, W_)
+    out = kb.zeros((B, H, W_, cout), np.float16)
+    e = epilogue(out.reshape(-1, cout), bias=bias)
+    wp = pack_conv_w(w)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(B * H * W_, cout, 9 * (c1 + c2), 1))
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(wp), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    assert relerr(kb.down(out), ref.permute(0, 2, 3, 1).numpy()) < 3e-3
+
+
 def test_gemm_geglu_160_needs_fast_path(kb):
     """geglu_block = 160 exists only in the LDS-DMA kernel: a K that is not a multiple of 64 is refused, not mis-paired."""
     M, N, K = 64, 160, 72

@@ -32,8 +32,9 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def epi(out, N, bias=None, act=0, residual=None):
+def epi(out, N, bias=None, act=0, residual=None, geglu_block=0):
     e = L.Epilogue()
+    e.geglu_block = geglu_block
     e.bias = bias.data_ptr() if bias is not None else None
     e.act = act
     e.scale = 1.0
@@ -48,8 +49,13 @@ def epi(out, N, bias=None, act=0, residual=None):
 results = []
 
 
+VARIANT = ""
+
+
 def report(name, secs, flops=None, bytes_=None):
     r = {"case": name, "us": round(secs * 1e6, 2)}
+    if VARIANT:
+        r["variant"] = VARIANT
     if flops:
         r["tflops"] = round(flops / secs / 1e12, 1)
         r["mfma_frac"] = round(flops / secs / 1e12 / PEAK_TF, 4)
@@ -66,7 +72,8 @@ def bench_gemm(M, N, K, act=0):
     bias = torch.randn(N, device=dev)
     No = N // 2 if act == 3 else N
     out = torch.empty(M, No, device=dev, dtype=torch.half)
-    e = epi(out, No, bias, act)
+    gb = 160 if (act == 3 and N % 160 == 0 and K % 64 == 0 and os.environ.get("EA_GEMM_FORCE") != "generic") else 0
+    e = epi(out, No, bias, act, geglu_block=gb)
     fn = lambda: lib.ea_gemm_f16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), WS.data_ptr(),
                                  WS.numel(), stream)
     assert fn() == 0
@@ -129,25 +136,42 @@ def bench_ln(M, Cc):
     report(f"layernorm M{M} C{Cc}", timeit(fn), bytes_=2.0 * x.numel() * 2)
 
 
-if __name__ == "__main__":
+def set_variant(v):
+    """v: "generic" (ea_gemm.h), "auto", or "1"/"2"/"3" (EA_GEMM2_VARIANT)."""
+    global VARIANT
+    VARIANT = v
+    os.environ.pop("EA_GEMM_FORCE", None)
+    os.environ.pop("EA_GEMM2_VARIANT", None)
+    if v == "generic":
+        os.environ["EA_GEMM_FORCE"] = "generic"
+    elif v not in ("auto", ""):
+        os.environ["EA_GEMM2_VARIANT"] = v
+
+
+def gemm_suite():
     B = 8
-    # UNet ResBlock convs per level (network batch 8)
+    # UNet / ControlNet convs, by share of the per-eval FLOPs (network batch 8)
     bench_conv(B, 64, 320, 0, 320)
     bench_conv(B, 32, 640, 0, 640)
     bench_conv(B, 16, 1280, 0, 1280)
     bench_conv(B, 8, 1280, 0, 1280)
     bench_conv(B, 8, 1280, 1280, 1280)
+    bench_conv(B, 16, 1280, 1280, 1280)
     bench_conv(B, 32, 640, 640, 640)
     bench_conv(B, 64, 320, 320, 320)
+    bench_conv(B, 64, 640, 320, 320)
     bench_conv(B, 64, 320, 0, 320, stride=2)
     bench_conv(B, 32, 640, 0, 640, ups=1)
+    bench_conv(B, 16, 1280, 0, 1280, ups=1)
     # transformer linears
     bench_gemm(B * 4096, 320, 320)
     bench_gemm(B * 4096, 960, 320)
     bench_gemm(B * 4096, 2560, 320, act=3)
     bench_gemm(B * 4096, 320, 1280)
+    bench_gemm(B * 1024, 640, 640)
     bench_gemm(B * 1024, 5120, 640, act=3)
     bench_gemm(B * 1024, 640, 2560)
+    bench_gemm(B * 256, 1280, 1280)
     bench_gemm(B * 256, 10240, 1280, act=3)
     bench_gemm(B * 256, 1280, 5120)
     bench_gemm(B * 64, 1280, 1280)
@@ -155,6 +179,18 @@ if __name__ == "__main__":
     bench_gemm(4900, 3840, 1280)
     bench_gemm(4096, 5120, 1280, act=2)
     bench_gemm(4096, 1280, 5120)
+    # VAE decoder
+    bench_conv(4, 256, 256, 0, 256)
+    bench_conv(4, 512, 128, 0, 128)
+
+
+if __name__ == "__main__":
+    B = 8
+    variants = [v for v in os.environ.get("EA_BENCH_VARIANTS", "auto").split(",") if v]
+    for v in variants:
+        set_variant(v)
+        gemm_suite()
+    set_variant("")
     # attention
     bench_attn(B, 5, 4096, 4096, 64)
     bench_attn(B, 10, 1024, 1024, 64)
