@@ -99,5 +99,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). editanything_amd has no CPU / eager fallback.")
+        # PyTorch-ROCm ships its own libamdhip64; load it FIRST so that our library's DT_NEEDED resolves to the same HIP
+        # runtime instance (two runtimes in one process = stream handles from one are invalid in the other: every
+        # launch fails).  torch owns the device memory and the streams, so it is always present on the product path.
+        import torch  # noqa: F401
         _lib = bind(LIB_PATH)
     return _lib

@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <stdio.h>
 
 #ifdef EA_EMU
 #include "hip_emu.h"
@@ -56,7 +57,10 @@ static inline int ea_launch_status() { return EA_OK; }
 #define EA_LAUNCH(kfn, grid, block, smem, stream, ...) \
   do { (void)hipGetLastError(); kfn<<<(grid), (block), (smem), (hipStream_t)(stream)>>>(__VA_ARGS__); } while (0)
 static inline int ea_launch_status() {
-  return hipGetLastError() == hipSuccess ? EA_OK : EA_ERR_LAUNCH;
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return EA_OK;
+  fprintf(stderr, "editanything_hip: kernel launch failed: %s (%s)\n", hipGetErrorName(e), hipGetErrorString(e));
+  return EA_ERR_LAUNCH;
 }
 #endif
 
