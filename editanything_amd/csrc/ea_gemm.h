@@ -67,6 +67,7 @@ struct EaGemmParams {
   long long strideA, strideW, strideC, strideR;
   int splits;
   int ktiles_per_split;
+  int debug;       // bench-only ablation (EA_GEMM2_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
   float* partial;  // [batch*splits][M][N] fp32 when splits > 1
   EaEpilogue epi;
 };

@@ -65,7 +65,8 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
 
 // ---- fast path (ea_gemm2.h): plan + eligibility
 struct Plan2 {
-  int bm, bn, stages;
+  int kind;       // kernel instantiation, see launch_fast
+  int bm, bn;
   int tiles;
   int splits;
   int ktiles_per_split;
@@ -90,7 +91,10 @@ static bool fast_eligible(const EaGemmParams& p) {
 
 // Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
 //   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
-//   EA_GEMM2_VARIANT=0|1|2|3   0 auto, 1: 128-row tiles 2-stage, 2: 128-row tiles 3-stage, 3: 256-row tiles 3-stage
+//   EA_GEMM2_VARIANT=k         0 auto; k = 1..6 forces instantiation k of launch_fast:
+//        1: 128 x bn, 4 waves 2x2 (wave tile 64x80), 2-stage, 16x16x32     2: same, 3-stage counted vmcnt
+//        3: 256 x bn, 8 waves 4x2 (64x80), 3-stage                        4: 256 x bn, 4 waves 2x2 (128x80), 3-stage
+//        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16              6: same, 2-stage
 static int g_force_generic = 0, g_variant = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
@@ -122,17 +126,15 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split) {
   const int nk = K / EA_BK;
   double best = 1e30;
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk;
-  const int bm_lo = (g_variant == 3) ? 256 : 128, bm_hi = (g_variant == 1 || g_variant == 2) ? 128 : 256;
-  for (int bm = bm_lo; bm <= bm_hi; bm *= 2) {
-    const int smax = allow_split ? 16 : 1;
-    for (int s = 1; s <= smax; ++s) {
-      if (s > 1 && nk / s < 4) break;
-      int kps, s_eff;
-      const double c = plan_cost(bm, t.bn, M, N, K, batch, s, &kps, &s_eff);
-      if (c < best - 1e-9) { best = c; t.bm = bm; t.splits = s_eff; t.ktiles_per_split = kps; }
-    }
+  const int bm = (g_variant <= 2) ? 128 : 256;
+  const int smax = allow_split ? 16 : 1;
+  for (int s = 1; s <= smax; ++s) {
+    if (s > 1 && nk / s < 4) break;
+    int kps, s_eff;
+    const double c = plan_cost(bm, t.bn, M, N, K, batch, s, &kps, &s_eff);
+    if (c < best - 1e-9) { best = c; t.bm = bm; t.splits = s_eff; t.ktiles_per_split = kps; }
   }
-  t.stages = (t.bm == 256 || g_variant == 2) ? 3 : 2;
+  t.kind = (g_variant == 0) ? 1 : g_variant;
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
@@ -151,28 +153,31 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
+  {
+    const char* dbg = getenv("EA_GEMM2_DEBUG");
+    p.debug = (dbg && *dbg) ? atoi(dbg) : 0;
+  }
   if (t.splits > 1) {
     const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
     if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
     p.partial = (float*)workspace;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
-#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_)                                         \
+#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_)                                    \
   do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_>;                              \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_>;                         \
     const int smem = ST_ * (BM_ + BN_) * 128;                                         \
     ea_allow_big_lds(kfn, smem);                                                      \
     EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64, 1, 1), smem, stream, p);                \
   } while (0)
-  if (t.bm == 256) {
-    if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3);
-    else EA_LAUNCH_G2(256, 128, 4, 2, 3);
-  } else if (t.stages == 3) {
-    if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3);
-    else EA_LAUNCH_G2(128, 128, 2, 2, 3);
-  } else {
-    if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2);
-    else EA_LAUNCH_G2(128, 128, 2, 2, 2);
+  switch (t.kind) {
+    case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16); break;
+    case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16); break;
+    case 3: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16); break;
+    case 4: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 2, 2, 3, 16); else EA_LAUNCH_G2(256, 128, 2, 2, 3, 16); break;
+    case 5: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32); break;
+    case 6: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 2, 32); else EA_LAUNCH_G2(256, 128, 4, 1, 2, 32); break;
+    default: return EA_ERR_UNSUPPORTED;
   }
 #undef EA_LAUNCH_G2
   int st = ea_launch_status();

@@ -96,11 +96,14 @@ __device__ __forceinline__ void ea_raw_barrier() {
 // 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
 __device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+// MT = 16: v_mfma_f32_16x16x32_f16 (wave tile WTM x WTN in 16x16 tiles); MT = 32: v_mfma_f32_32x32x16_f16.
+template <int BM, int BN, int WM, int WN, int STAGES, int MT>
 __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int MI = WTM / 16, NI = WTN / 16;
+  constexpr int MI = WTM / MT, NI = WTN / MT;
+  static_assert(MT == 16 || MT == 32, "MFMA tile");
+  static_assert(WTM % MT == 0 && WTN % MT == 0, "wave tile must be a whole number of MFMA tiles");
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   const int kt_begin = split * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nk_total) kt_end = nk_total;
-  const int nk = kt_end - kt_begin;
+  const int nk = (p.debug == 2) ? 0 : kt_end - kt_begin;
 
   const ea_rsrc rs_a1 = ea_make_rsrc(p.a1 + batch * p.strideA);
   const ea_rsrc rs_a2 = ea_make_rsrc(p.a2 ? p.a2 + batch * p.strideA : p.a1);
@@ -223,37 +226,54 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
     }
   };
 
-  f32x4 acc[MI][NI];
+  // accumulators: MT == 16 -> f32x4 per tile, MT == 32 -> f32x16 per tile (the unused array is dead code)
+  f32x4 acc[MT == 16 ? MI : 1][MT == 16 ? NI : 1];
+  f32x16 acc32[MT == 32 ? MI : 1][MT == 32 ? NI : 1];
+  if (MT == 16) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+        for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] = 0.0f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[MT == 32 ? i : 0][MT == 32 ? j : 0][r] = 0.0f;
+  }
 
-  // fragment read coordinates: row (lane & 15) of a 16-row MFMA tile, 16-B chunk (lane >> 4) of a 32-wide K step
-  const int frow = lane & 15, fq = lane >> 4;
+  // fragment read coordinates: row (lane % MT) of an MFMA tile; 16-B chunk (lane / MT) of a K step
+  // (16x16x32: 4 chunks = 32 K per step, 2 steps per tile; 32x32x16: 2 chunks = 16 K per step, 4 steps per tile)
+  const int frow = lane & (MT - 1), fq = lane / MT;
   auto compute_tile = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
+    constexpr int KSTEPS = (MT == 16) ? 2 : 4;
+    constexpr int CH_PER_STEP = (MT == 16) ? 4 : 2;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = ks * 4 + fq;
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int ch = ks * CH_PER_STEP + fq;
       f16x8 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int r = wm * WTM + i * 16 + frow;
+        const int r = wm * WTM + i * MT + frow;
         fa[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const int r = wn * WTN + j * 16 + frow;
+        const int r = wn * WTN + j * MT + frow;
         fb[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = ea_mfma_16x16x32(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) {
+          if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[i], fb[j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+          else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[i], fb[j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
+        }
     }
   };
 
@@ -295,6 +315,15 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   // One WTM-row slab (the waves with wm == pass) at a time through LDS: fp32 [WTM][BN + 4].
   float* stg = reinterpret_cast<float*>(smem);
   const EaEpilogue& e = p.epi;
+  if (p.debug == 1) {   // ablation: keep the accumulators live, write (almost) nothing
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) sum += (MT == 16) ? acc[MT == 16 ? i : 0][MT == 16 ? j : 0][0] : acc32[MT == 32 ? i : 0][MT == 32 ? j : 0][0];
+    if (sum == 123456.789f) ((f16*)e.out)[0] = (f16)sum;
+    return;
+  }
   const bool raw = p.splits > 1;
   const bool geglu = (!raw) && e.act == EA_ACT_GEGLU;
   const int tile_cols = geglu ? BN / 2 : BN;
@@ -309,8 +338,10 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            stg[(i * 16 + fq * 4 + r) * EPI_LD + wn * WTN + j * 16 + frow] = acc[i][j][r];
+          for (int r = 0; r < (MT == 16 ? 4 : 16); ++r) {
+            if (MT == 16) stg[(i * 16 + fq * 4 + r) * EPI_LD + wn * WTN + j * 16 + frow] = acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r & 3];
+            else stg[(i * 32 + ea_mfma_row(r, lane)) * EPI_LD + wn * WTN + j * 32 + frow] = acc32[MT == 32 ? i : 0][MT == 32 ? j : 0][r];
+          }
     }
     __syncthreads();
     for (int idx = tid; idx < WTM * vec_per_row; idx += NT) {
