@@ -55,7 +55,7 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
   e.M = M;
   e.N = (epi->act == EA_ACT_GEGLU) ? N / 2 : N;
   if (epi->act < 0 || epi->act > EA_ACT_GEGLU) return EA_ERR_BAD_ARG;
-  if (epi->act == EA_ACT_GEGLU && e.geglu_block != 64 && e.geglu_block != 160) return EA_ERR_UNSUPPORTED;
+  if (epi->act == EA_ACT_GEGLU && e.geglu_block != 64 && e.geglu_block != 80) return EA_ERR_UNSUPPORTED;
   if (epi->act == EA_ACT_GEGLU && (N % e.geglu_block) != 0) return EA_ERR_BAD_SHAPE;
   if (epi->act == EA_ACT_GEGLU && epi->bias_per_row) return EA_ERR_UNSUPPORTED;
   if (e.ldc < e.N) return EA_ERR_BAD_SHAPE;
@@ -85,7 +85,7 @@ static bool fast_eligible(const EaGemmParams& p) {
   } else {
     if ((long long)p.M * p.lda * 2 > lim) return false;
   }
-  if (p.epi.act == EA_ACT_GEGLU) return p.epi.geglu_block == 160 && (p.N % 160) == 0;
+  if (p.epi.act == EA_ACT_GEGLU) return p.epi.geglu_block == 80 && (p.N % 160) == 0;
   return true;
 }
 

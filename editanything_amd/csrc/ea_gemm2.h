@@ -25,8 +25,10 @@
 //    v_mfma_f32_16x16x32_f16, 4 waves as 2x2, wave tile 64x80 (4x5 MFMA tiles, 80
 //    accumulator VGPRs); 2-stage LDS ring (72 KiB) -> two workgroups per CU, whose
 //    barriers / DMA waits overlap each other's MFMA phases.
-//  * epilogue staged through LDS (fp32) one 64-row half at a time so every global
-//    access is a 16-byte coalesced one; GEGLU pairs column c with c + BN/2 there.
+//  * epilogue: each wave stages its own accumulator tile through a private fp32 LDS slab
+//    (no workgroup barriers), gathers every global read of a slab before the first use
+//    and writes 16-byte coalesced vectors; GEGLU weights are packed [40 value | 40 gate]
+//    per 80 rows so both halves of an output land in the same wave's slab.
 #pragma once
 #include "ea_gemm.h"
 
@@ -66,6 +68,7 @@ __device__ __forceinline__ void ea_dma16(ea_rsrc r, unsigned voff, unsigned soff
 __device__ __forceinline__ int ea_uniform(int v) { return v; }
 template <int N> __device__ __forceinline__ void ea_wait_dma() {}
 __device__ __forceinline__ void ea_raw_barrier() { ea_emu::block_sync(); }
+__device__ __forceinline__ void ea_wave_lds_sync() { ea_emu::wave_sync(); }
 #else
 // v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8*(l >> 4) + j], B[k = 8*(l >> 4) + j][n = l & 15],
 // C/D reg r < 4: col = l & 15, row = 4*(l >> 4) + r.
@@ -91,14 +94,26 @@ __device__ __forceinline__ void ea_raw_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// LDS hand-off between the lanes of ONE wave: the LDS pipeline is in order per wave, so retiring this wave's
+// outstanding DS operations is enough; no workgroup barrier.
+__device__ __forceinline__ void ea_wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 #endif
 
 // 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
 __device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
 
 // MT = 16: v_mfma_f32_16x16x32_f16 (wave tile WTM x WTN in 16x16 tiles); MT = 32: v_mfma_f32_32x32x16_f16.
+// Register budget: two co-resident 4-wave workgroups per CU (the 2-stage 128-row tiles, <= 80 KiB LDS each) need
+// <= 256 VGPR+AGPR per lane, i.e. 2 waves per SIMD; the 1-workgroup-per-CU instantiations may use the whole file.
+constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
+  return (nwaves == 4 && stages * (bm + bn) * 128 <= 80 * 1024) ? 2 : 1;
+}
+
 template <int BM, int BN, int WM, int WN, int STAGES, int MT>
-__global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))) void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
@@ -107,7 +122,6 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
-  constexpr int EPI_LD = BN + 4;
   static_assert(WTM % 16 == 0 && WTN % 16 == 0 && BM % 8 == 0 && BN % 8 == 0, "tile shape");
   EA_SMEM(smem);
 
@@ -312,8 +326,11 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
   }
 
   // ------------------------------------------------------------- epilogue
-  // One WTM-row slab (the waves with wm == pass) at a time through LDS: fp32 [WTM][BN + 4].
-  float* stg = reinterpret_cast<float*>(smem);
+  // Each wave turns its own WTM x WTN accumulator tile into coalesced 16-byte global accesses through a private fp32
+  // LDS slab (SLAB rows at a time), with no workgroup barriers after the first one.  Per slab every lane first issues
+  // ALL its global reads (residual / time-embedding row vector) and only then does the math and the stores, so the
+  // memory latency of the epilogue is paid once per slab, not once per output vector (a per-vector load -> use -> store
+  // chain measured 25 us per [32768 x 320] launch -- more than the whole K loop of the K = 320 linears).
   const EaEpilogue& e = p.epi;
   if (p.debug == 1) {   // ablation: keep the accumulators live, write (almost) nothing
     float sum = 0.0f;
@@ -324,60 +341,213 @@ __global__ __launch_bounds__(WM* WN * 64) void ea_gemm2_kernel(EaGemmParams p) {
     if (sum == 123456.789f) ((f16*)e.out)[0] = (f16)sum;
     return;
   }
+  constexpr int SLAB = (WTN > 80) ? 16 : 32;   // rows per slab: keeps the per-lane gather depth at <= 6 vectors
+  constexpr int SLD = WTN + 4;                 // fp32 words per slab row (pad: conflict-free accumulator scatter)
+  constexpr int NSLAB = WTM / SLAB;
+  constexpr int ITERS = 6, SUB = 3;             // vectors per lane per slab (upper bound), gathered SUB at a time
+  static_assert(NW * SLAB * SLD * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+  static_assert(WTM % SLAB == 0, "slab rows");
+  float* wstg = reinterpret_cast<float*>(smem) + wave * (SLAB * SLD);
   const bool raw = p.splits > 1;
   const bool geglu = (!raw) && e.act == EA_ACT_GEGLU;
-  const int tile_cols = geglu ? BN / 2 : BN;
-  const int ncol0 = geglu ? n0 / 2 : n0;
-  const int vec_per_row = tile_cols / 8;
-#pragma unroll 1
-  for (int pass = 0; pass < WM; ++pass) {
-    __syncthreads();  // K loop (pass 0) / previous slab fully consumed
-    if (wm == pass) {
+  const int out_w = geglu ? WTN / 2 : WTN;   // output columns this wave produces
+  const int vpr = out_w / 8;                 // 8-wide vectors per output row
+  const int rpp = 64 / vpr;                  // rows per pass of the wave
+  const int lc = lane % vpr, lr = lane / vpr;
+  const bool lane_on = lr < rpp;
+  // staging column(s) and global column of this lane's vector.  GEGLU: weight rows are packed [40 value | 40 gate]
+  // per 80 (geglu_block), so value and gate of one output live in the same wave's slab.
+  int scol = lc * 8, gcol = 0;
+  if (geglu) {
+    const int q = lc * 8, g = q / 40;
+    scol = g * 80 + (q - g * 40);
+    gcol = scol + 40;
+  }
+  const int nbase = geglu ? (n0 + wn * WTN) / 2 : n0 + wn * WTN;
+  const int n = nbase + lc * 8;
+  const int Nout = raw ? p.N : e.N;
+  const bool col_on = lane_on && n < Nout;
+  const long long cbase = (long long)batch * p.strideC, rbase = (long long)batch * p.strideR;
+  // fully vectorisable launch? (uniform)  otherwise every vector goes through the generic scalar-capable helper
+  const bool fast = raw ? ((p.N & 7) == 0)
+                        : ((e.N & 7) == 0 && (e.ldc & 7) == 0 && (cbase & 7) == 0 &&
+                           (!(e.residual || e.residual32) || ((e.ldr & 7) == 0 && (rbase & 7) == 0)) &&
+                           (!e.rowvec || ((e.rowvec_ld & 3) == 0 && (((uintptr_t)e.rowvec) & 15) == 0)));
+  float bias8[8], biasg8[8];
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+  for (int j = 0; j < 8; ++j) { bias8[j] = 0.0f; biasg8[j] = 0.0f; }
+  if (!raw && e.bias && !e.bias_per_row && col_on) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (geglu) {
+        bias8[j] = e.bias[n0 + wn * WTN + scol + j];
+        biasg8[j] = e.bias[n0 + wn * WTN + gcol + j];
+      } else if (n + j < Nout) {
+        bias8[j] = e.bias[n + j];
+      }
+    }
+  }
+
+  __syncthreads();  // every wave is done reading the K-loop stages: the ring becomes slab memory
+#pragma unroll 1
+  for (int slab = 0; slab < NSLAB; ++slab) {
+    // ---- scatter this slab's accumulators (MFMA C layout) into the wave's LDS slab
+    if (MT == 16) {
+      constexpr int TPS = SLAB / 16;  // 16-row MFMA tiles per slab
+#pragma unroll
+      for (int ii = 0; ii < (MT == 16 ? MI : 1); ++ii) {
+        if (ii / TPS != slab) continue;
+        const int il = ii % TPS;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
-          for (int r = 0; r < (MT == 16 ? 4 : 16); ++r) {
-            if (MT == 16) stg[(i * 16 + fq * 4 + r) * EPI_LD + wn * WTN + j * 16 + frow] = acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r & 3];
-            else stg[(i * 32 + ea_mfma_row(r, lane)) * EPI_LD + wn * WTN + j * 32 + frow] = acc32[MT == 32 ? i : 0][MT == 32 ? j : 0][r];
-          }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < WTM * vec_per_row; idx += NT) {
-      const int row = idx / vec_per_row;
-      const int cv = (idx - row * vec_per_row) * 8;
-      const int m = m0 + pass * WTM + row, n = ncol0 + cv;
-      float v[8];
-      if (geglu) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float val = stg[row * EPI_LD + cv + j], gate = stg[row * EPI_LD + BN / 2 + cv + j];
-          if (e.bias) {
-            val += e.bias[n0 + cv + j];
-            gate += e.bias[n0 + BN / 2 + cv + j];
-          }
-          v[j] = val * ea_gelu_erf(gate);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = stg[row * EPI_LD + cv + j];
+          for (int r = 0; r < 4; ++r)
+            wstg[(il * 16 + fq * 4 + r) * SLD + j * 16 + frow] = acc[MT == 16 ? ii : 0][MT == 16 ? j : 0][r];
       }
-      if (raw) {
-        if (m < p.M && n < p.N) {
+    } else {
+      constexpr int SPT = 32 / SLAB;  // slabs per 32-row MFMA tile (1 or 2)
+#pragma unroll
+      for (int ii = 0; ii < (MT == 32 ? MI : 1); ++ii) {
+        if (ii != slab / SPT) continue;
+        const int part = slab % SPT;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (SPT == 2 && (r >> 3) != part) continue;
+            const int row = (r & 3) + 8 * ((r >> 2) & (SPT == 2 ? 1 : 3)) + 4 * fq;
+            wstg[row * SLD + j * 32 + frow] = acc32[MT == 32 ? ii : 0][MT == 32 ? j : 0][r];
+          }
+      }
+    }
+    ea_wave_lds_sync();
+    const int mrow0 = m0 + wm * WTM + slab * SLAB;
+    if (!fast) {
+      // launches that cannot use 16-byte vectors (ragged N, odd strides): one vector at a time through the
+      // scalar-capable helper; not unrolled, so it does not inflate the hot path's register allocation.
+#pragma unroll 1
+      for (int row = lr; row < SLAB; row += rpp) {
+        const int m = mrow0 + row;
+        if (!(col_on && m < p.M)) continue;
+        const float* sp = wstg + row * SLD;
+        float v1[8];
+        if (geglu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v1[j] = (sp[scol + j] + bias8[j]) * ea_gelu_erf(sp[gcol + j] + biasg8[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v1[j] = sp[scol + j];
+        }
+        if (raw) {
           float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
           const int nvalid = (p.N - n) < 8 ? (p.N - n) : 8;
-          if (nvalid == 8 && (p.N & 3) == 0) {
-            f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-            *reinterpret_cast<f32x4*>(dst) = lo;
-            *reinterpret_cast<f32x4*>(dst + 4) = hi;
-          } else {
-            for (int j = 0; j < nvalid; ++j) dst[j] = v[j];
+          for (int j = 0; j < nvalid; ++j) dst[j] = v1[j];
+        } else {
+          ea_epilogue_store8(e, cbase, rbase, m, n, v1, !geglu);
+        }
+      }
+      ea_wave_lds_sync();
+      continue;
+    }
+#pragma unroll 1
+    for (int k0 = 0; k0 < ITERS; k0 += SUB) {
+      // ---- phase A: gather (slab reads + every global read this lane needs for SUB vectors), no dependent use yet
+      float v[SUB][8];
+      f16x8 r16[SUB];
+      f32x4 aux[SUB][2];   // fp32 residual, else the row vector (both at once: the row vector is read in phase B)
+      bool ok[SUB];
+#pragma unroll
+      for (int kk = 0; kk < SUB; ++kk) {
+        const int row = lr + (k0 + kk) * rpp;
+        const int m = mrow0 + row;
+        ok[kk] = col_on && row < SLAB && m < p.M;
+        if (!ok[kk]) continue;
+        const float* sp = wstg + row * SLD;
+        if (geglu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[kk][j] = (sp[scol + j] + bias8[j]) * ea_gelu_erf(sp[gcol + j] + biasg8[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[kk][j] = sp[scol + j];
+        }
+        if (!raw) {
+          const long long roff = rbase + (long long)m * e.ldr + n;
+          if (e.residual) r16[kk] = ea_ld8(e.residual + roff);
+          if (e.residual32) {
+            aux[kk][0] = *reinterpret_cast<const f32x4*>(e.residual32 + roff);
+            aux[kk][1] = *reinterpret_cast<const f32x4*>(e.residual32 + roff + 4);
+          } else if (e.rowvec) {
+            const float* rp = e.rowvec + (long long)(m / e.rows_per_group) * e.rowvec_ld + n;
+            aux[kk][0] = *reinterpret_cast<const f32x4*>(rp);
+            aux[kk][1] = *reinterpret_cast<const f32x4*>(rp + 4);
           }
         }
-      } else {
-        ea_epilogue_store8(e, batch * p.strideC, batch * p.strideR, m, n, v, !geglu);
+      }
+      // ---- phase B: math + stores
+#pragma unroll
+      for (int kk = 0; kk < SUB; ++kk) {
+        if (!ok[kk]) continue;
+        const int m = mrow0 + lr + (k0 + kk) * rpp;
+        if (raw) {
+          float* dst = p.partial + ((long long)bz * p.M + m) * p.N + n;
+          f32x4 lo = {v[kk][0], v[kk][1], v[kk][2], v[kk][3]}, hi = {v[kk][4], v[kk][5], v[kk][6], v[kk][7]};
+          *reinterpret_cast<f32x4*>(dst) = lo;
+          *reinterpret_cast<f32x4*>(dst + 4) = hi;
+          continue;
+        }
+        if (!geglu) {
+          if (e.bias_per_row) {
+            const float b = e.bias ? e.bias[m] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[kk][j] += b;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[kk][j] += bias8[j];
+          }
+          if (e.rowvec) {
+            if (e.residual32) {   // rare: both fp32 residual and row vector -> the row vector was not prefetched
+              const float* rp = e.rowvec + (long long)(m / e.rows_per_group) * e.rowvec_ld + n;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[kk][j] += rp[j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { v[kk][j] += aux[kk][0][j]; v[kk][4 + j] += aux[kk][1][j]; }
+            }
+          }
+          if (e.act == EA_ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[kk][j] = ea_silu(v[kk][j]);
+          } else if (e.act == EA_ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[kk][j] = ea_gelu_erf(v[kk][j]);
+          }
+        }
+        float sc = e.scale;
+        if (e.row_scale) sc *= e.row_scale[m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[kk][j] *= sc;
+        if (e.residual) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[kk][j] += (float)r16[kk][j];
+        }
+        if (e.residual32) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[kk][j] += aux[kk][0][j]; v[kk][4 + j] += aux[kk][1][j]; }
+        }
+        const long long coff = cbase + (long long)m * e.ldc + n;
+        if (e.out_f32) {
+          float* o = (float*)e.out + coff;
+          f32x4 lo = {v[kk][0], v[kk][1], v[kk][2], v[kk][3]}, hi = {v[kk][4], v[kk][5], v[kk][6], v[kk][7]};
+          *reinterpret_cast<f32x4*>(o) = lo;
+          *reinterpret_cast<f32x4*>(o + 4) = hi;
+        } else {
+          f16x8 h;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) h[j] = (f16)v[kk][j];
+          ea_st8((f16*)e.out + coff, h);
+        }
       }
     }
+    ea_wave_lds_sync();  // slab reads retired before the next slab's scatter overwrites it
   }
 }

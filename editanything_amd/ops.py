@@ -98,7 +98,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
     ws = workspace(a.device)
     e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
     if act == ACT_GEGLU:
-        e.geglu_block = 160 if (N % 160 == 0 and K % 64 == 0) else 64      # must match unet.pack_geglu
+        e.geglu_block = 80 if (N % 160 == 0 and K % 64 == 0) else 64       # must match unet.pack_geglu
     ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
     _prof_end(ev, 2.0 * M * N * K)
@@ -209,7 +209,7 @@ def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None,
     ws = workspace(x.device)
     e = _epilogue(out, n_out, bias, act, 1.0, residual)
     if act == ACT_GEGLU:
-        e.geglu_block = 160 if (N % 160 == 0 and K % 64 == 0) else 64
+        e.geglu_block = 80 if (N % 160 == 0 and K % 64 == 0) else 64
     st = _lib().ea_ln_gemm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), eps, _p(ln_out), _p(w),
                                w.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream())
     L.check(st, "ea_ln_gemm_f16")

@@ -45,9 +45,9 @@ def pack_conv(w, device):
 
 
 def geglu_block(n_gemm, k):
-    """Packing granule of the EA_ACT_GEGLU weight rows: 160 when the fast 160-wide-tile kernel applies
-    (every SD2.1/SD1.5 width), else the generic kernel's 64."""
-    return 160 if (n_gemm % 160 == 0 and k % 64 == 0) else 64
+    """Packing granule of the EA_ACT_GEGLU weight rows: 80 (one wave's columns of the 160-wide-tile LDS-DMA kernel)
+    when that kernel applies (every SD2.1/SD1.5 width), else the generic kernel's 64."""
+    return 80 if (n_gemm % 160 == 0 and k % 64 == 0) else 64
 
 
 def pack_geglu(w, b):

@@ -64,7 +64,7 @@ typedef struct ea_epilogue {
   void* out;              /* fp16 (out_f32=0) or fp32 [M][ldc] */
   int32_t ldc;
   int32_t out_f32;
-  int32_t geglu_block;    /* EA_ACT_GEGLU packing granule G: 64 (0 means 64) or 160 (N % 160 == 0, K % 64 == 0) */
+  int32_t geglu_block;    /* EA_ACT_GEGLU packing granule G: 64 (0 means 64) or 80 (needs N % 160 == 0, K % 64 == 0) */
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and

@@ -81,7 +81,7 @@ def test_gemm(kb, M, N, K, batch, act, res, f32out):
 
 @pytest.mark.parametrize("M,N,K,batch,act,res,f32out,gb", [
     (200, 160, 128, 1, 0, True, False, 0),     # 128x160 tile, ragged M
-    (128, 320, 64, 1, 3, True, False, 160),    # GEGLU, 160-row packing (value | gate per workgroup tile)
+    (128, 320, 64, 1, 3, True, False, 80),     # GEGLU, 80-row packing (value | gate inside one wave's columns)
     (130, 192, 192, 1, 2, False, True, 0),     # 128x128 tile, ragged M and N, fp32 out
     (128, 160, 2048, 1, 0, True, False, 0),    # split-K through the LDS-DMA kernel + reduce
     (96, 160, 64, 2, 1, False, False, 0),      # batched
@@ -112,7 +112,7 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
 
 
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
-@pytest.mark.parametrize("M,N,K,act,gb", [(300, 160, 512, 0, 0), (256, 320, 192, 3, 160), (260, 128, 64, 1, 0),
+@pytest.mark.parametrize("M,N,K,act,gb", [(300, 160, 512, 0, 0), (256, 320, 192, 3, 80), (260, 128, 64, 1, 0),
                                           (128, 160, 2048, 0, 0)])
 def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
     """Every instantiation of launch_fast (EA_GEMM2_VARIANT 2..6: 3-stage counted-vmcnt rings, 256-row tiles,
@@ -153,11 +153,41 @@ def test_conv_fast_path_variants(kb, variant, monkeypatch):
     assert relerr(kb.down(out), ref.permute(0, 2, 3, 1).numpy()) < 3e-3
 
 
-def test_gemm_geglu_160_needs_fast_path(kb):
-    """geglu_block = 160 exists only in the LDS-DMA kernel: a K that is not a multiple of 64 is refused, not mis-paired."""
+@pytest.mark.parametrize("variant", [1, 4, 5])
+def test_gemm_fast_epilogue_options(kb, variant, monkeypatch):
+    """Every epilogue operand of the LDS-DMA kernel's vector path: time-embedding row vector, per-row scale map,
+    scalar scale, fp32 residual, fp32 out; then bias-per-row; then a ragged N (N % 8 != 0 -> scalar-capable path)."""
+    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    M, N, K, hw = 96, 160, 64, 32
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    rowvec, rs, bias, R32 = f32(M // hw, N), f32(M), f32(N), f32(M, N)
+    out = kb.zeros((M, N), np.float32)
+    e = epilogue(out, bias=bias, rowvec=rowvec, rows_per_group=hw, row_scale=rs, scale=0.5, residual32=R32, act=1)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ref = F.silu(t(A) @ t(W).T + t(bias) + t(rowvec).repeat_interleave(hw, 0)) * 0.5 * t(rs)[:, None] + t(R32)
+    assert relerr(kb.down(out), ref.numpy()) < 2e-3
+    # bias per row (VAE V^T projection), fp16 out
+    biasm = f32(M)
+    out2 = kb.zeros((M, N), np.float16)
+    e2 = epilogue(out2, bias=biasm, bias_per_row=1)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e2), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    assert relerr(kb.down(out2), (t(A) @ t(W).T + t(biasm)[:, None]).numpy()) < 2e-3
+    # ragged N: vectors straddle the edge, row stride not a multiple of 8
+    N3 = 100
+    W3, b3, R3 = f16(N3, K, scale=0.2), f32(N3), f16(70, N3)
+    A3 = f16(70, K)
+    out3 = kb.zeros((70, N3), np.float16)
+    e3 = epilogue(out3, bias=b3, residual=R3, act=2)
+    assert kb.lib.ea_gemm_f16(ptr(A3), K, ptr(W3), K, 70, N3, K, 1, 0, 0, 0, 0, C.byref(e3), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    assert relerr(kb.down(out3), (F.gelu(t(A3) @ t(W3).T + t(b3)) + t(R3)).numpy()) < 2e-3
+
+
+def test_gemm_geglu_80_needs_fast_path(kb):
+    """geglu_block = 80 exists only in the LDS-DMA kernel: a K that is not a multiple of 64 is refused, not mis-paired."""
     M, N, K = 64, 160, 72
     out = kb.zeros((M, N // 2), np.float16)
-    e = epilogue(out, act=3, geglu_block=160)
+    e = epilogue(out, act=3, geglu_block=80)
     A, W = f16(M, K), f16(N, K)
     ws = workspace(kb, 0)
     assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == -3
