@@ -15,18 +15,29 @@ from editanything_amd import _lib as L  # noqa: E402
 PEAK_TF, PEAK_GBS = 2500.0, 8000.0
 lib = L.lib()
 dev = torch.device("cuda:0")
-stream = torch.cuda.current_stream().cuda_stream
 WS = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
 
+def S():
+    """Launch stream = torch's current stream at CALL time (the capture stream inside torch.cuda.graph)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
 def timeit(fn, iters=20, warm=3):
+    """GPU time per launch: the launches are captured into one HIP graph and the replay is timed with events, so the
+    ~10 us host cost of a ctypes call + hipLaunchKernel does not floor the short kernels (the product replays graphs too)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
@@ -75,7 +86,7 @@ def bench_gemm(M, N, K, act=0):
     gb = 80 if (act == 3 and N % 160 == 0 and K % 64 == 0 and os.environ.get("EA_GEMM_FORCE") != "generic") else 0
     e = epi(out, No, bias, act, geglu_block=gb)
     fn = lambda: lib.ea_gemm_f16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), WS.data_ptr(),
-                                 WS.numel(), stream)
+                                 WS.numel(), S())
     assert fn() == 0
     report(f"gemm M{M} N{N} K{K} act{act}", timeit(fn), flops=2.0 * M * N * K)
 
@@ -96,25 +107,25 @@ def bench_conv(B, H, c1, c2, cout, stride=1, ups=0):
     s.ksize, s.stride, s.pad, s.ups = 3, stride, 1, ups
     s.Hout = s.Wout = ho
     e = epi(out, cout, bias)
-    fn = lambda: lib.ea_conv2d_f16(C.byref(s), W.data_ptr(), cout, C.byref(e), WS.data_ptr(), WS.numel(), stream)
+    fn = lambda: lib.ea_conv2d_f16(C.byref(s), W.data_ptr(), cout, C.byref(e), WS.data_ptr(), WS.numel(), S())
     assert fn() == 0
     report(f"conv3x3 B{B} H{H} c{c1}+{c2}->{cout} s{stride} ups{ups}", timeit(fn), flops=2.0 * B * ho * ho * cout * K)
 
 
-def bench_attn(B, H, N, Nk, D, S=0):
+def bench_attn(B, H, N, Nk, D, S_=0):
     q = torch.randn(B, N, H, D, device=dev).half()
     k = torch.randn(B, Nk, H, D, device=dev).half()
     v = torch.randn(B, Nk, H, D, device=dev).half()
     out = torch.empty(B, N, H, D, device=dev, dtype=torch.half)
     bh = bw = None
-    if S:
-        bh = torch.randn(B * H, N, S, device=dev)
-        bw = torch.randn(B * H, N, S, device=dev)
+    if S_:
+        bh = torch.randn(B * H, N, S_, device=dev)
+        bw = torch.randn(B * H, N, S_, device=dev)
     fn = lambda: lib.ea_attention_f16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, N, Nk, D,
                                       N * H * D, H * D, Nk * H * D, H * D, Nk * H * D, H * D, N * H * D, H * D,
-                                      D ** -0.5, bh.data_ptr() if S else None, bw.data_ptr() if S else None, S, stream)
+                                      D ** -0.5, bh.data_ptr() if S_ else None, bw.data_ptr() if S_ else None, S_, S())
     assert fn() == 0
-    report(f"attn B{B} H{H} N{N} Nk{Nk} D{D} S{S}", timeit(fn), flops=4.0 * B * H * N * Nk * D)
+    report(f"attn B{B} H{H} N{N} Nk{Nk} D{D} S{S_}", timeit(fn), flops=4.0 * B * H * N * Nk * D)
 
 
 def bench_gn(B, HW, Cc):
@@ -122,7 +133,7 @@ def bench_gn(B, HW, Cc):
     g, b = torch.randn(Cc, device=dev), torch.randn(Cc, device=dev)
     out = torch.empty_like(x)
     fn = lambda: lib.ea_groupnorm_f16(x.data_ptr(), Cc, None, 0, None, g.data_ptr(), b.data_ptr(), out.data_ptr(), B,
-                                      HW, 32, 1e-5, 1, WS.data_ptr(), WS.numel(), stream)
+                                      HW, 32, 1e-5, 1, WS.data_ptr(), WS.numel(), S())
     assert fn() == 0
     report(f"groupnorm+silu B{B} HW{HW} C{Cc}", timeit(fn), bytes_=3.0 * x.numel() * 2)
 
@@ -131,7 +142,7 @@ def bench_ln(M, Cc):
     x = torch.randn(M, Cc, device=dev).half()
     g, b = torch.randn(Cc, device=dev), torch.randn(Cc, device=dev)
     out = torch.empty_like(x)
-    fn = lambda: lib.ea_layernorm_f16(x.data_ptr(), 0, g.data_ptr(), b.data_ptr(), out.data_ptr(), M, Cc, 1e-5, stream)
+    fn = lambda: lib.ea_layernorm_f16(x.data_ptr(), 0, g.data_ptr(), b.data_ptr(), out.data_ptr(), M, Cc, 1e-5, S())
     assert fn() == 0
     report(f"layernorm M{M} C{Cc}", timeit(fn), bytes_=2.0 * x.numel() * 2)
 
@@ -196,8 +207,8 @@ if __name__ == "__main__":
     bench_attn(B, 10, 1024, 1024, 64)
     bench_attn(B, 20, 256, 256, 64)
     bench_attn(B, 5, 4096, 77, 64)
-    bench_attn(25, 16, 196, 196, 80, S=14)
-    bench_attn(1, 16, 4096, 4096, 80, S=64)
+    bench_attn(25, 16, 196, 196, 80, S_=14)
+    bench_attn(1, 16, 4096, 4096, 80, S_=64)
     bench_attn(1, 16, 4096, 4096, 80)
     # HBM-bound
     bench_gn(B, 4096, 320)
