@@ -161,6 +161,9 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
     if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
     p.partial = (float*)workspace;
+  } else if (p.debug == 3) {   // phase-timestamp dump (tools/phase_times.py): 8 x u64 per workgroup
+    if (!workspace || ws_bytes < (size_t)t.tiles * p.batch * 64) return EA_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_)                                    \

@@ -102,6 +102,18 @@ __device__ __forceinline__ void ea_wave_lds_sync() {
 }
 #endif
 
+// Phase timestamps for tools/phase_times.py (EA_GEMM2_DEBUG=3): wave 0 / lane 0 of every workgroup stores the
+// constant-rate wall clock (100 MHz) at a few program points into the (otherwise unused) split-K workspace.
+#ifdef EA_EMU
+#define EA_STAMP(i) do {} while (0)
+#else
+#define EA_STAMP(i)                                                                                   \
+  do {                                                                                                \
+    if (p.debug == 3 && tid == 0)                                                                     \
+      reinterpret_cast<unsigned long long*>(p.partial)[(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = wall_clock64(); \
+  } while (0)
+#endif
+
 // 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
 __device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
 
@@ -130,6 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
   const int wave = ea_uniform(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
+  EA_STAMP(0);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
   const int tile = ea_xcd_remap(blockIdx.x, ntile);
@@ -262,35 +275,43 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
   // fragment read coordinates: row (lane % MT) of an MFMA tile; 16-B chunk (lane / MT) of a K step
   // (16x16x32: 4 chunks = 32 K per step, 2 steps per tile; 32x32x16: 2 chunks = 16 K per step, 4 steps per tile)
   const int frow = lane & (MT - 1), fq = lane / MT;
+  // One K tile: KSTEPS MFMA steps.  Fragments are register double-buffered -- step s+1's ds_reads are issued before
+  // step s's MFMAs, so the LDS latency of a step hides under the previous step's matrix work (the waits become
+  // counted lgkmcnt(N), not drains).  Only the first step of a tile is exposed; the co-resident workgroup covers it.
   auto compute_tile = [&](int buf) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
     constexpr int KSTEPS = (MT == 16) ? 2 : 4;
     constexpr int CH_PER_STEP = (MT == 16) ? 4 : 2;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
+    f16x8 fa[2][MI], fb[2][NI];
+    auto load_frags = [&](int ks, int slot) {
       const int ch = ks * CH_PER_STEP + fq;
-      f16x8 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int r = wm * WTM + i * MT + frow;
-        fa[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        fa[slot][i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int r = wn * WTN + j * MT + frow;
-        fb[j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        fb[slot][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      if (ks + 1 < KSTEPS) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[i], fb[j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
-          else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[i], fb[j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
+          if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[ks & 1][i], fb[ks & 1][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+          else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[ks & 1][i], fb[ks & 1][j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
         }
     }
   };
 
+  EA_STAMP(1);
   if (STAGES == 2) {
     if (nk > 0) issue_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
@@ -388,7 +409,9 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
     }
   }
 
+  EA_STAMP(2);
   __syncthreads();  // every wave is done reading the K-loop stages: the ring becomes slab memory
+  EA_STAMP(3);
 #pragma unroll 1
   for (int slab = 0; slab < NSLAB; ++slab) {
     // ---- scatter this slab's accumulators (MFMA C layout) into the wave's LDS slab
@@ -550,4 +573,5 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
     }
     ea_wave_lds_sync();  // slab reads retired before the next slab's scatter overwrites it
   }
+  EA_STAMP(4);
 }

@@ -1,0 +1,48 @@
+"""Per-phase wall time of ea_gemm2 workgroups (EA_GEMM2_DEBUG=3 timestamp dump; 100 MHz clock).
+stamps: 0 kernel entry, 1 setup done (K loop starts), 2 K loop done, 3 past the pre-epilogue barrier, 4 end."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import bench_ops as bo  # noqa: E402
+
+
+def run(name, launch, nblocks):
+    os.environ["EA_GEMM2_DEBUG"] = "3"
+    bo.WS.zero_()
+    for _ in range(3):
+        assert launch() == 0
+    torch.cuda.synchronize()
+    st = bo.WS[:nblocks * 64].view(torch.int64).view(nblocks, 8).cpu().double()
+    os.environ.pop("EA_GEMM2_DEBUG")
+    t0 = st[:, 0].min()
+    rel = (st[:, :5] - t0) / 100.0          # us since the first workgroup started
+    d = (st[:, 1:5] - st[:, 0:4]) / 100.0
+    print(f"{name}: blocks {nblocks}  start spread {rel[:,0].max():.1f}us  kernel span {rel[:,4].max():.1f}us")
+    for i, lab in enumerate(["setup", "K loop", "barrier", "epilogue"]):
+        print(f"   {lab:9s} mean {d[:,i].mean():7.2f}  min {d[:,i].min():7.2f}  max {d[:,i].max():7.2f} us")
+
+
+def gemm(M, N, K, act=0):
+    A = torch.randn(M, K, device=bo.dev).half()
+    W = (torch.randn(N, K, device=bo.dev) * 0.05).half()
+    bias = torch.randn(N, device=bo.dev)
+    No = N // 2 if act == 3 else N
+    out = torch.empty(M, No, device=bo.dev, dtype=torch.half)
+    e = bo.epi(out, No, bias, act, geglu_block=80 if act == 3 else 0)
+    keep = (A, W, bias, out, e)
+    fn = lambda: bo.lib.ea_gemm_f16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), bo.WS.data_ptr(),
+                                    bo.WS.numel(), bo.S())
+    run(f"gemm M{M} N{N} K{K} act{act}", fn, ((M + 127) // 128) * (N // 160))
+    return keep
+
+
+if __name__ == "__main__":
+    bo.set_variant("1")
+    gemm(32768, 320, 320)
+    gemm(32768, 320, 1280)
+    gemm(32768, 2560, 320, act=3)
+    gemm(8192, 640, 640)
