@@ -91,10 +91,11 @@ static bool fast_eligible(const EaGemmParams& p) {
 
 // Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
 //   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
-//   EA_GEMM2_VARIANT=k         0 auto; k = 1..6 forces instantiation k of launch_fast:
+//   EA_GEMM2_VARIANT=k         0 auto; k = 1..8 forces instantiation k of launch_fast:
 //        1: 128 x bn, 4 waves 2x2 (wave tile 64x80), 2-stage, 16x16x32     2: same, 3-stage counted vmcnt
 //        3: 256 x bn, 8 waves 4x2 (64x80), 3-stage                        4: 256 x bn, 4 waves 2x2 (128x80), 3-stage
-//        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16              6: same, 2-stage
+//        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
+//        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
 static int g_force_generic = 0, g_variant = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
@@ -126,7 +127,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split) {
   const int nk = K / EA_BK;
   double best = 1e30;
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk;
-  const int bm = (g_variant <= 2) ? 128 : 256;
+  const int bm = (g_variant <= 2 || g_variant == 7) ? 128 : 256;   // tile height of the forced instantiation
   const int smax = allow_split ? 16 : 1;
   for (int s = 1; s <= smax; ++s) {
     if (s > 1 && nk / s < 4) break;
@@ -166,20 +167,22 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     p.partial = (float*)workspace;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
-#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_)                                    \
+#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_)                                   \
   do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_>;                         \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_, IL_>;                    \
     const int smem = ST_ * (BM_ + BN_) * 128;                                         \
     ea_allow_big_lds(kfn, smem);                                                      \
     EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64, 1, 1), smem, stream, p);                \
   } while (0)
   switch (t.kind) {
-    case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16); break;
-    case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16); break;
-    case 3: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16); break;
-    case 4: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 2, 2, 3, 16); else EA_LAUNCH_G2(256, 128, 2, 2, 3, 16); break;
-    case 5: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32); break;
-    case 6: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 2, 32); else EA_LAUNCH_G2(256, 128, 4, 1, 2, 32); break;
+    case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
+    case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 0); break;
+    case 3: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 0); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 0); break;
+    case 4: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(256, 128, 2, 2, 3, 16, 0); break;
+    case 5: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32, 0); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32, 0); break;
+    case 6: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 1); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 1); break;
+    case 7: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 1); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 1); break;
+    case 8: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32, 1); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32, 1); break;
     default: return EA_ERR_UNSUPPORTED;
   }
 #undef EA_LAUNCH_G2

@@ -124,12 +124,13 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
   return (nwaves == 4 && stages * (bm + bn) * 128 <= 80 * 1024) ? 2 : 1;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MT>
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV>
 __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))) void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
   static_assert(MT == 16 || MT == 32, "MFMA tile");
+  static_assert(!ILV || STAGES == 3, "interleaved issue needs the 3-deep ring (a full iteration of latency budget)");
   static_assert(WTM % MT == 0 && WTN % MT == 0, "wave tile must be a whole number of MFMA tiles");
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
@@ -224,22 +225,34 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
     set_voff();
   }
 
-  auto issue_tile = [&](int buf) {
-    char* sa = smem + buf * STAGE_BYTES;
-    char* sb = sa + BM * 128;
+  // Staging of one K tile = PIECES 1-KiB DMA instructions per wave (A rows first, then W rows).  `begin_issue` fixes
+  // the tile's scalar state, `issue_piece` launches one instruction, `end_issue` advances K (and, for convolutions,
+  // the tap / concat-source state).
+  constexpr int PIECES = A_PW + B_PW;
+  ea_rsrc is_rs_a = rs_a1;
+  unsigned is_soff_a = 0, is_soff_b = 0;
+  char* is_sa = smem;
+  char* is_sb = smem;
+  auto begin_issue = [&](int buf) {
+    is_sa = smem + buf * STAGE_BYTES;
+    is_sb = is_sa + BM * 128;
     k_cur = ea_uniform(k_cur);   // loop-carried scalars: keep them provably wave-uniform (SGPR descriptors / offsets)
     cin = ea_uniform(cin);
     tap = ea_uniform(tap);
     const bool second = p.conv && cin >= p.c1;
-    const ea_rsrc rs_a = second ? rs_a2 : rs_a1;
-    const unsigned soff_a = (unsigned)(p.conv ? (second ? cin - p.c1 : cin) : k_cur) * 2u;
-    const unsigned soff_b = (unsigned)k_cur * 2u;
-#pragma unroll
-    for (int j = 0; j < A_PW; ++j)
-      if (A_INSTR % NW == 0 || j * NW + wave < A_INSTR) ea_dma16(rs_a, a_voff[j], soff_a, sa + (j * NW + wave) * 1024);
-#pragma unroll
-    for (int j = 0; j < B_PW; ++j)
-      if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff_b, sb + (j * NW + wave) * 1024);
+    is_rs_a = second ? rs_a2 : rs_a1;
+    is_soff_a = (unsigned)(p.conv ? (second ? cin - p.c1 : cin) : k_cur) * 2u;
+    is_soff_b = (unsigned)k_cur * 2u;
+  };
+  auto issue_piece = [&](int pc) {
+    if (pc < A_PW) {
+      if (A_INSTR % NW == 0 || pc * NW + wave < A_INSTR) ea_dma16(is_rs_a, a_voff[pc], is_soff_a, is_sa + (pc * NW + wave) * 1024);
+    } else {
+      const int j = pc - A_PW;
+      if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], is_soff_b, is_sb + (j * NW + wave) * 1024);
+    }
+  };
+  auto end_issue = [&]() {
     k_cur += EA_BK;
     if (p.conv) {
       cin += EA_BK;
@@ -251,6 +264,12 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
         set_voff();
       }
     }
+  };
+  auto issue_tile = [&](int buf) {
+    begin_issue(buf);
+#pragma unroll
+    for (int pc = 0; pc < PIECES; ++pc) issue_piece(pc);
+    end_issue();
   };
 
   // accumulators: MT == 16 -> f32x4 per tile, MT == 32 -> f32x16 per tile (the unused array is dead code)
@@ -278,7 +297,11 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
   // One K tile: KSTEPS MFMA steps.  Fragments are register double-buffered -- step s+1's ds_reads are issued before
   // step s's MFMAs, so the LDS latency of a step hides under the previous step's matrix work (the waits become
   // counted lgkmcnt(N), not drains).  Only the first step of a tile is exposed; the co-resident workgroup covers it.
-  auto compute_tile = [&](int buf) {
+  // `ilv_issue` (ILV instantiations): the next tile's DMA pieces are issued BETWEEN the MFMA groups of this tile, one
+  // every few MFMAs, instead of as one burst in front of them.  A wave's DMA burst occupies the CU's single
+  // address/texture path (64 B/clk: 576 clk for a 36-KiB tile) while the wave sits in VMEM issue, i.e. burst + MFMA
+  // phases add up (measured: tile time = 576 + 640 clk); interleaved, the path drains while the matrix pipe works.
+  auto compute_tile = [&](int buf, bool ilv_issue = false) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
     constexpr int KSTEPS = (MT == 16) ? 2 : 4;
@@ -302,12 +325,23 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if (ks + 1 < KSTEPS) load_frags(ks + 1, (ks + 1) & 1);
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[ks & 1][i], fb[ks & 1][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
           else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[ks & 1][i], fb[ks & 1][j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
         }
+        if (ILV) {
+          // MFMA group g of G: issue the pieces [g*PIECES/G, (g+1)*PIECES/G) of the next tile
+          constexpr int G = KSTEPS * MI;
+          const int g = ks * MI + i;
+          if (ilv_issue) {
+#pragma unroll
+            for (int pc = 0; pc < PIECES; ++pc)
+              if (pc >= (g * PIECES) / G && pc < ((g + 1) * PIECES) / G) issue_piece(pc);
+          }
+        }
+      }
     }
   };
 
@@ -340,8 +374,15 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
         ea_wait_dma<0>();
       }
       ea_raw_barrier();
-      if (kt + 2 < nk) issue_tile(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
-      compute_tile(cur);
+      if (ILV) {
+        const bool more = kt + 2 < nk;
+        if (more) begin_issue(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
+        compute_tile(cur, more);
+        if (more) end_issue();
+      } else {
+        if (kt + 2 < nk) issue_tile(cur >= 1 ? cur - 1 : 2);
+        compute_tile(cur);
+      }
       cur = (cur == 2) ? 0 : cur + 1;
     }
   }

@@ -111,11 +111,11 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K,act,gb", [(300, 160, 512, 0, 0), (256, 320, 192, 3, 80), (260, 128, 64, 1, 0),
                                           (128, 160, 2048, 0, 0)])
 def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
-    """Every instantiation of launch_fast (EA_GEMM2_VARIANT 2..6: 3-stage counted-vmcnt rings, 256-row tiles,
+    """Every instantiation of launch_fast (EA_GEMM2_VARIANT 2..8: 3-stage counted-vmcnt rings, 256-row tiles,
     128x80 and 64x160 wave tiles, 32x32x16 MFMA) against the same reference."""
     monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
     A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
@@ -137,7 +137,7 @@ def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8])
 def test_conv_fast_path_variants(kb, variant, monkeypatch):
     monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
     B, H, W_, c1, c2, cout = 2, 12, 12, 64, 64, 160
