@@ -117,6 +117,18 @@ def main():
     torch.cuda.synchronize()
     eadist.barrier()
     elapsed = eadist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    # untimed diagnostic pass: GPU time per phase of one step (events on the launch stream; not part of `value`).
+    # pipeline marks: start | inputs+vae_encode | prepare(hint,text kv) | denoise loop | vae_decode
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    pipe.trace = []
+    one_step(args.seed + 5000)
+    marks, pipe.trace = pipe.trace, None
+    torch.cuda.synchronize()
+    phases, prev = {}, ev0
+    for name, ev in marks:
+        phases["sam_encode(+resize)" if name == "start" else name] = round(prev.elapsed_time(ev), 2)
+        prev = ev
     pipe.decode_latents = orig_decode
     assert torch.isfinite(out.images if hasattr(out, "images") else out).all()
 
@@ -133,7 +145,7 @@ def main():
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
-                   "weights_setup_s": round(t_weights, 1)},
+                   "weights_setup_s": round(t_weights, 1), "phase_ms": phases},
     }
     if rank == 0:
         result["roofline"] = roofline_leg(pipe, inp, init_image, args)
@@ -158,6 +170,7 @@ def roofline_leg(pipe, inp, init_image, args):
     pipe.denoiser.eps(x, ts)
     torch.cuda.synchronize()
     recs, ops.PROFILE = ops.PROFILE, None
+    recs = [r for r in recs if r[3].startswith(("gemm", "conv"))]     # the MFMA contraction launches only
     tot_f = sum(r[0] for r in recs)
     tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
     n = len(recs)

@@ -40,7 +40,10 @@ struct AttnParams {
 constexpr int ATT_BQ = 128;  // queries per workgroup
 constexpr int ATT_BK = 64;   // keys per tile
 
-template <int D, bool BIAS>
+// BIAS: 0 none; 1 decomposed rel-pos bias through a per-workgroup LDS table (any S <= 32: SAM's 14x14 windows);
+// 2 the S == ATT_BK == 64 case (SAM global attention): a key tile is exactly one key row, so bias_h is ONE value per
+// query per tile and bias_w is the same 32 values per lane for every tile -> registers, no per-score memory access.
+template <int D, int BIAS>
 __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
   constexpr int NKS = DQK / 16;
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   EA_SMEM(smem);
   char* ks = smem;
   char* vs = smem + ATT_BK * KROW;
+  float* bt = reinterpret_cast<float*>(smem + ATT_BK * KROW + NDT * 32 * VROW);   // BIAS == 1: [128][2S + 1] fp32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -87,6 +91,37 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
     for (int r = 0; r < 16; ++r) oacc[e][r] = 0.0f;
   float m_run = -INFINITY, l_run = 0.0f;
   const float sc2 = p.scale * 1.4426950408889634f;
+
+  constexpr float LOG2E = 1.4426950408889634f;
+  const long long brow = ((long long)bh * p.Nq + q_ld) * p.S;
+  const int bt_ld = 2 * p.S + 1;
+  const float* btq = bt + (wave * 32 + l31) * bt_ld;
+  float bwr[BIAS == 2 ? 2 : 1][BIAS == 2 ? 16 : 1];
+  float bh_next = 0.0f;
+  if (BIAS == 1) {
+    // table rows = this workgroup's 128 queries: [bias_h[q][0..S) | bias_w[q][0..S)] * log2(e)
+    const int q0 = blockIdx.x * ATT_BQ;
+    const int per_q = 2 * p.S;
+    for (int i = tid; i < ATT_BQ * per_q; i += 256) {
+      const int ql = i / per_q, c = i - ql * per_q;
+      int qg = q0 + ql;
+      if (qg >= p.Nq) qg = p.Nq - 1;
+      const long long rb = ((long long)bh * p.Nq + qg) * p.S;
+      bt[ql * bt_ld + c] = (c < p.S ? p.bias_h[rb + c] : p.bias_w[rb + c - p.S]) * LOG2E;
+    }
+  }
+  if (BIAS == 2) {
+    // C-layout row of register r = 4g + j is 8g + 4*half + j: four consecutive keys -> one 16-byte load
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(p.bias_w + brow + 32 * t + 8 * g + 4 * half);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bwr[BIAS == 2 ? t : 0][BIAS == 2 ? 4 * g + j : 0] = w4[j] * LOG2E;
+      }
+    bh_next = p.bias_h[brow] * LOG2E;
+  }
 
   f16x8 kreg[NKLD], vreg[NVLD];
   auto load_kv = [&](int kt) {
@@ -132,6 +167,8 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
 
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) load_kv(kt + 1);
+    const float bh_cur = bh_next;
+    if (BIAS == 2 && kt + 1 < nkt) bh_next = p.bias_h[brow + kt + 1] * LOG2E;
 
     // ---- S^T = K Q^T : two 32-key tiles
     f32x16 sacc[2];
@@ -153,13 +190,13 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
       for (int r = 0; r < 16; ++r) {
         const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
         float sv = sacc[t][r] * sc2;
-        if (BIAS) {
+        if (BIAS == 1) {
           if (key < p.Nk) {
-            const long long brow = ((long long)bh * p.Nq + q_ld) * p.S;
             const int kh = (int)(((unsigned)key * p.magic) >> 22), kw = key - kh * p.S;
-            sv += (p.bias_h[brow + kh] + p.bias_w[brow + kw]) * 1.4426950408889634f;
+            sv += btq[kh] + btq[p.S + kw];
           }
         }
+        if (BIAS == 2) sv += bh_cur + bwr[BIAS == 2 ? t : 0][BIAS == 2 ? r : 0];
         if (key >= p.Nk) sv = -INFINITY;
         sacc[t][r] = sv;
         mx = fmaxf(mx, sv);
@@ -228,11 +265,11 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   }
 }
 
-template <int D, bool BIAS>
+template <int D, int BIAS>
 static int launch_attn(const AttnParams& p, void* stream) {
   constexpr int DQK = (D + 15) / 16 * 16;
   constexpr int NDT = (D + 31) / 32;
-  constexpr int smem = ATT_BK * (DQK * 2 + 16) + NDT * 32 * (ATT_BK * 2 + 8);
+  const int smem = ATT_BK * (DQK * 2 + 16) + NDT * 32 * (ATT_BK * 2 + 8) + (BIAS == 1 ? ATT_BQ * (2 * p.S + 1) * 4 : 0);
   auto kfn = ea_attn_kernel<D, BIAS>;
   ea_allow_big_lds(kfn, smem);
   dim3 grid((p.Nq + ATT_BQ - 1) / ATT_BQ, p.B * p.H, 1);
@@ -298,17 +335,25 @@ extern "C" int ea_attention_f16(const void* q, const void* k, const void* v, voi
   p.magic = S > 0 ? (unsigned)(((1u << 22) + S - 1) / S) : 0u;
   if (S == 0) {
     switch (D) {
-      case 40: return launch_attn<40, false>(p, stream);
-      case 64: return launch_attn<64, false>(p, stream);
-      case 80: return launch_attn<80, false>(p, stream);
-      case 160: return launch_attn<160, false>(p, stream);
+      case 40: return launch_attn<40, 0>(p, stream);
+      case 64: return launch_attn<64, 0>(p, stream);
+      case 80: return launch_attn<80, 0>(p, stream);
+      case 160: return launch_attn<160, 0>(p, stream);
       default: return EA_ERR_UNSUPPORTED;
     }
   }
-  if (S > 128) return EA_ERR_UNSUPPORTED;
+  if (S == ATT_BK) {   // SAM global attention (64 x 64 token grid); bias rows are 256-B aligned fp32
+    if (((uintptr_t)bias_h & 15) || ((uintptr_t)bias_w & 15)) return EA_ERR_BAD_ARG;
+    switch (D) {
+      case 64: return launch_attn<64, 2>(p, stream);
+      case 80: return launch_attn<80, 2>(p, stream);
+      default: return EA_ERR_UNSUPPORTED;
+    }
+  }
+  if (S > 32) return EA_ERR_UNSUPPORTED;   // window sizes: the per-workgroup bias table must fit next to the K/V tiles
   switch (D) {
-    case 64: return launch_attn<64, true>(p, stream);
-    case 80: return launch_attn<80, true>(p, stream);
+    case 64: return launch_attn<64, 1>(p, stream);
+    case 80: return launch_attn<80, 1>(p, stream);
     default: return EA_ERR_UNSUPPORTED;
   }
 }

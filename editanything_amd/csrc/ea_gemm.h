@@ -402,9 +402,33 @@ __global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.0f;
-    for (int s = 0; s < p.splits; ++s) {
-      const float* src = p.partial + ((long long)(batch * p.splits + s) * p.M + m) * p.N + n;
-      for (int j = 0; j < nvalid; ++j) v[j] += src[j];
+    const long long slab = (long long)p.M * p.N;
+    const float* src = p.partial + ((long long)(batch * p.splits) * p.M + m) * p.N + n;
+    if ((p.N & 7) == 0) {
+      // 16-byte loads, four splits in flight per lane before the first add (the adds keep split order: results do
+      // not depend on the unroll)
+      int s = 0;
+      for (; s + 4 <= p.splits; s += 4) {
+        f32x4 t[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          t[u][0] = *reinterpret_cast<const f32x4*>(src + (s + u) * slab);
+          t[u][1] = *reinterpret_cast<const f32x4*>(src + (s + u) * slab + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { v[j] += t[u][0][j]; v[4 + j] += t[u][1][j]; }
+      }
+      for (; s < p.splits; ++s) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src + s * slab);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(src + s * slab + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += lo[j]; v[4 + j] += hi[j]; }
+      }
+    } else {
+      for (int s = 0; s < p.splits; ++s)
+        for (int j = 0; j < nvalid; ++j) v[j] += src[s * slab + j];
     }
     ea_epilogue_store8(p.epi, batch * p.strideC, batch * p.strideR, m, n, v, true);
   }

@@ -13,6 +13,8 @@
 #include "../../include/editanything_hip.h"
 #include <string.h>
 
+#define EA_GN_MAX_CHUNKS 128
+
 namespace {
 
 struct GnParams {
@@ -24,7 +26,8 @@ struct GnParams {
   float* partial;  // [B][nchunk][groups][2]
   int B, HW, C, groups, cpg;
   int V, R;        // channel octets per pixel, pixel rows per workgroup pass
-  int nchunk, chunk_px;
+  int nchunk, chunk_px;     // stats pass chunking (partials per sample)
+  int anchunk, achunk_px;   // apply pass chunking
   float eps;
   int silu;
 };
@@ -37,6 +40,7 @@ __device__ __forceinline__ f16x8 gn_load8(const GnParams& p, long long pix, int 
   return v;
 }
 
+// Pass 1: per-(sample, chunk, group) partial sums.  Four pixels in flight per thread before the first use.
 __global__ void ea_gn_stats_kernel(GnParams p) {
   EA_SMEM(smem);
   float* chs = reinterpret_cast<float*>(smem);  // [R][C]
@@ -51,8 +55,23 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-  for (int px = p_begin + pr; px < p_end; px += p.R) {
-    f16x8 x = gn_load8(p, (long long)b * p.HW + px, c0);
+  const long long pix0 = (long long)b * p.HW;
+  int px = p_begin + pr;
+  for (; px + 3 * p.R < p_end; px += 4 * p.R) {
+    f16x8 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = gn_load8(p, pix0 + px + u * p.R, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)x[u][j];
+        s[j] += f;
+        q[j] += f * f;
+      }
+  }
+  for (; px < p_end; px += p.R) {
+    f16x8 x = gn_load8(p, pix0 + px, c0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float f = (float)x[j];
@@ -66,55 +85,99 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
     chq[pr * p.C + c0 + j] = q[j];
   }
   __syncthreads();
+  // fold rows: thread c sums column c over the R rows (conflict-free), then one thread per group sums cpg columns
+  for (int c = tid; c < p.C; c += blockDim.x) {
+    float cs = 0.0f, cq = 0.0f;
+    for (int rr = 0; rr < p.R; ++rr) {
+      cs += chs[rr * p.C + c];
+      cq += chq[rr * p.C + c];
+    }
+    chs[c] = cs;   // row 0 is only read by this thread in the loop above
+    chq[c] = cq;
+  }
+  __syncthreads();
   for (int g = tid; g < p.groups; g += blockDim.x) {
     float gs = 0.0f, gq = 0.0f;
-    for (int rr = 0; rr < p.R; ++rr)
-      for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) {
-        gs += chs[rr * p.C + c];
-        gq += chq[rr * p.C + c];
-      }
+    for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) {
+      gs += chs[c];
+      gq += chq[c];
+    }
     float* dst = p.partial + (((long long)b * p.nchunk + chunk) * p.groups + g) * 2;
     dst[0] = gs;
     dst[1] = gq;
   }
 }
 
+// Pass 2: fold the partials (in parallel, fixed order), normalise (+SiLU), write fp16.  Its own, finer chunking.
 __global__ void ea_gn_apply_kernel(GnParams p) {
+  EA_SMEM(smem);
+  float* part = reinterpret_cast<float*>(smem);   // [nsub][groups][2]
+  float* gst = part + 2 * p.groups * (blockDim.x / p.groups > 0 ? blockDim.x / p.groups : 1);   // [groups][2]: mean, rstd
   const int tid = threadIdx.x;
   const int v = tid % p.V, pr = tid / p.V;
   const int c0 = v * 8;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int p_begin = chunk * p.chunk_px;
-  int p_end = p_begin + p.chunk_px;
+  const int p_begin = chunk * p.achunk_px;
+  int p_end = p_begin + p.achunk_px;
   if (p_end > p.HW) p_end = p.HW;
-  // fold the partial sums of the groups this octet touches into scale/shift
-  float a[8], sh[8];
-  int g_prev = -1;
-  float mean = 0.0f, rstd = 0.0f;
-  const float inv_n = 1.0f / ((float)p.HW * (float)p.cpg);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int c = c0 + j;
-    const int g = c / p.cpg;
-    if (g != g_prev) {
+  {
+    int nsub = blockDim.x / p.groups;
+    if (nsub < 1) nsub = 1;
+    for (int t = tid; t < nsub * p.groups; t += blockDim.x) {
+      const int g = t % p.groups, sub = t / p.groups;
       float gs = 0.0f, gq = 0.0f;
-      for (int ch = 0; ch < p.nchunk; ++ch) {
+      for (int ch = sub; ch < p.nchunk; ch += nsub) {
         const float* src = p.partial + (((long long)b * p.nchunk + ch) * p.groups + g) * 2;
         gs += src[0];
         gq += src[1];
       }
-      mean = gs * inv_n;
+      part[(sub * p.groups + g) * 2] = gs;
+      part[(sub * p.groups + g) * 2 + 1] = gq;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / ((float)p.HW * (float)p.cpg);
+    for (int g = tid; g < p.groups; g += blockDim.x) {
+      float gs = 0.0f, gq = 0.0f;
+      for (int sub = 0; sub < nsub; ++sub) {
+        gs += part[(sub * p.groups + g) * 2];
+        gq += part[(sub * p.groups + g) * 2 + 1];
+      }
+      const float mean = gs * inv_n;
       float var = gq * inv_n - mean * mean;
       var = var > 0.0f ? var : 0.0f;
-      rstd = 1.0f / sqrtf(var + p.eps);
-      g_prev = g;
+      gst[g * 2] = mean;
+      gst[g * 2 + 1] = 1.0f / sqrtf(var + p.eps);
     }
-    a[j] = rstd * p.gamma[c];
-    sh[j] = p.beta[c] - mean * a[j];
+    __syncthreads();
   }
-  for (int px = p_begin + pr; px < p_end; px += p.R) {
-    const long long pix = (long long)b * p.HW + px;
-    f16x8 x = gn_load8(p, pix, c0);
+  float a[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    const int g = c / p.cpg;
+    a[j] = gst[g * 2 + 1] * p.gamma[c];
+    sh[j] = p.beta[c] - gst[g * 2] * a[j];
+  }
+  const long long pix0 = (long long)b * p.HW;
+  int px = p_begin + pr;
+  for (; px + 3 * p.R < p_end; px += 4 * p.R) {
+    f16x8 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = gn_load8(p, pix0 + px + u * p.R, c0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)x[u][j] * a[j] + sh[j];
+        if (p.silu) f = ea_silu(f);
+        y[j] = (f16)f;
+      }
+      ea_st8(p.out + (pix0 + px + u * p.R) * p.C + c0, y);
+    }
+  }
+  for (; px < p_end; px += p.R) {
+    f16x8 x = gn_load8(p, pix0 + px, c0);
     f16x8 y;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -122,8 +185,127 @@ __global__ void ea_gn_apply_kernel(GnParams p) {
       if (p.silu) f = ea_silu(f);
       y[j] = (f16)f;
     }
-    ea_st8(p.out + pix * p.C + c0, y);
+    ea_st8(p.out + (pix0 + px) * p.C + c0, y);
   }
+}
+
+// Single pass for activations whose (sample, channel slab) fits the register file of one workgroup: one read, one
+// write, one launch.  A workgroup owns `SG` whole groups (slab = SG * cpg channels, a multiple of 8) of one sample for
+// ALL pixels; thread <-> (channel octet of the slab, pixel row), up to GN_MAXIT pixels per thread held in registers.
+constexpr int GN_MAXIT = 16;
+struct GnFusedParams {
+  GnParams g;
+  int slab_ch, slab_oct, sg;   // channels / octets / groups per slab
+  int rows;                    // pixel rows per pass = threads / slab_oct
+};
+
+__global__ __launch_bounds__(512) void ea_gn_fused_kernel(GnFusedParams fp) {
+  const GnParams& p = fp.g;
+  EA_SMEM(smem);
+  float* chs = reinterpret_cast<float*>(smem);      // [rows][slab_ch]
+  float* chq = chs + fp.rows * fp.slab_ch;          // [rows][slab_ch]
+  float* gst = chq + fp.rows * fp.slab_ch;          // [sg][2]
+  const int tid = threadIdx.x;
+  const int v = tid % fp.slab_oct, pr = tid / fp.slab_oct;
+  const bool on = pr < fp.rows;
+  const int slab = blockIdx.x, b = blockIdx.y;
+  const int cl = v * 8;                   // channel within the slab
+  const int c0 = slab * fp.slab_ch + cl;  // global channel
+  const long long pix0 = (long long)b * p.HW;
+  f16x8 x[GN_MAXIT];
+#pragma unroll
+  for (int it = 0; it < GN_MAXIT; ++it) {
+    const int px = pr + it * fp.rows;
+    if (on && px < p.HW) x[it] = gn_load8(p, pix0 + px, c0);
+    else x[it] = ea_zero8();
+  }
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+#pragma unroll
+  for (int it = 0; it < GN_MAXIT; ++it)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)x[it][j];
+      s[j] += f;
+      q[j] += f * f;
+    }
+  if (on) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      chs[pr * fp.slab_ch + cl + j] = s[j];
+      chq[pr * fp.slab_ch + cl + j] = q[j];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < fp.slab_ch; c += blockDim.x) {
+    float cs = 0.0f, cq = 0.0f;
+    for (int rr = 0; rr < fp.rows; ++rr) {
+      cs += chs[rr * fp.slab_ch + c];
+      cq += chq[rr * fp.slab_ch + c];
+    }
+    chs[c] = cs;
+    chq[c] = cq;
+  }
+  __syncthreads();
+  if (tid < fp.sg) {
+    float gs = 0.0f, gq = 0.0f;
+    for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c) {
+      gs += chs[c];
+      gq += chq[c];
+    }
+    const float inv_n = 1.0f / ((float)p.HW * (float)p.cpg);
+    const float mean = gs * inv_n;
+    float var = gq * inv_n - mean * mean;
+    var = var > 0.0f ? var : 0.0f;
+    gst[tid * 2] = mean;
+    gst[tid * 2 + 1] = 1.0f / sqrtf(var + p.eps);
+  }
+  __syncthreads();
+  if (!on) return;
+  float a[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int g = (cl + j) / p.cpg;
+    a[j] = gst[g * 2 + 1] * p.gamma[c0 + j];
+    sh[j] = p.beta[c0 + j] - gst[g * 2] * a[j];
+  }
+#pragma unroll
+  for (int it = 0; it < GN_MAXIT; ++it) {
+    const int px = pr + it * fp.rows;
+    if (px < p.HW) {
+      f16x8 y;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (float)x[it][j] * a[j] + sh[j];
+        if (p.silu) f = ea_silu(f);
+        y[j] = (f16)f;
+      }
+      ea_st8(p.out + (pix0 + px) * p.C + c0, y);
+    }
+  }
+}
+
+// Slab of the single-pass kernel: the fewest whole groups whose channels are a multiple of 8 and span >= 64 bytes,
+// never straddling the x1 | x2 boundary of a two-source input.  Returns 0 when the single pass does not apply.
+static int gn_fused_plan(const GnParams& p, GnFusedParams& fp) {
+  int sg = 0;
+  for (int k = 1; k <= p.groups; ++k) {
+    const int ch = k * p.cpg;
+    if ((ch & 7) == 0 && ch >= 32 && (p.groups % k) == 0) { sg = k; break; }
+  }
+  if (!sg) return 0;
+  const int slab_ch = sg * p.cpg;
+  if (p.c2 > 0 && (p.c1 % slab_ch) != 0) return 0;
+  const int slab_oct = slab_ch / 8;
+  const long long octets = (long long)p.HW * slab_oct;      // 16-byte vectors per (sample, slab)
+  int threads = 256;
+  while (threads < 512 && (long long)(threads / slab_oct) * slab_oct * GN_MAXIT < octets) threads *= 2;
+  const int rows = threads / slab_oct;
+  if (rows < 1 || (long long)rows * GN_MAXIT < p.HW) return 0;
+  fp.g = p;
+  fp.sg = sg; fp.slab_ch = slab_ch; fp.slab_oct = slab_oct; fp.rows = rows;
+  return threads;
 }
 
 static int gn_plan(GnParams& p) {
@@ -136,14 +318,19 @@ static int gn_plan(GnParams& p) {
   if (r > 32) r = 32;
   if (r > p.HW) r = p.HW;
   p.R = r;
-  int target = 1024 / (p.B > 0 ? p.B : 1);
+  int target = 2048 / (p.B > 0 ? p.B : 1);
   if (target < 1) target = 1;
-  int nchunk = p.HW / (r * 2);
+  int nchunk = p.HW / (r * 4);
   if (nchunk > target) nchunk = target;
-  if (nchunk > 64) nchunk = 64;
+  if (nchunk > EA_GN_MAX_CHUNKS) nchunk = EA_GN_MAX_CHUNKS;
   if (nchunk < 1) nchunk = 1;
   p.chunk_px = (p.HW + nchunk - 1) / nchunk;
   p.nchunk = (p.HW + p.chunk_px - 1) / p.chunk_px;
+  // apply pass: ~8 pixels per thread, at most 4096 workgroups per sample
+  int achunk = r * 8;
+  if ((p.HW + achunk - 1) / achunk > 4096) achunk = (p.HW + 4095) / 4096;
+  p.achunk_px = achunk;
+  p.anchunk = (p.HW + achunk - 1) / achunk;
   return EA_OK;
 }
 
@@ -248,7 +435,7 @@ __global__ __launch_bounds__(256) void ea_softmax_rows_kernel(const float* x, f1
 
 extern "C" size_t ea_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
   if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
-  return (size_t)B * 64 * groups * 2 * sizeof(float);
+  return (size_t)B * EA_GN_MAX_CHUNKS * groups * 2 * sizeof(float);
 }
 
 extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, const void* x2_add,
@@ -271,6 +458,16 @@ extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, 
   if (st != EA_OK) return st;
   if (ws_bytes < ea_groupnorm_workspace_bytes(B, HW, p.C, groups)) return EA_ERR_WORKSPACE;
   p.partial = (float*)workspace;
+  GnFusedParams fp;
+  const int fthreads = gn_fused_plan(p, fp);
+  if (fthreads > 0) {
+    dim3 fgrid(p.C / fp.slab_ch, B, 1);
+    const int fsmem = (2 * fp.rows * fp.slab_ch + 2 * fp.sg) * (int)sizeof(float);
+    auto kf = ea_gn_fused_kernel;
+    ea_allow_big_lds(kf, fsmem);
+    EA_LAUNCH(kf, fgrid, dim3(fthreads, 1, 1), fsmem, stream, fp);
+    return ea_launch_status();
+  }
   dim3 grid(p.nchunk, B, 1), block(p.V * p.R, 1, 1);
   const int smem = 2 * p.R * p.C * (int)sizeof(float);
   auto k1 = ea_gn_stats_kernel;
@@ -279,7 +476,10 @@ extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, 
   st = ea_launch_status();
   if (st != EA_OK) return st;
   auto k2 = ea_gn_apply_kernel;
-  EA_LAUNCH(k2, grid, block, 0, stream, p);
+  int nsub = (p.V * p.R) / groups;
+  if (nsub < 1) nsub = 1;
+  const int smem2 = (2 * groups * nsub + 2 * groups) * (int)sizeof(float);
+  EA_LAUNCH(k2, dim3(p.anchunk, B, 1), block, smem2, stream, p);
   return ea_launch_status();
 }
 

@@ -27,11 +27,13 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, flops):
+def _prof_end(e0, flops, label=""):
+    """label: "gemm ..." / "conv ..." for the MFMA contraction launches (the ones bench.py's roofline leg sums),
+    anything else for the other kernels (tools/eval_breakdown.py)."""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((flops, e0, e1))
+        PROFILE.append((flops, e0, e1, label))
 
 
 def _lib():
@@ -101,7 +103,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
         e.geglu_block = 80 if (N % 160 == 0 and K % 64 == 0) else 64       # must match unet.pack_geglu
     ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
-    _prof_end(ev, 2.0 * M * N * K)
+    _prof_end(ev, 2.0 * M * N * K, f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}")
     L.check(st, f"ea_gemm_f16 M{M} N{N} K{K}")
     return out
 
@@ -145,7 +147,8 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
     e = _epilogue(out, cout, bias, act, scale, residual, rowvec, s.Hout * s.Wout, row_scale)
     ev = _prof_begin()
     st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
-    _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1])
+    _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1],
+              f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}")
     L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
     return out
 
@@ -159,8 +162,10 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
     if out is None:
         out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=torch.float16, device=x1.device)
     ws = workspace(x1.device)
+    ev = _prof_begin()
     st = _lib().ea_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(x2_add), _p(gamma), _p(beta), _p(out), B, HW, groups, eps,
                                  int(silu), _p(ws), ws.numel(), _stream())
+    _prof_end(ev, 0.0, f"groupnorm B{B} HW{HW} C{c1}+{c2}")
     L.check(st, "ea_groupnorm_f16")
     return out
 
@@ -190,7 +195,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     Cc = x.shape[-1]
     M = x.numel() // Cc
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    ev = _prof_begin()
     st = _lib().ea_layernorm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), _p(out), M, Cc, eps, _stream())
+    _prof_end(ev, 0.0, f"layernorm M{M} C{Cc}")
     L.check(st, "ea_layernorm_f16")
     return out
 
@@ -225,9 +232,11 @@ def attention(q, k, v, heads, dim_head, scale=None, bias_h=None, bias_w=None, S=
     if out is None:
         out = torch.empty((B, Nq, heads * dim_head), dtype=torch.float16, device=q.device)
     scale = dim_head ** -0.5 if scale is None else scale
+    ev = _prof_begin()
     st = _lib().ea_attention_f16(_p(q), _p(k), _p(v), _p(out), B, heads, Nq, Nk, dim_head, q.stride(0), q.stride(1),
                                  k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
                                  float(scale), _p(bias_h), _p(bias_w), S, _stream())
+    _prof_end(ev, 0.0, f"attn B{B} H{heads} Nq{Nq} Nk{Nk} D{dim_head} S{S}")
     L.check(st, f"ea_attention_f16 B{B} H{heads} Nq{Nq} Nk{Nk} D{dim_head}")
     return out
 

@@ -330,13 +330,31 @@ class ControlledDenoiser:
         self.control_scales = None
         self.only_mid_control = False
 
-    def prepare(self, context, hints=None, control_scales=None):
-        self.kv_u = self.unet.project_context(context)
-        self.kv_c, self.hints = [], []
+    def static_state(self):
+        """The per-call invariants a captured step reads (pipeline graph cache keeps them alive and refills them)."""
+        return dict(kv_u=self.kv_u, kv_c=self.kv_c, hints=self.hints)
+
+    def prepare(self, context, hints=None, control_scales=None, static=None):
+        """`static`: a `static_state()` of an earlier call with identical shapes -- the new values are written INTO
+        those buffers (same addresses), so a HIP graph captured over them stays valid."""
+        kv_u = self.unet.project_context(context)
+        kv_c, hs = [], []
         hints = [] if hints is None else (hints if isinstance(hints, (list, tuple)) else [hints])
         for cn, hint in zip(self.controlnets, hints):
-            self.kv_c.append(cn.project_context(context))
-            self.hints.append(None if hint is None else cn.encode_hint(hint))
+            kv_c.append(cn.project_context(context))
+            hs.append(None if hint is None else cn.encode_hint(hint))
+        if static is None:
+            self.kv_u, self.kv_c, self.hints = kv_u, kv_c, hs
+        else:
+            for dst, src in zip(static["kv_u"], kv_u):
+                dst.copy_(src)
+            for dl, sl in zip(static["kv_c"], kv_c):
+                for dst, src in zip(dl, sl):
+                    dst.copy_(src)
+            for dst, src in zip(static["hints"], hs):
+                if dst is not None:
+                    dst.copy_(src)
+            self.kv_u, self.kv_c, self.hints = static["kv_u"], static["kv_c"], static["hints"]
         n = len(self.unet.plan["input"]) + 1
         if control_scales is None:
             control_scales = [[1.0] * n for _ in self.controlnets]

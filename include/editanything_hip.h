@@ -121,7 +121,8 @@ int ea_ln_gemm_f16(const void* x, int in_f32, const float* gamma, const float* b
 
 /* Flash-style attention.  q/k/v element (b, i, h, d) at ptr + b*s_b + i*s_n + h*D + d (fp16).
  * out [B][Nq][H*D] fp16 (row stride o_sn).  Optional decomposed rel-pos bias (SAM):
- * bias_h/bias_w fp32 [B*H][Nq][S]; key j -> (j / S, j % S); S = 0 disables. D in {40,64,80,160}. */
+ * bias_h/bias_w fp32 [B*H][Nq][S]; key j -> (j / S, j % S); S = 0 disables; S <= 32 (windows) or S == 64 (global
+ * 64x64 grid; tables 16-byte aligned).  D in {40,64,80,160}; with bias D in {64,80}. */
 int ea_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq, int Nk,
                      int D, long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb,
                      long long v_sn, long long o_sb, long long o_sn, float scale, const float* bias_h,

@@ -396,6 +396,22 @@ def test_sam_window_attention_relpos(kb, S, D):
     assert relerr(kb.down(out), attn_ref(q, k, v, scale, bias).numpy()) < 3e-3
 
 
+def test_sam_global_attention_bias_rows(kb):
+    """S == 64 path (bias_w in registers, one bias_h value per key tile): 128 query rows against the full 64x64 key
+    grid, bias tables given directly (random), ragged last query block."""
+    S, D, B, H, Nq = 64, 80, 1, 1, 100
+    Nk = S * S
+    q, k, v = f16(B, Nq, H, D), f16(B, Nk, H, D), f16(B, Nk, H, D)
+    bh, bw = f32(B * H, Nq, S), f32(B * H, Nq, S)
+    out = kb.zeros((B, Nq, H, D), np.float16)
+    scale = D ** -0.5
+    st = kb.lib.ea_attention_f16(ptr(q), ptr(k), ptr(v), ptr(out), B, H, Nq, Nk, D, Nq * H * D, H * D, Nk * H * D, H * D,
+                                 Nk * H * D, H * D, Nq * H * D, H * D, scale, ptr(bh), ptr(bw), S, kb.stream)
+    assert st == 0
+    bias = (t(bh)[:, :, :, None] + t(bw)[:, :, None, :]).reshape(B, H, Nq, Nk)
+    assert relerr(kb.down(out), attn_ref(q, k, v, scale, bias).numpy()) < 3e-3
+
+
 def test_softmax_rows(kb):
     x = f32(5, 300, scale=3.0)
     out = kb.zeros((5, 300), np.float16)

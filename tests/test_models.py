@@ -174,3 +174,28 @@ def test_sam_vit_b_full_size_vs_oracle():
         ref = sam_oracle.image_encoder(sd, arch.SAM_VIT_B, sam_oracle.preprocess(img))
         out = ImageEncoderViT(arch.SAM_VIT_B, sd, DEV).encode_image(img)
     check(out, ref, l2=1e-2, mx=3e-2)
+
+
+def test_graph_cache_reuse_across_calls(tiny):
+    """The captured step is reused by later calls with the same shapes: a second call with DIFFERENT latents, prompt
+    embeddings and control image must equal the eager (graph-free) result for those inputs, and the first call's
+    returned latents must not be overwritten by the second (static buffers are never handed out)."""
+    from editanything_amd.pipeline import StableDiffusionControlNetPipeline
+    from editanything_amd.scheduler import DDIMScheduler
+    cn, un, vae = tiny
+    d = g("ldm_tiny_ddim.npz")
+    pg = StableDiffusionControlNetPipeline(vae, un, cn, DDIMScheduler(), device=DEV, use_graph=True)
+    pe = StableDiffusionControlNetPipeline(vae, un, cn, DDIMScheduler(), device=DEV, use_graph=False)
+    gen = torch.Generator("cpu").manual_seed(3)
+    calls = []
+    for k in range(3):
+        ctx = t(d["ctx"]) + 0.3 * k * torch.randn(t(d["ctx"]).shape, generator=gen)
+        hint = (t(d["hint"]) + 17.0 * k) % 256
+        xT = t(d["x_T"]) + 0.5 * k * torch.randn(t(d["x_T"]).shape, generator=gen)
+        kw = dict(prompt_embeds=ctx, negative_prompt_embeds=t(d["un_ctx"]), image=hint, num_inference_steps=4,
+                  guidance_scale=9.0, latents=xT, output_type="latent", height=128, width=128)
+        calls.append((pg(**kw).images, pe(**kw).images))
+    assert len(pg._graphs) == 1, "one capture for three same-shaped calls"
+    for og, oe in calls:
+        check(og, oe, l2=1e-3, mx=3e-3)
+    assert rel_l2(calls[0][0], calls[2][0]) > 1e-2, "calls with different inputs must differ"
