@@ -39,25 +39,89 @@ struct AttnParams {
 
 constexpr int ATT_BQ = 128;  // queries per workgroup
 constexpr int ATT_BK = 64;   // keys per tile
+// Deferred rescale (guide T13): the running max only moves (and O / l are only rescaled) when some lane's tile max
+// exceeds it by more than this many log2 units; until then P = exp2(s - m_run) <= 2^8, exact in fp16's range, l and O
+// accumulate in fp32 -- the result differs from the always-rescale form only by fp32 rounding.
+constexpr float ATT_DEFER = 8.0f;
+
+// ds_read_b64_tr_b16: within each 16-lane group the 16 x 8-byte pieces form a [4][16] fp16 block (row r = lanes
+// 4r..4r+3, each supplying 4 consecutive columns); lane i receives column i = (M[0][i], M[1][i], M[2][i], M[3][i]).
+// (Mapping measured on gfx950 with tools/probe_tr.hip.)  Lets V stay row-major [key][d] in LDS -- written with plain
+// 16-byte stores -- and still be consumed as the V^T operand of O^T = V^T P^T.
+__device__ __forceinline__ f16x4 ea_lds_read_tr16(const char* ptr) {
+#ifdef EA_EMU
+  char* sc = ea_emu::wave_scratch();
+  const int l = ea_emu::lane_id();
+  memcpy(sc + l * 64, ptr, 8);
+  ea_emu::wave_sync();
+  const int g = l & ~15, i = l & 15;
+  f16x4 r;
+  for (int rr = 0; rr < 4; ++rr) {
+    f16 v;
+    memcpy(&v, sc + (g + 4 * rr + (i >> 2)) * 64 + (i & 3) * 2, 2);
+    r[rr] = v;
+  }
+  ea_emu::wave_sync();
+  return r;
+#else
+  f16x4 r;
+  const unsigned addr = (unsigned)(uintptr_t)ptr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+#endif
+}
+// the asm read above is invisible to the compiler's lgkmcnt bookkeeping: wait for it explicitly before the first use,
+// and keep the consumers behind the wait (guide section 5.4 rule 18)
+__device__ __forceinline__ void ea_lds_tr_wait() {
+#ifndef EA_EMU
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+__device__ __forceinline__ float ea_exp2(float x) {
+#ifdef EA_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);   // bare v_exp_f32 (inputs here are <= 8, denormal results flush to 0)
+#endif
+}
+__device__ __forceinline__ bool ea_wave_any(bool v) {
+#ifdef EA_EMU
+  char* sc = ea_emu::wave_scratch();
+  const int l = ea_emu::lane_id();
+  sc[l * 64] = v ? 1 : 0;
+  ea_emu::wave_sync();
+  bool r = false;
+  for (int i = 0; i < ea_emu::wave_lanes(); ++i) r = r || sc[i * 64];
+  ea_emu::wave_sync();
+  return r;
+#else
+  return __any(v);
+#endif
+}
 
 // BIAS: 0 none; 1 decomposed rel-pos bias through a per-workgroup LDS table (any S <= 32: SAM's 14x14 windows);
 // 2 the S == ATT_BK == 64 case (SAM global attention): a key tile is exactly one key row, so bias_h is ONE value per
 // query per tile and bias_w is the same 32 values per lane for every tile -> registers, no per-score memory access.
 template <int D, int BIAS>
-__global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
   constexpr int NKS = DQK / 16;
   constexpr int NDT = (D + 31) / 32;       // 32-wide tiles of the head dim for O^T
+  constexpr int DV = NDT * 32;             // V row width in LDS (columns >= D stay zero)
   constexpr int KROW = DQK * 2 + 16;       // bytes per K row in LDS (pad -> conflict-free b128 reads)
-  constexpr int VROW = ATT_BK * 2 + 8;     // bytes per V^T row in LDS
+  // V row stride: the transpose read of a 32-lane half touches 4 consecutive rows x 64 bytes; a stride of 64 or 192
+  // mod 256 puts those four segments on disjoint banks
+  constexpr int VROW = ((DV * 2) % 256 == 64 || (DV * 2) % 256 == 192) ? DV * 2 : DV * 2 + 64;
+  static_assert(VROW % 256 == 64 || VROW % 256 == 192, "V row stride");
   constexpr int KCH = DQK / 8;             // 16-B chunks per K row
   constexpr int VCH = D / 8;
   constexpr int NKLD = (ATT_BK * KCH + 255) / 256;
   constexpr int NVLD = (ATT_BK * VCH + 255) / 256;
+  constexpr int STAGE = ATT_BK * KROW + ATT_BK * VROW;   // one K/V tile; two of them form the ring
+  constexpr float LOG2E = 1.4426950408889634f;
   EA_SMEM(smem);
-  char* ks = smem;
-  char* vs = smem + ATT_BK * KROW;
-  float* bt = reinterpret_cast<float*>(smem + ATT_BK * KROW + NDT * 32 * VROW);   // BIAS == 1: [128][2S + 1] fp32
+  float* bt = reinterpret_cast<float*>(smem + 2 * STAGE);   // BIAS == 1: [128][2S + 1] fp32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -71,9 +135,15 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   const f16* kp = p.k + b * p.k_sb + (long long)h * D;
   const f16* vp = p.v + b * p.v_sb + (long long)h * D;
 
-  // zero the V^T rows that pad D up to NDT*32 (never rewritten afterwards)
-  for (int i = tid; i < (NDT * 32 - D) * (VROW / 2); i += 256)
-    reinterpret_cast<f16*>(vs + D * VROW)[i] = (f16)0.0f;
+  // zero the V columns that pad D up to DV in both stages (never rewritten afterwards)
+  if (DV > D) {
+    constexpr int PADC = DV - D;   // multiple of 8
+    for (int i = tid; i < 2 * ATT_BK * (PADC / 8); i += 256) {
+      const int st = i / (ATT_BK * (PADC / 8)), rem = i - st * (ATT_BK * (PADC / 8));
+      const int row = rem / (PADC / 8), c = rem - row * (PADC / 8);
+      *reinterpret_cast<f16x8*>(smem + st * STAGE + ATT_BK * KROW + row * VROW + (D + 8 * c) * 2) = ea_zero8();
+    }
+  }
 
   // Q^T fragments (B operand): lane holds Q[q][16s + 8*half .. +7]
   f16x8 qf[NKS];
@@ -89,10 +159,9 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
   for (int e = 0; e < NDT; ++e)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[e][r] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f;
-  const float sc2 = p.scale * 1.4426950408889634f;
+  float m_run = -INFINITY, l_run = 0.0f;   // m_run in the scaled log2 domain
+  const float sc2 = p.scale * LOG2E;
 
-  constexpr float LOG2E = 1.4426950408889634f;
   const long long brow = ((long long)bh * p.Nq + q_ld) * p.S;
   const int bt_ld = 2 * p.S + 1;
   const float* btq = bt + (wave * 32 + l31) * bt_ld;
@@ -123,6 +192,7 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
     bh_next = p.bias_h[brow] * LOG2E;
   }
 
+  // K/V staging (guide T14): global -> registers early, registers -> LDS late; both row-major 16-byte stores
   f16x8 kreg[NKLD], vreg[NVLD];
   auto load_kv = [&](int kt) {
 #pragma unroll
@@ -142,7 +212,9 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
       else vreg[i] = ea_zero8();
     }
   };
-  auto store_kv = [&]() {
+  auto store_kv = [&](int buf) {
+    char* ks = smem + buf * STAGE;
+    char* vs = ks + ATT_BK * KROW;
 #pragma unroll
     for (int i = 0; i < NKLD; ++i) {
       const int c = tid + 256 * i;
@@ -152,21 +224,24 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < NVLD; ++i) {
       const int c = tid + 256 * i;
-      const int row = c / VCH, d0 = (c - row * VCH) * 8;
-      if (c < ATT_BK * VCH) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<f16*>(vs + (d0 + j) * VROW + row * 2) = vreg[i][j];
-      }
+      const int row = c / VCH, cc = c - row * VCH;
+      if (c < ATT_BK * VCH) *reinterpret_cast<f16x8*>(vs + row * VROW + cc * 16) = vreg[i];
     }
   };
 
+  // per-lane part of the V^T fragment address: 16-lane group g -> key half (g >> 1), d block (g & 1); lane i of the
+  // group supplies key row (i >> 2), columns 4*(i & 3) of the [4 keys][16 d] block
+  const int vt_off = (4 * half + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
   const int nkt = (p.Nk + ATT_BK - 1) / ATT_BK;
   load_kv(0);
-  store_kv();
+  store_kv(0);
+  if (nkt > 1) load_kv(1);
   __syncthreads();
 
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) load_kv(kt + 1);
+    const char* ks = smem + (kt & 1) * STAGE;
+    const char* vs = ks + ATT_BK * KROW;
     const float bh_cur = bh_next;
     if (BIAS == 2 && kt + 1 < nkt) bh_next = p.bias_h[brow + kt + 1] * LOG2E;
 
@@ -182,67 +257,83 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
         sacc[t] = ea_mfma_32x32x16(a, qf[s], sacc[t]);
       }
     }
-    // ---- scale, bias, mask, running max
+    // ---- scores -> scaled log2 domain (+ bias), key mask on the ragged last tile only, tile max
+    const bool ragged = (kt + 1) * ATT_BK > p.Nk;
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
         float sv = sacc[t][r] * sc2;
         if (BIAS == 1) {
+          const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
           if (key < p.Nk) {
             const int kh = (int)(((unsigned)key * p.magic) >> 22), kw = key - kh * p.S;
             sv += btq[kh] + btq[p.S + kw];
           }
         }
         if (BIAS == 2) sv += bh_cur + bwr[BIAS == 2 ? t : 0][BIAS == 2 ? r : 0];
-        if (key >= p.Nk) sv = -INFINITY;
+        if (ragged) {
+          const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
+          if (key >= p.Nk) sv = -INFINITY;
+        }
         sacc[t][r] = sv;
         mx = fmaxf(mx, sv);
       }
     mx = fmaxf(mx, ea_shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.0f : m_new;
-    const float alpha = exp2f(m_run - m_use);
-    m_run = m_new;
+    // ---- deferred rescale: move the running max only when some lane outgrew it by more than ATT_DEFER
+    if (ea_wave_any(mx > m_run + ATT_DEFER)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : ea_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int e = 0; e < NDT; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[e][r] *= alpha;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.0f : m_run;
     float psum = 0.0f;
     f16x8 pb[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(sacc[t][r] - m_use);
+        const float pv = ea_exp2(sacc[t][r] - m_use);
         psum += pv;
         pb[t][r >> 3][r & 7] = (f16)pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int e = 0; e < NDT; ++e)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[e][r] *= alpha;
+    l_run += psum;
 
-    // ---- O^T += V^T P^T
+    // ---- O^T += V^T P^T.  P^T (B operand) comes straight from the S^T accumulator registers: MFMA k index
+    // 8*half + j  <->  key 32t + 16u + 4*half + (j & 3) + 8*(j >> 2); the V^T fragment is gathered to match by two
+    // transpose reads of 4 keys each (keys +0..3 and +8..11).
 #pragma unroll
-    for (int e = 0; e < NDT; ++e)
+    for (int e = 0; e < NDT; ++e) {
+      f16x4 vlo[4], vhi[4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int tu = 0; tu < 4; ++tu) {
+        const char* base = vs + vt_off + (16 * tu) * VROW + 64 * e;
+        vlo[tu] = ea_lds_read_tr16(base);
+        vhi[tu] = ea_lds_read_tr16(base + 8 * VROW);
+      }
+      ea_lds_tr_wait();
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const char* base = vs + (32 * e + l31) * VROW + (32 * t + 16 * u + 4 * half) * 2;
-          const f16x4 lo = *reinterpret_cast<const f16x4*>(base);
-          const f16x4 hi = *reinterpret_cast<const f16x4*>(base + 16);
-          f16x8 a;
+      for (int tu = 0; tu < 4; ++tu) {
+        f16x8 a;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
-          oacc[e] = ea_mfma_32x32x16(a, pb[t][u], oacc[e]);
-        }
-
-    __syncthreads();
-    if (kt + 1 < nkt) {
-      store_kv();
-      __syncthreads();
+        for (int j = 0; j < 4; ++j) { a[j] = vlo[tu][j]; a[4 + j] = vhi[tu][j]; }
+        oacc[e] = ea_mfma_32x32x16(a, pb[tu >> 1][tu & 1], oacc[e]);
+      }
     }
+
+    // ---- stage the next tile into the other buffer (last read during iteration kt - 1, i.e. before the barrier
+    // every wave passed at the end of that iteration), then fetch the tile after it into the freed registers
+    if (kt + 1 < nkt) {
+      store_kv((kt + 1) & 1);
+      if (kt + 2 < nkt) load_kv(kt + 2);
+    }
+    __syncthreads();
   }
 
   // ---- normalise and store: lane holds O[q][32e + 8g + 4*half + 0..3]
@@ -268,8 +359,9 @@ __global__ __launch_bounds__(256) void ea_attn_kernel(AttnParams p) {
 template <int D, int BIAS>
 static int launch_attn(const AttnParams& p, void* stream) {
   constexpr int DQK = (D + 15) / 16 * 16;
-  constexpr int NDT = (D + 31) / 32;
-  const int smem = ATT_BK * (DQK * 2 + 16) + NDT * 32 * (ATT_BK * 2 + 8) + (BIAS == 1 ? ATT_BQ * (2 * p.S + 1) * 4 : 0);
+  constexpr int DV = (D + 31) / 32 * 32;
+  constexpr int VROW = ((DV * 2) % 256 == 64 || (DV * 2) % 256 == 192) ? DV * 2 : DV * 2 + 64;
+  const int smem = 2 * ATT_BK * ((DQK * 2 + 16) + VROW) + (BIAS == 1 ? ATT_BQ * (2 * p.S + 1) * 4 : 0);
   auto kfn = ea_attn_kernel<D, BIAS>;
   ea_allow_big_lds(kfn, smem);
   dim3 grid((p.Nq + ATT_BQ - 1) / ATT_BQ, p.B * p.H, 1);

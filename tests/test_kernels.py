@@ -302,6 +302,9 @@ def test_conv1x1_scale_add_zero_conv(kb):
     (1, 100, 320, 0, 32, 1, 1e-5),   # 10 channels per group: octets straddle groups
     (2, 36, 32, 64, 32, 0, 1e-6),    # concat source, no SiLU (SpatialTransformer.norm)
     (1, 7, 128, 0, 32, 1, 1e-6),
+    (1, 2100, 64, 0, 32, 1, 1e-5),   # too many pixels for the single-pass kernel -> stats + apply passes
+    (2, 36, 64, 64, 32, 0, 1e-6),    # single pass over a two-source input (slabs never straddle x1 | x2)
+    (1, 300, 960, 0, 32, 1, 1e-5),   # 30 channels per group -> 4-group slabs of 120 channels
 ])
 def test_groupnorm(kb, B, HW, c1, c2, groups, silu, eps):
     x1 = (f16(B, HW, c1).astype(np.float32) * 2 + 0.5).astype(np.float16)
