@@ -24,6 +24,7 @@
 #include "ea_platform.h"
 #include "../../include/editanything_hip.h"
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -48,7 +49,9 @@ constexpr float ATT_DEFER = 8.0f;
 // 4r..4r+3, each supplying 4 consecutive columns); lane i receives column i = (M[0][i], M[1][i], M[2][i], M[3][i]).
 // (Mapping measured on gfx950 with tools/probe_tr.hip.)  Lets V stay row-major [key][d] in LDS -- written with plain
 // 16-byte stores -- and still be consumed as the V^T operand of O^T = V^T P^T.
-__device__ __forceinline__ f16x4 ea_lds_read_tr16(const char* ptr) {
+template <int OFF>
+__device__ __forceinline__ f16x4 ea_lds_read_tr16(const char* ptr0) {
+  const char* ptr = ptr0 + OFF;
 #ifdef EA_EMU
   char* sc = ea_emu::wave_scratch();
   const int l = ea_emu::lane_id();
@@ -65,13 +68,21 @@ __device__ __forceinline__ f16x4 ea_lds_read_tr16(const char* ptr) {
   return r;
 #else
   f16x4 r;
-  const unsigned addr = (unsigned)(uintptr_t)ptr;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  (void)ptr;
+  const unsigned addr = (unsigned)(uintptr_t)ptr0;   // one address VGPR per tile, the rest is the 16-bit immediate
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
   return r;
 #endif
 }
 // the asm read above is invisible to the compiler's lgkmcnt bookkeeping: wait for it explicitly before the first use,
 // and keep the consumers behind the wait (guide section 5.4 rule 18)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void ea_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    ea_static_for<N, I + 1>(f);
+  }
+}
 __device__ __forceinline__ void ea_lds_tr_wait() {
 #ifndef EA_EMU
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -83,6 +94,17 @@ __device__ __forceinline__ float ea_exp2(float x) {
   return exp2f(x);
 #else
   return __builtin_amdgcn_exp2f(x);   // bare v_exp_f32 (inputs here are <= 8, denormal results flush to 0)
+#endif
+}
+// c + a.x + a.y (fp32 accumulate)
+__device__ __forceinline__ float ea_dot2_ones(f16x2 a, float c) {
+#ifdef EA_EMU
+  return c + (float)a[0] + (float)a[1];
+#else
+  f16x2 one;
+  one[0] = (f16)1.0f;
+  one[1] = (f16)1.0f;
+  return __builtin_amdgcn_fdot2(a, one, c, false);
 #endif
 }
 __device__ __forceinline__ bool ea_wave_any(bool v) {
@@ -104,7 +126,7 @@ __device__ __forceinline__ bool ea_wave_any(bool v) {
 // 2 the S == ATT_BK == 64 case (SAM global attention): a key tile is exactly one key row, so bias_h is ONE value per
 // query per tile and bias_w is the same 32 values per lane for every tile -> registers, no per-score memory access.
 template <int D, int BIAS>
-__global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 && BIAS == 0 ? 3 : (D <= 80 ? 2 : 1))) void ea_attn_kernel(AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
   constexpr int NKS = DQK / 16;
   constexpr int NDT = (D + 31) / 32;       // 32-wide tiles of the head dim for O^T
@@ -239,7 +261,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnPar
   if (nkt > 1) load_kv(1);
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  // One K/V tile.  MASKED is the ragged last tile (keys >= Nk get -inf): a separate instantiation, so the full tiles
+  // carry no per-score compare/select work.
+  auto tile = [&](int kt, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const char* ks = smem + (kt & 1) * STAGE;
     const char* vs = ks + ATT_BK * KROW;
     const float bh_cur = bh_next;
@@ -257,29 +282,31 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnPar
         sacc[t] = ea_mfma_32x32x16(a, qf[s], sacc[t]);
       }
     }
-    // ---- scores -> scaled log2 domain (+ bias), key mask on the ragged last tile only, tile max
-    const bool ragged = (kt + 1) * ATT_BK > p.Nk;
+    // ---- tile max.  BIAS == 0: on the raw scores (the positive scale is folded into the exponent's FMA);
+    // with a bias the scores are first moved to the scaled log2 domain.
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float sv = sacc[t][r] * sc2;
+        float sv = sacc[t][r];
+        if (BIAS != 0) sv *= sc2;
         if (BIAS == 1) {
           const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
-          if (key < p.Nk) {
+          if (!MASKED || key < p.Nk) {
             const int kh = (int)(((unsigned)key * p.magic) >> 22), kw = key - kh * p.S;
             sv += btq[kh] + btq[p.S + kw];
           }
         }
         if (BIAS == 2) sv += bh_cur + bwr[BIAS == 2 ? t : 0][BIAS == 2 ? r : 0];
-        if (ragged) {
+        if (MASKED) {
           const int key = kt * ATT_BK + 32 * t + ea_mfma_row(r, lane);
           if (key >= p.Nk) sv = -INFINITY;
         }
         sacc[t][r] = sv;
         mx = fmaxf(mx, sv);
       }
+    if (BIAS == 0) mx *= sc2;
     mx = fmaxf(mx, ea_shfl_xor(mx, 32));
     // ---- deferred rescale: move the running max only when some lane outgrew it by more than ATT_DEFER
     if (ea_wave_any(mx > m_run + ATT_DEFER)) {
@@ -291,32 +318,42 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnPar
       for (int e = 0; e < NDT; ++e)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[e][r] *= alpha;
+#ifndef EA_EMU
+      asm volatile("" ::: "memory");   // a real (wave-uniform) branch: the common no-rescale path pays nothing
+#endif
     }
     const float m_use = (m_run == -INFINITY) ? 0.0f : m_run;
+    // the row sum is taken over the fp16-rounded probabilities -- the values the PV MFMA actually uses -- two per
+    // v_dot2_f32_f16 (half the VALU instructions of an fp32 add chain; this loop is VALU-bound at D = 64)
     float psum = 0.0f;
     f16x8 pb[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = ea_exp2(sacc[t][r] - m_use);
-        psum += pv;
-        pb[t][r >> 3][r & 7] = (f16)pv;
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = (BIAS == 0) ? ea_exp2(fmaf(sacc[t][r], sc2, -m_use)) : ea_exp2(sacc[t][r] - m_use);
+        const float p1 = (BIAS == 0) ? ea_exp2(fmaf(sacc[t][r + 1], sc2, -m_use)) : ea_exp2(sacc[t][r + 1] - m_use);
+        f16x2 pp;
+        pp[0] = (f16)p0;
+        pp[1] = (f16)p1;
+        psum = ea_dot2_ones(pp, psum);
+        pb[t][r >> 3][r & 7] = pp[0];
+        pb[t][r >> 3][(r & 7) + 1] = pp[1];
       }
     l_run += psum;
 
     // ---- O^T += V^T P^T.  P^T (B operand) comes straight from the S^T accumulator registers: MFMA k index
     // 8*half + j  <->  key 32t + 16u + 4*half + (j & 3) + 8*(j >> 2); the V^T fragment is gathered to match by two
     // transpose reads of 4 keys each (keys +0..3 and +8..11).
-#pragma unroll
-    for (int e = 0; e < NDT; ++e) {
+    const char* vbase = vs + vt_off;
+    ea_static_for<NDT>([&](auto e_tag) {
+      constexpr int e = decltype(e_tag)::value;
       f16x4 vlo[4], vhi[4];
-#pragma unroll
-      for (int tu = 0; tu < 4; ++tu) {
-        const char* base = vs + vt_off + (16 * tu) * VROW + 64 * e;
-        vlo[tu] = ea_lds_read_tr16(base);
-        vhi[tu] = ea_lds_read_tr16(base + 8 * VROW);
-      }
+      ea_static_for<4>([&](auto tu_tag) {
+        constexpr int tu = decltype(tu_tag)::value;
+        vlo[tu] = ea_lds_read_tr16<(16 * tu) * VROW + 64 * e>(vbase);
+        vhi[tu] = ea_lds_read_tr16<(16 * tu + 8) * VROW + 64 * e>(vbase);
+      });
       ea_lds_tr_wait();
 #pragma unroll
       for (int tu = 0; tu < 4; ++tu) {
@@ -325,7 +362,7 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnPar
         for (int j = 0; j < 4; ++j) { a[j] = vlo[tu][j]; a[4 + j] = vhi[tu][j]; }
         oacc[e] = ea_mfma_32x32x16(a, pb[tu >> 1][tu & 1], oacc[e]);
       }
-    }
+    });
 
     // ---- stage the next tile into the other buffer (last read during iteration kt - 1, i.e. before the barrier
     // every wave passed at the end of that iteration), then fetch the tile after it into the freed registers
@@ -334,7 +371,10 @@ __global__ __launch_bounds__(256, (D <= 80 ? 2 : 1)) void ea_attn_kernel(AttnPar
       if (kt + 2 < nkt) load_kv(kt + 2);
     }
     __syncthreads();
-  }
+  };
+  const int nfull = p.Nk / ATT_BK;   // tiles with no key mask
+  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+  if (nfull < nkt) tile(nfull, std::true_type{});
 
   // ---- normalise and store: lane holds O[q][32e + 8g + 4*half + 0..3]
   const float l_tot = l_run + ea_shfl_xor(l_run, 32);
