@@ -96,46 +96,72 @@ static bool fast_eligible(const EaGemmParams& p) {
 //        3: 256 x bn, 8 waves 4x2 (64x80), 3-stage                        4: 256 x bn, 4 waves 2x2 (128x80), 3-stage
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
-static int g_force_generic = 0, g_variant = 0;
+static int g_force_generic = 0, g_variant = 0, g_force_splits = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
   g_force_generic = (f && !strcmp(f, "generic")) ? 1 : 0;
   const char* v = getenv("EA_GEMM2_VARIANT");
   g_variant = (v && *v) ? atoi(v) : 0;
+  const char* sp = getenv("EA_GEMM2_SPLITS");   // tuning sweeps only: force the split-K factor
+  g_force_splits = (sp && *sp) ? atoi(sp) : 0;
 }
 
-// Cost model (microseconds) used to pick the tile height and the split-K factor: MFMA time of the busiest CU + the
-// fp32 partial round trip and the extra launch.  Constants are measured ballparks, only their ratios matter.
-static double plan_cost(int bm, int bn, int M, int N, int K, int batch, int s, int* kps_out, int* s_eff_out) {
+// Cost model (microseconds) that picks tile height (64 / 128 rows) and split-K factor.  Fitted to the forced
+// (variant, splits) sweep of tools/sweep_splits.py on MI355X (profiles/r01_sweep_splits.json):
+//  * a K-loop iteration of the 2-stage LDS-DMA pipeline is latency-bound, not MFMA-bound: ~0.7 us per 64-deep K tile
+//    for a workgroup alone on its CU whatever the tile height, ~1.2 us (128 rows) / ~0.8 us (64 rows) when two
+//    workgroups share the CU -- so two co-resident workgroups nearly double a CU's throughput, and 64-row tiles win
+//    whenever 128-row tiles would leave CUs with fewer than two workgroups;
+//  * fixed cost per launch (launch + prologue + epilogue): ~13 us for 128-row tiles, ~7 us for 64-row tiles;
+//  * split-K adds the reduce launch (~3 us) and (splits + 1) passes over the fp32 output at ~8 TB/s (MALL-resident).
+static double plan_cost(int bm, int bn, int M, int N, int K, int batch, int s, int conv, int* kps_out, int* s_eff_out) {
   const int nk = K / EA_BK;
   const double tiles = (double)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch;
   const int kps = (nk + s - 1) / s;
   const int s_eff = (nk + kps - 1) / kps;
-  const double t_kt = 0.42 * (bm / 128.0) * (bn / 160.0) * (bm == 256 ? 0.85 : 1.0);  // us per K tile per workgroup
-  const double per_cu = ceil(tiles * s_eff / 256.0);
-  double cost = per_cu * (kps * t_kt + 1.5);
-  if (s_eff > 1) cost += 4.0 + (double)M * N * batch * 4.0 * (2.0 * s_eff + 1.0) / 3.0e6;
+  const double wgs = tiles * s_eff;
+  const double shape = (bn == 160 ? 1.0 : 0.9) * (conv ? 1.07 : 1.0);
+  const double t1 = (bm == 64 ? 0.62 : (bm == 128 ? 0.72 : 1.1)) * shape;   // alone on the CU
+  const double t2 = (bm == 64 ? 0.72 : (bm == 128 ? 1.20 : 1.1)) * shape;   // two per CU (256-row tiles: one per CU)
+  const double slots = (bm == 256) ? 256.0 : 512.0;
+  double loop;
+  if (wgs <= 256.0) loop = kps * t1;
+  else if (wgs <= slots) loop = kps * (t1 + (t2 - t1) * (wgs - 256.0) / 256.0);
+  else loop = ceil(2.0 * wgs / slots) * 0.5 * kps * t2;
+  double cost = loop + (bm == 64 ? 7.0 : 13.0);
+  if (s_eff > 1) cost += 3.0 + 0.15 * s_eff + (double)M * N * batch * 4.0 * (s_eff + 1.0) / 8.0e6;
   *kps_out = kps;
   *s_eff_out = s_eff;
   return cost;
 }
 
-static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split) {
+static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv) {
   read_env();
   Plan2 t;
   t.bn = (N % 160 == 0) ? 160 : 128;
   const int nk = K / EA_BK;
   double best = 1e30;
-  t.bm = 128; t.splits = 1; t.ktiles_per_split = nk;
-  const int bm = (g_variant <= 2 || g_variant == 7) ? 128 : 256;   // tile height of the forced instantiation
+  t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
-  for (int s = 1; s <= smax; ++s) {
-    if (s > 1 && nk / s < 4) break;
-    int kps, s_eff;
-    const double c = plan_cost(bm, t.bn, M, N, K, batch, s, &kps, &s_eff);
-    if (c < best - 1e-9) { best = c; t.bm = bm; t.splits = s_eff; t.ktiles_per_split = kps; }
+  // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9) ? 64 : (g_variant <= 2 || g_variant == 7) ? 128 : 256;
+  const int cand_bm[2] = {128, 64};
+  for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
+    const int bm = forced_bm ? forced_bm : cand_bm[ci];
+    for (int s = 1; s <= smax; ++s) {
+      if (g_force_splits > 0 && s != g_force_splits && allow_split) continue;
+      if (s > 1 && nk / s < 4 && g_force_splits == 0) break;
+      // 64-row tiles re-read every weight tile twice as often: with deep split-K (few M tiles, weight-streaming
+      // bound) they lose to 128-row tiles in every measured case
+      if (bm == 64 && s > 2 && g_force_splits == 0) break;
+      int kps, s_eff;
+      const double c = plan_cost(bm, t.bn, M, N, K, batch, s, conv, &kps, &s_eff);
+      if (c < best - 1e-9) {
+        best = c; t.bm = bm; t.splits = s_eff; t.ktiles_per_split = kps;
+        t.kind = forced_bm ? g_variant : (bm == 64 ? 9 : 1);
+      }
+    }
   }
-  t.kind = (g_variant == 0) ? 1 : g_variant;
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
@@ -150,7 +176,7 @@ static int launch_reduce(EaGemmParams& p, void* stream) {
 }
 
 static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
-  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU);
+  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv);
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
@@ -183,6 +209,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 6: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 1); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 1); break;
     case 7: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 1); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 1); break;
     case 8: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32, 1); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32, 1); break;
+    case 9: if (t.bn == 160) EA_LAUNCH_G2(64, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(64, 128, 2, 2, 2, 16, 0); break;
     default: return EA_ERR_UNSUPPORTED;
   }
 #undef EA_LAUNCH_G2
@@ -234,8 +261,10 @@ extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
   TilePlan t = plan_tiles(M, N, K, batch, 1);
   int splits = t.splits;
   if (K % EA_BK == 0) {
-    Plan2 f = plan_fast(M, N, K, batch, 1);
-    if (f.splits > splits) splits = f.splits;
+    for (int conv = 0; conv < 2; ++conv) {
+      Plan2 f = plan_fast(M, N, K, batch, 1, conv);
+      if (f.splits > splits) splits = f.splits;
+    }
   }
   if (splits <= 1) return 0;
   return (size_t)batch * splits * M * N * sizeof(float);

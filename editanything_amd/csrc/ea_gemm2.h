@@ -485,6 +485,7 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
       }
     }
     ea_wave_lds_sync();
+    if (slab == 0) EA_STAMP(5);
     const int mrow0 = m0 + wm * WTM + slab * SLAB;
     if (!fast) {
       // launches that cannot use 16-byte vectors (ragged N, odd strides): one vector at a time through the
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
       }
     }
     ea_wave_lds_sync();  // slab reads retired before the next slab's scatter overwrites it
+    if (slab == 0) EA_STAMP(6);
   }
   EA_STAMP(4);
 }

@@ -108,7 +108,8 @@ def bench_conv(B, H, c1, c2, cout, stride=1, ups=0):
     s.Hout = s.Wout = ho
     e = epi(out, cout, bias)
     fn = lambda: lib.ea_conv2d_f16(C.byref(s), W.data_ptr(), cout, C.byref(e), WS.data_ptr(), WS.numel(), S())
-    assert fn() == 0
+    rc = fn()
+    assert rc == 0, f"ea_conv2d_f16 -> {rc}"
     report(f"conv3x3 B{B} H{H} c{c1}+{c2}->{cout} s{stride} ups{ups}", timeit(fn), flops=2.0 * B * ho * ho * cout * K)
 
 

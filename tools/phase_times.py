@@ -24,6 +24,10 @@ def run(name, launch, nblocks):
     print(f"{name}: blocks {nblocks}  start spread {rel[:,0].max():.1f}us  kernel span {rel[:,4].max():.1f}us")
     for i, lab in enumerate(["setup", "K loop", "barrier", "epilogue"]):
         print(f"   {lab:9s} mean {d[:,i].mean():7.2f}  min {d[:,i].min():7.2f}  max {d[:,i].max():7.2f} us")
+    # inside the epilogue (wave 0): 3 -> 5 first slab scattered to LDS, 5 -> 6 first slab gathered + stored, 6 -> 4 the rest
+    e = torch.stack([st[:, 5] - st[:, 3], st[:, 6] - st[:, 5], st[:, 4] - st[:, 6]], 1) / 100.0
+    for i, lab in enumerate(["scatter0", "store0", "rest"]):
+        print(f"      {lab:9s} mean {e[:,i].mean():7.2f}  min {e[:,i].min():7.2f}  max {e[:,i].max():7.2f} us")
 
 
 def gemm(M, N, K, act=0):
