@@ -96,7 +96,7 @@ def main():
         x = torch.nn.functional.interpolate(inp["images_u8"].permute(0, 3, 1, 2).float(), size=(1024, 1024), mode="bilinear",
                                             align_corners=False)
         x = (x - sam.mean) / sam.std
-        emb = sam.forward(x)
+        emb = sam.forward(x) if args.no_graph else sam.forward_graph(x)
         gen = torch.Generator("cpu").manual_seed(seed)
         out = pipe(prompt_embeds=inp["embeds"], negative_prompt_embeds=inp["neg"], image=init_image, mask_image=inp["mask"][0],
                    controlnet_conditioning_image=inp["control"], height=512, width=512, num_inference_steps=args.ddim_steps,

@@ -343,65 +343,85 @@ struct LnParams {
   float eps;
 };
 
-// One wave per row; two-pass in registers (mean, then centred variance), as torch does.
+// One wave per row, ROWS rows per wave in flight (all their loads are issued before the first reduction: the kernel
+// is latency-bound, not bandwidth-bound, at one row per wave); two-pass in registers (mean, then centred variance),
+// as torch does.  MAXV = 16-byte vectors per lane: C <= 512 * MAXV.
+template <int MAXV, int ROWS>
 __global__ __launch_bounds__(256) void ea_layernorm_kernel(LnParams p) {
-  constexpr int MAXV = 8;  // up to 8 octets per lane -> C <= 4096
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const bool active = row < p.M;
-  const int r = active ? row : 0;
+  const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * ROWS;
   const int nv = p.C / 8;
-  float vals[MAXV][8];
-  float sum = 0.0f;
+  float vals[ROWS][MAXV][8];
+  float sum[ROWS];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nv) {
-      if (p.in_f32) {
-        const float* src = (const float*)p.x + (long long)r * p.C + v * 8;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int row = row0 + rr;
+    const int r = row < p.M ? row : p.M - 1;
+    sum[rr] = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vals[i][j] = lo[j]; vals[i][4 + j] = hi[j]; }
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+        if (p.in_f32) {
+          const float* src = (const float*)p.x + (long long)r * p.C + v * 8;
+          f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { vals[rr][i][j] = lo[j]; vals[rr][i][4 + j] = hi[j]; }
+        } else {
+          f16x8 h = ea_ld8((const f16*)p.x + (long long)r * p.C + v * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vals[rr][i][j] = (float)h[j];
+        }
       } else {
-        f16x8 h = ea_ld8((const f16*)p.x + (long long)r * p.C + v * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) vals[i][j] = (float)h[j];
+        for (int j = 0; j < 8; ++j) vals[rr][i][j] = 0.0f;
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sum += vals[i][j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vals[i][j] = 0.0f;
     }
   }
-  sum = ea_wave_sum(sum);
-  const float mean = sum / (float)p.C;
-  float sq = 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum[rr] += vals[rr][i][j];
+    sum[rr] = ea_wave_sum(sum[rr]);
+  }
+  float mean[ROWS], rstd[ROWS];
+#pragma unroll
+  for (int rr = 0; rr < ROWS; ++rr) {
+    mean[rr] = sum[rr] / (float)p.C;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + 64 * i;
+      if (v < nv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = vals[rr][i][j] - mean[rr];
+          sq += d * d;
+        }
+      }
+    }
+    sq = ea_wave_sum(sq);
+    rstd[rr] = 1.0f / sqrtf(sq / (float)p.C + p.eps);
+  }
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     const int v = lane + 64 * i;
     if (v < nv) {
+      float ga[8], be[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = vals[i][j] - mean;
-        sq += d * d;
+      for (int j = 0; j < 8; ++j) { ga[j] = p.gamma[v * 8 + j]; be[j] = p.beta[v * 8 + j]; }
+#pragma unroll
+      for (int rr = 0; rr < ROWS; ++rr) {
+        const int row = row0 + rr;
+        if (row < p.M) {
+          f16x8 y;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) y[j] = (f16)((vals[rr][i][j] - mean[rr]) * rstd[rr] * ga[j] + be[j]);
+          ea_st8(p.out + (long long)row * p.C + v * 8, y);
+        }
       }
-    }
-  }
-  sq = ea_wave_sum(sq);
-  const float rstd = 1.0f / sqrtf(sq / (float)p.C + p.eps);
-  if (!active) return;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + 64 * i;
-    if (v < nv) {
-      f16x8 y;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = v * 8 + j;
-        y[j] = (f16)((vals[i][j] - mean) * rstd * p.gamma[c] + p.beta[c]);
-      }
-      ea_st8(p.out + (long long)row * p.C + v * 8, y);
     }
   }
 }
@@ -491,8 +511,16 @@ extern "C" int ea_layernorm_f16(const void* x, int in_f32, const float* gamma, c
   LnParams p;
   p.x = x; p.in_f32 = in_f32; p.gamma = gamma; p.beta = beta; p.out = (f16*)out;
   p.M = M; p.C = C; p.eps = eps;
-  auto kfn = ea_layernorm_kernel;
-  EA_LAUNCH(kfn, dim3((M + 3) / 4), dim3(256), 0, stream, p);
+  if (C <= 512) {
+    auto kfn = ea_layernorm_kernel<1, 4>;
+    EA_LAUNCH(kfn, dim3((M + 15) / 16), dim3(256), 0, stream, p);
+  } else if (C <= 1536) {
+    auto kfn = ea_layernorm_kernel<3, 2>;
+    EA_LAUNCH(kfn, dim3((M + 7) / 8), dim3(256), 0, stream, p);
+  } else {
+    auto kfn = ea_layernorm_kernel<8, 1>;
+    EA_LAUNCH(kfn, dim3((M + 3) / 4), dim3(256), 0, stream, p);
+  }
   return ea_launch_status();
 }
 

@@ -44,13 +44,30 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_aux = False   # True while ops are being issued on a side stream: they use the second workspace
+
+
 def workspace(device):
-    """One persistent fp32 scratch buffer per device (split-K partials, GroupNorm partial sums).
-    Allocated once, before any HIP-graph capture; ops on one stream use it serially."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """Persistent fp32 scratch per device (split-K partials, GroupNorm partial sums): one for the main stream and one
+    for a concurrent side stream (`aux_workspace`).  Allocated once, before any HIP-graph capture; ops on one stream
+    use theirs serially."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _aux)
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
     return _ws[key]
+
+
+class aux_workspace:
+    """Context manager for work issued on a second stream that overlaps the main stream: same ops, other scratch."""
+
+    def __enter__(self):
+        global _aux
+        self._prev, _aux = _aux, True
+
+    def __exit__(self, *exc):
+        global _aux
+        _aux = self._prev
 
 
 def _p(t):
@@ -135,6 +152,14 @@ def _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout):
     return s
 
 
+def _rows_per_group(rowvec, s):
+    """Rows (output pixels) sharing one row of `rowvec`: a sample's pixels, or the whole batch when the row vector has
+    a single row (one timestep for every sample)."""
+    if rowvec is not None and rowvec.shape[0] == 1:
+        return s.B * s.Hout * s.Wout
+    return s.Hout * s.Wout
+
+
 def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
            residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None):
     """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin)."""
@@ -144,7 +169,7 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
     if out is None:
         out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
     ws = workspace(x1.device)
-    e = _epilogue(out, cout, bias, act, scale, residual, rowvec, s.Hout * s.Wout, row_scale)
+    e = _epilogue(out, cout, bias, act, scale, residual, rowvec, _rows_per_group(rowvec, s), row_scale)
     ev = _prof_begin()
     st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
     _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1],
@@ -183,7 +208,7 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
     norm = torch.empty((s.B, s.Hin, s.Win, ctot), dtype=torch.float16, device=x1.device)
     out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
     ws = workspace(x1.device)
-    e = _epilogue(out, cout, bias, ACT_NONE, scale, residual, rowvec, s.Hout * s.Wout)
+    e = _epilogue(out, cout, bias, ACT_NONE, scale, residual, rowvec, _rows_per_group(rowvec, s))
     st = _lib().ea_groupnorm_silu_conv3x3(C.byref(s), _p(gamma), _p(beta), groups, eps, _p(norm), _p(w), cout, C.byref(e),
                                           _p(ws), ws.numel(), _stream())
     L.check(st, "ea_groupnorm_silu_conv3x3")

@@ -175,7 +175,7 @@ class StableDiffusionControlNetInpaintPipeline:
         x2 = torch.cat([lat] * 2) if st["cfg"] else lat
         if st["extra"] is not None:                               # 9-ch inpaint UNet: latents || mask || masked latents
             x2 = torch.cat([x2, st["extra"]], dim=1)
-        eps = self.denoiser.eps(x2, st["t"])
+        eps = self.denoiser.eps(x2, st["t"], embs=st.get("embs"))
         if st["cfg"]:
             e_u, e_c = eps.chunk(2)
         else:
@@ -295,10 +295,16 @@ class StableDiffusionControlNetInpaintPipeline:
                       extra=extra, noise=None, blend_mask=None, x_orig=x_orig,
                       noise_orig=noise0 if x_orig is not None else None)
             graph = None
+        # every step's time-embedding rows in one shot; step i copies row i into the static [1, sum(Cout)] buffers
+        emb_tables = self.denoiser.time_embeddings(torch.as_tensor(timesteps.astype(np.int64), device=self.device))
+        if st.get("embs") is None:
+            st["embs"] = [tb[:1].clone() for tb in emb_tables]
         self._mark("prepare(hint,text kv)")
         for i in range(nsteps):
             st["t"].fill_(int(timesteps[i]))
             st["coef"].copy_(coef_table[i])
+            for dst, tb in zip(st["embs"], emb_tables):
+                dst.copy_(tb[i:i + 1])
             st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
                 if step_noise else None
             blend_now = in_loop_blend and i < nsteps * alignment_ratio and i + 1 < nsteps

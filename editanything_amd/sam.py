@@ -89,6 +89,7 @@ class ImageEncoderViT:
         self.ln1 = (_f32(sd["neck.1.weight"], dev), _f32(sd["neck.1.bias"], dev))
         self.neck2 = pack_conv(sd["neck.2.weight"], dev)
         self.ln2 = (_f32(sd["neck.3.weight"], dev), _f32(sd["neck.3.bias"], dev))
+        self._graphs = {}
         self.mean = torch.tensor(PIXEL_MEAN, device=dev).view(1, 3, 1, 1)
         self.std = torch.tensor(PIXEL_STD, device=dev).view(1, 3, 1, 1)
 
@@ -120,6 +121,28 @@ class ImageEncoderViT:
         return ops.nhwc_to_nchw(n)
 
     __call__ = forward
+
+    def forward_graph(self, x):
+        """`forward` replayed from a HIP graph captured once per input shape (~450 launches per ViT-H pass otherwise;
+        the serving path: same result, no per-launch host cost, no inter-kernel gaps from the Python side)."""
+        key = tuple(x.shape)
+        ent = self._graphs.get(key)
+        if ent is None:
+            xs = x.to(self.device).clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.forward(xs)                      # warm-up outside capture (lazy allocations, workspace)
+            cur.wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.forward(xs)
+            ent = self._graphs[key] = (g, xs, out)
+        g, xs, out = ent
+        xs.copy_(x)
+        g.replay()
+        return out.clone()
 
     def encode_image(self, image_u8_hwc):
         return self.forward(self.preprocess(image_u8_hwc))

@@ -299,6 +299,15 @@ class ControlNet(_UNetBase):
         feats.append(self._run(self.middle_block, h, None, emb_all, kvs))
         return feats
 
+    def add_features(self, feats, skips, mid, scales):
+        """Zero-convs of precomputed `_features` accumulated into the UNet skips / middle tensor (see add_control)."""
+        targets = list(skips) + [mid]
+        for f, (w, b), tgt, s in zip(feats, self.zero, targets, scales):
+            if torch.is_tensor(s):
+                ops.conv2d(f, w, b, ksize=1, pad=0, row_scale=s, residual=tgt, out=tgt)
+            else:
+                ops.conv2d(f, w, b, ksize=1, pad=0, scale=float(s), residual=tgt, out=tgt)
+
     def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales):
         """Fused path: skips[i] += scales[i] * zero_conv_i(h_i); mid += scales[-1] * middle_block_out(h_mid)
         (cldm.py:300-303 + :338 + :34-41 in one epilogue per tensor).  `scales[i]` may be a float or a per-pixel
@@ -329,6 +338,8 @@ class ControlledDenoiser:
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
         self.only_mid_control = False
+        self.overlap = True       # ControlNet trunk(s) on a side stream, concurrent with the UNet encoder
+        self._side = None
 
     def static_state(self):
         """The per-call invariants a captured step reads (pipeline graph cache keeps them alive and refills them)."""
@@ -362,20 +373,53 @@ class ControlledDenoiser:
             control_scales = [list(control_scales) for _ in self.controlnets]
         self.control_scales = control_scales
 
-    def eps(self, x, timesteps):
-        """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32."""
+    def time_embeddings(self, timesteps):
+        """Per-network time-embedding projections (fp32 [len(timesteps), sum(Cout)]) for a vector of timesteps.  The
+        sampler's timesteps are known up front, so the pipeline computes ALL steps' rows in one call and feeds row i
+        to step i (`embs=`) instead of re-running five tiny GEMMs inside every step."""
+        return [self.unet.time_embedding(timesteps)] + [cn.time_embedding(timesteps) for cn in self.controlnets]
+
+    def eps(self, x, timesteps, embs=None):
+        """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32.  `embs`: optional precomputed
+        `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch)."""
         u = self.unet
-        emb_u = u.time_embedding(timesteps)
+        emb_u = u.time_embedding(timesteps) if embs is None else embs[0]
         xin = u.to_nhwc(x)
-        hs, mid = u.encode(xin, emb_u, self.kv_u)
-        for cn, kv, gh, sc in zip(self.controlnets, self.kv_c, self.hints, self.control_scales):
+        jobs = []
+        for i, (cn, kv, gh, sc) in enumerate(zip(self.controlnets, self.kv_c, self.hints, self.control_scales)):
             if gh is None:
                 continue
-            emb_c = cn.time_embedding(timesteps)
+            emb_c = cn.time_embedding(timesteps) if embs is None else embs[1 + i]
             x_cn = xin if cn.cfg["in_channels"] == u.cfg["in_channels"] else cn.to_nhwc(x[:, :cn.cfg["in_channels"]])
             if self.only_mid_control:
                 sc = [0.0] * (len(sc) - 1) + [sc[-1]]
-            cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc)
-        return u.decode(mid, hs, emb_u, self.kv_u)
+            jobs.append((cn, x_cn, emb_c, kv, gh, sc))
+        if not (self.overlap and jobs and ops.PROFILE is None):
+            hs, mid = u.encode(xin, emb_u, self.kv_u)
+            for cn, x_cn, emb_c, kv, gh, sc in jobs:
+                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc)
+            return u.decode(mid, hs, emb_u, self.kv_u)
+        # The ControlNet trunks and the UNet encoder are independent until the zero-convs: run the ControlNets on a
+        # side stream (forked / joined inside a HIP-graph capture just the same).  Most launches at the 16x16 and 8x8
+        # levels fill fewer than 256 CUs or are latency-bound, so the two branches pack into each other's gaps.
+        cur = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), ops.aux_workspace():
+            feats = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in jobs]
+        hs, mid = u.encode(xin, emb_u, self.kv_u)
+        cur.wait_stream(side)
+        for (cn, x_cn, emb_c, kv, gh, sc), f in zip(jobs, feats):
+            cn.add_features(f, hs, mid, sc)
+        out = u.decode(mid, hs, emb_u, self.kv_u)
+        del feats           # kept alive until here: side-stream tensors must not be recycled while the main stream reads them
+        return out
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            with ops.aux_workspace():
+                ops.workspace(self.unet.device)      # allocate the second workspace now, never inside a capture
+        return self._side
 
     apply_model = eps

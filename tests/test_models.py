@@ -165,6 +165,20 @@ def test_sd21_full_size_eval_vs_oracle():
     check(out, ref, l2=1e-2, mx=2e-2)
 
 
+def test_sam_encoder_graph_replay_equals_eager():
+    from editanything_amd.sam import ImageEncoderViT
+    d = g("sam_tiny_encoder.npz")
+    enc = ImageEncoderViT(arch.TINY_SAM, synth.synth_state_dict_torch(arch.sam_encoder_param_shapes(arch.TINY_SAM), SEED + 3), DEV)
+    with torch.no_grad():
+        x1 = enc.preprocess(d["image"])
+        x2 = enc.preprocess(np.roll(d["image"], 37, axis=1))
+        e1, e2 = enc.forward(x1), enc.forward(x2)
+        g1, g2 = enc.forward_graph(x1), enc.forward_graph(x2)
+    assert len(enc._graphs) == 1
+    assert torch.equal(e1, g1) and torch.equal(e2, g2)
+    assert not torch.equal(g1, g2)
+
+
 def test_sam_vit_b_full_size_vs_oracle():
     from editanything_amd.sam import ImageEncoderViT
     from oracle import sam_oracle
