@@ -1,0 +1,379 @@
+"""SAM prompt encoder + mask decoder + automatic mask generation on the MI355X.
+
+Call surface of the third-party objects the reference uses:
+  * `SamAutomaticMaskGenerator(sam).generate(image) -> list[dict]`   (sam2image.py:71,118; editany_lora.py:523)
+  * `SamPredictor(sam).set_image(image)` / `.predict(point_coords, point_labels, multimask_output)`
+    (editany_lora.py:527-543)
+with upstream's defaults (points_per_side 32, points_per_batch 64, pred_iou_thresh 0.88, stability_score_thresh 0.95,
+stability_score_offset 1.0, box_nms_thresh 0.7, crop_n_layers 0, min_mask_region_area 0, "binary_mask" output).
+Record order = NMS keep order (descending predicted_iou), which is the order `show_anns` indexes.
+
+Device work: the image encoder is `editanything_amd.sam.ImageEncoderViT`; in the decoder every contraction over the
+4096 image tokens of a point batch (k/v/q projections of the two-way transformer's image side, out-projection +
+residual, both transposed-conv upscalers as GEMMs with a fused GELU) runs through the C-ABI MFMA kernels (fp16
+operands, fp32 accumulate); LayerNorms through `ea_layernorm_f16`.  The 7-token side (self-attention, token MLPs,
+hypernetwork heads) and the mask post-processing (bilinear resizes, thresholds, stability score, boxes, NMS) are
+short torch-on-device expressions -- HBM-bound scans (section 8f item 1 lists fusing them as the next step).
+The encoder and decoder run fp16 where the reference runs fp32: masks agree with the fp32 oracle to a few pixels per
+mask on the `logits > 0` boundary (tests/test_amg.py states the tolerance); `show_anns` itself stays bit-exact.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+AMG_DEFAULTS = dict(points_per_side=32, points_per_batch=64, pred_iou_thresh=0.88, stability_score_thresh=0.95,
+                    stability_score_offset=1.0, box_nms_thresh=0.7, mask_threshold=0.0)
+
+
+def _f16(t, dev):
+    return t.to(device=dev, dtype=torch.float16).contiguous()
+
+
+def _f32(t, dev):
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
+class _Attn:
+    """segment_anything modeling/transformer.py Attention (q/k/v/out projections, `heads` heads over the internal dim)."""
+
+    def __init__(self, sd, p, dev, heads):
+        self.heads = heads
+        self.w = {n: _f16(sd[f"{p}{n}_proj.weight"], dev) for n in "qkv"}
+        self.b = {n: _f32(sd[f"{p}{n}_proj.bias"], dev) for n in "qkv"}
+        self.wo, self.bo = _f16(sd[p + "out_proj.weight"], dev), _f32(sd[p + "out_proj.bias"], dev)
+        self.internal = self.wo.shape[1]
+
+    def proj(self, n, x16):
+        return ops.gemm(x16, self.w[n], self.b[n])
+
+    def core(self, q, k, v):
+        """softmax(q k^T / sqrt(d)) v on already projected [B, N, internal] fp16 tensors (fp32 scores)."""
+        B, Nq, Ci = q.shape
+        h, d = self.heads, Ci // self.heads
+        sp = lambda t: t.reshape(B, t.shape[1], h, d).transpose(1, 2)
+        a = torch.matmul(sp(q).float(), sp(k).float().transpose(-2, -1)) * (1.0 / math.sqrt(d))
+        o = torch.matmul(torch.softmax(a, dim=-1), sp(v).float())
+        return o.transpose(1, 2).reshape(B, Nq, Ci).half()
+
+
+class SamPromptDecoder:
+    """PromptEncoder (points, no mask prompt) + MaskDecoder.  `state_dict`: a SAM checkpoint's `prompt_encoder.*` and
+    `mask_decoder.*` entries (editanything_amd.arch.sam_decoder_param_shapes)."""
+
+    def __init__(self, state_dict, device="cuda", heads=8, img_size=1024):
+        sd, dev = state_dict, torch.device(device)
+        self.device, self.img_size, self.heads = dev, img_size, heads
+        pe = "prompt_encoder."
+        self.gauss = _f32(sd[pe + "pe_layer.positional_encoding_gaussian_matrix"], dev)
+        self.point_emb = [_f32(sd[f"{pe}point_embeddings.{i}.weight"], dev) for i in range(4)]
+        self.not_a_point = _f32(sd[pe + "not_a_point_embed.weight"], dev)
+        self.no_mask = _f32(sd[pe + "no_mask_embed.weight"], dev)
+        md = "mask_decoder."
+        self.out_tokens = torch.cat([_f32(sd[md + "iou_token.weight"], dev), _f32(sd[md + "mask_tokens.weight"], dev)], 0)
+        self.C = self.out_tokens.shape[1]
+        t = md + "transformer."
+        self.layers = []
+        i = 0
+        while f"{t}layers.{i}.self_attn.q_proj.weight" in sd:
+            lp = f"{t}layers.{i}."
+            self.layers.append(dict(
+                self_attn=_Attn(sd, lp + "self_attn.", dev, heads), t2i=_Attn(sd, lp + "cross_attn_token_to_image.", dev, heads),
+                i2t=_Attn(sd, lp + "cross_attn_image_to_token.", dev, heads),
+                norms=[(_f32(sd[f"{lp}norm{k}.weight"], dev), _f32(sd[f"{lp}norm{k}.bias"], dev)) for k in (1, 2, 3, 4)],
+                w1=_f16(sd[lp + "mlp.lin1.weight"], dev), b1=_f32(sd[lp + "mlp.lin1.bias"], dev),
+                w2=_f16(sd[lp + "mlp.lin2.weight"], dev), b2=_f32(sd[lp + "mlp.lin2.bias"], dev)))
+            i += 1
+        self.final = _Attn(sd, t + "final_attn_token_to_image.", dev, heads)
+        self.norm_final = (_f32(sd[t + "norm_final_attn.weight"], dev), _f32(sd[t + "norm_final_attn.bias"], dev))
+        # ConvTranspose2d(k=2, s=2) == one GEMM per input pixel: N = (dy, dx, cout), K = cin
+        w0 = sd[md + "output_upscaling.0.weight"]                       # [cin, cout, 2, 2]
+        self.up0_w = _f16(w0.permute(2, 3, 1, 0).reshape(-1, w0.shape[0]), dev)
+        self.up0_b = _f32(sd[md + "output_upscaling.0.bias"].repeat(4), dev)
+        self.up_ln = (_f32(sd[md + "output_upscaling.1.weight"], dev), _f32(sd[md + "output_upscaling.1.bias"], dev))
+        w1 = sd[md + "output_upscaling.3.weight"]
+        self.up1_w = _f16(w1.permute(2, 3, 1, 0).reshape(-1, w1.shape[0]), dev)
+        self.up1_b = _f32(sd[md + "output_upscaling.3.bias"].repeat(4), dev)
+        self.c0, self.c1 = w0.shape[1], w1.shape[1]
+        mlp = lambda p: [(_f32(sd[f"{p}layers.{j}.weight"], dev), _f32(sd[f"{p}layers.{j}.bias"], dev)) for j in range(3)]
+        self.hyper = [mlp(f"{md}output_hypernetworks_mlps.{i}.") for i in range(self.out_tokens.shape[0] - 1)]
+        self.iou_head = mlp(md + "iou_prediction_head.")
+        self._pe_cache = {}
+
+    # ------------------------------------------------------------------ prompt encoder
+    def _pe(self, coords01):
+        c = (2.0 * coords01 - 1.0) @ self.gauss
+        c = 2.0 * math.pi * c
+        return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+
+    def dense_pe(self, size):
+        """PromptEncoder.get_dense_pe as image tokens: fp16 [h*w, C]."""
+        if size not in self._pe_cache:
+            h, w = size
+            y = (torch.arange(h, dtype=torch.float32, device=self.device) + 0.5) / h
+            x = (torch.arange(w, dtype=torch.float32, device=self.device) + 0.5) / w
+            grid = torch.stack([x[None, :].expand(h, w), y[:, None].expand(h, w)], dim=-1)
+            self._pe_cache[size] = self._pe(grid).reshape(h * w, -1).half().contiguous()
+        return self._pe_cache[size]
+
+    def embed_points(self, points, labels):
+        """points [B, N, 2] (x, y) in the 1024-frame, labels [B, N] -> sparse embeddings fp32 [B, N + 1, C]."""
+        B = points.shape[0]
+        pts = torch.cat([points.to(self.device).float() + 0.5, torch.zeros(B, 1, 2, device=self.device)], dim=1)
+        lab = torch.cat([labels.to(self.device).float(), -torch.ones(B, 1, device=self.device)], dim=1)[..., None]
+        emb = self._pe(pts / float(self.img_size))
+        emb = torch.where(lab == -1, torch.zeros_like(emb), emb)
+        return emb + (lab == -1) * self.not_a_point + (lab == 0) * self.point_emb[0] + (lab == 1) * self.point_emb[1]
+
+    # ------------------------------------------------------------------ mask decoder
+    @staticmethod
+    def _mlp3(layers, x):
+        for j, (w, b) in enumerate(layers):
+            x = F.linear(x, w, b)
+            if j < 2:
+                x = F.relu(x)
+        return x
+
+    def _ln(self, x, wb, eps=1e-5):
+        return F.layer_norm(x, (x.shape[-1],), wb[0], wb[1], eps)
+
+    def predict_masks(self, image_tokens, emb_hw, sparse, multimask_output=True):
+        """image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
+        -> low-res mask logits fp32 [B, 3|1, 4h, 4w], iou predictions fp32 [B, 3|1]."""
+        B, C = sparse.shape[0], self.C
+        h, w = emb_hw
+        T = h * w
+        key_pe = self.dense_pe(emb_hw)                                   # [T, C] fp16
+        point_emb = torch.cat([self.out_tokens[None].expand(B, -1, -1), sparse], dim=1)   # fp32 [B, 7, C]
+        queries = point_emb
+        keys = image_tokens[None].expand(B, -1, -1)                     # fp16 [B, T, C] (layer 0: shared by all points)
+        shared = True
+        for li, L in enumerate(self.layers):
+            a = L["self_attn"]
+            if li == 0:
+                q16 = queries.half()
+                queries = F.linear(a.core(a.proj("q", q16), a.proj("k", q16), a.proj("v", q16)).float(), a.wo.float(), a.bo)
+            else:
+                q16 = (queries + point_emb).half()
+                att = a.core(a.proj("q", q16), a.proj("k", q16), a.proj("v", queries.half()))
+                queries = queries + F.linear(att.float(), a.wo.float(), a.bo)
+            queries = self._ln(queries, L["norms"][0])
+            # tokens -> image.  In the first layer the image side is the same for every point: project it once.
+            a = L["t2i"]
+            src = keys[0] if shared else keys
+            kin = (src + key_pe).contiguous() if shared else (src + key_pe[None]).reshape(B * T, C)
+            k = a.proj("k", kin).reshape(1 if shared else B, T, -1)
+            v = a.proj("v", src.reshape(-1, C)).reshape(1 if shared else B, T, -1)
+            if shared:
+                k, v = k.expand(B, -1, -1), v.expand(B, -1, -1)
+            att = a.core(a.proj("q", (queries + point_emb).half()), k, v)
+            queries = self._ln(queries + F.linear(att.float(), a.wo.float(), a.bo), L["norms"][1])
+            m = F.linear(F.relu(F.linear(queries, L["w1"].float(), L["b1"])), L["w2"].float(), L["b2"])
+            queries = self._ln(queries + m, L["norms"][2])
+            # image -> tokens: the image side becomes per-point from here on
+            a = L["i2t"]
+            qt = (queries + point_emb).half()
+            qi = a.proj("q", kin).reshape(1 if shared else B, T, -1)
+            if shared:
+                qi = qi.expand(B, -1, -1)
+            att = a.core(qi, a.proj("k", qt), a.proj("v", queries.half()))       # [B, T, internal]
+            res = keys.reshape(B * T, C) if not shared else keys.contiguous().reshape(B * T, C)
+            keys = ops.gemm(att.reshape(B * T, -1), a.wo, a.bo, residual=res)
+            keys = ops.layernorm(keys, L["norms"][3][0], L["norms"][3][1], eps=1e-5).reshape(B, T, C)
+            shared = False
+        a = self.final
+        kin = (keys + key_pe[None]).reshape(B * T, C)
+        att = a.core(a.proj("q", (queries + point_emb).half()), a.proj("k", kin).reshape(B, T, -1),
+                     a.proj("v", keys.reshape(B * T, C)).reshape(B, T, -1))
+        queries = self._ln(queries + F.linear(att.float(), a.wo.float(), a.bo), self.norm_final)
+        iou_tok, mask_toks = queries[:, 0], queries[:, 1:1 + len(self.hyper)]
+        # upscaling: two stride-2 transposed convs == per-pixel GEMMs + pixel shuffle (NHWC)
+        u = ops.gemm(keys.reshape(B * T, C), self.up0_w, self.up0_b)                                  # [B*T, 4*c0]
+        u = u.reshape(B, h, w, 2, 2, self.c0).permute(0, 1, 3, 2, 4, 5).reshape(B * 4 * T, self.c0)
+        u = F.gelu(ops.layernorm(u, self.up_ln[0], self.up_ln[1], eps=1e-6).float()).half()
+        u = ops.gemm(u, self.up1_w, self.up1_b, act=ops.ACT_GELU)                                     # [B*4T, 4*c1]
+        u = u.reshape(B, 2 * h, 2 * w, 2, 2, self.c1).permute(0, 1, 3, 2, 4, 5).reshape(B, 16 * T, self.c1)
+        hyper = torch.stack([self._mlp3(self.hyper[i], mask_toks[:, i]) for i in range(len(self.hyper))], dim=1)
+        masks = torch.bmm(u.float(), hyper.transpose(1, 2)).transpose(1, 2).reshape(B, -1, 4 * h, 4 * w)
+        iou = self._mlp3(self.iou_head, iou_tok)
+        sl = slice(1, None) if multimask_output else slice(0, 1)
+        return masks[:, sl], iou[:, sl]
+
+    def image_tokens(self, embedding_nchw):
+        """Encoder output [1, C, h, w] -> decoder image tokens (embedding + no-mask dense prompt) fp16 [h*w, C]."""
+        e = embedding_nchw.to(self.device).float()
+        return (e[0].permute(1, 2, 0).reshape(-1, e.shape[1]) + self.no_mask).half().contiguous()
+
+
+# ---------------------------------------------------------------------- post-processing (utils/amg.py, on device)
+def preprocess_shape(oldh, oldw, long_side=1024):
+    scale = long_side * 1.0 / max(oldh, oldw)
+    return int(oldh * scale + 0.5), int(oldw * scale + 0.5)
+
+
+def build_point_grid(n):
+    off = 1.0 / (2 * n)
+    pts = np.linspace(off, 1 - off, n)
+    return np.stack([np.tile(pts[None, :], (n, 1)), np.tile(pts[:, None], (1, n))], axis=-1).reshape(-1, 2)
+
+
+def postprocess_masks(masks, input_size, original_size, img_size=1024):
+    masks = F.interpolate(masks, (img_size, img_size), mode="bilinear", align_corners=False)
+    masks = masks[..., :input_size[0], :input_size[1]]
+    return F.interpolate(masks, original_size, mode="bilinear", align_corners=False)
+
+
+def stability_score(masks, thr, off):
+    inter = (masks > (thr + off)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+    union = (masks > (thr - off)).sum(-1, dtype=torch.int16).sum(-1, dtype=torch.int32)
+    return inter / union
+
+
+def batched_mask_to_box(masks):
+    if masks.numel() == 0:
+        return torch.zeros(*masks.shape[:-2], 4, device=masks.device)
+    h, w = masks.shape[-2:]
+    dev = masks.device
+    in_h, _ = torch.max(masks, dim=-1)
+    hc = in_h * torch.arange(h, device=dev)[None, :]
+    bottom, _ = torch.max(hc, dim=-1)
+    top, _ = torch.min(hc + h * (~in_h), dim=-1)
+    in_w, _ = torch.max(masks, dim=-2)
+    wc = in_w * torch.arange(w, device=dev)[None, :]
+    right, _ = torch.max(wc, dim=-1)
+    left, _ = torch.min(wc + w * (~in_w), dim=-1)
+    empty = (right < left) | (bottom < top)
+    return torch.stack([left, top, right, bottom], dim=-1) * (~empty).unsqueeze(-1)
+
+
+def is_box_near_crop_edge(boxes, crop_box, orig_box, atol=20.0):
+    cb = torch.as_tensor(crop_box, dtype=torch.float, device=boxes.device)
+    ob = torch.as_tensor(orig_box, dtype=torch.float, device=boxes.device)
+    b = boxes.float()
+    near_crop = torch.isclose(b, cb[None, :], atol=atol, rtol=0)
+    near_img = torch.isclose(b, ob[None, :], atol=atol, rtol=0)
+    return torch.any(near_crop & ~near_img, dim=1)
+
+
+def nms(boxes, scores, thr):
+    """torchvision.ops.nms semantics; the IoU matrix is computed on the device, the greedy sweep over the (few hundred)
+    candidates on the host.  Returns kept indices in descending-score order."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.zeros(0, dtype=torch.long)
+    order = torch.argsort(scores, descending=True, stable=True)
+    b = boxes[order].float()
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(b[:, None, :2], b[None, :, :2])
+    rb = torch.min(b[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    over = ((inter / (area[:, None] + area[None, :] - inter)) > thr).cpu().numpy()
+    order = order.cpu().numpy()
+    alive = np.ones(n, dtype=bool)
+    keep = []
+    for i in range(n):
+        if not alive[i]:
+            continue
+        keep.append(int(order[i]))
+        alive &= ~over[i]
+        alive[i] = False
+    return torch.as_tensor(keep, dtype=torch.long)
+
+
+class SamAutomaticMaskGenerator:
+    """`SamAutomaticMaskGenerator(sam)` of the reference (sam2image.py:71): `encoder` is an
+    `editanything_amd.sam.ImageEncoderViT`, `decoder` a `SamPromptDecoder`; keyword arguments override upstream's
+    defaults under their upstream names."""
+
+    def __init__(self, encoder, decoder, **overrides):
+        self.encoder, self.decoder = encoder, decoder
+        self.cfg = dict(AMG_DEFAULTS)
+        unknown = set(overrides) - set(self.cfg)
+        if unknown:
+            raise TypeError(f"unsupported generator arguments: {sorted(unknown)}")
+        self.cfg.update(overrides)
+
+    def set_image(self, image_u8_hwc):
+        """SamPredictor.set_image: ResizeLongestSide(1024) -> normalise / pad -> encoder.  Returns decoder tokens."""
+        from . import host
+        img = np.asarray(image_u8_hwc)
+        H, W = img.shape[:2]
+        S = self.encoder.cfg["img_size"]
+        in_h, in_w = preprocess_shape(H, W, S)
+        resized = host.resize_longest_side(img, S) if (H, W) != (in_h, in_w) else img
+        emb = self.encoder.encode_image(resized)
+        self._state = dict(tokens=self.decoder.image_tokens(emb), emb_hw=tuple(emb.shape[-2:]), orig=(H, W), inp=(in_h, in_w))
+        return self._state
+
+    @torch.no_grad()
+    def generate(self, image, image_embedding=None):
+        c = self.cfg
+        dec, dev = self.decoder, self.decoder.device
+        S = self.encoder.cfg["img_size"] if self.encoder is not None else dec.img_size
+        if image_embedding is None:
+            st = self.set_image(image)
+        else:
+            H, W = np.asarray(image).shape[:2]
+            st = dict(tokens=dec.image_tokens(image_embedding), emb_hw=tuple(image_embedding.shape[-2:]), orig=(H, W),
+                      inp=preprocess_shape(H, W, S))
+        (H, W), (in_h, in_w) = st["orig"], st["inp"]
+        pts_all = build_point_grid(c["points_per_side"]) * np.array([[W, H]])
+        crop_box = [0, 0, W, H]
+        keep = dict(masks=[], iou=[], pts=[], stab=[], boxes=[])
+        scale = torch.tensor([in_w / W, in_h / H], device=dev)
+        for s in range(0, len(pts_all), c["points_per_batch"]):
+            p = torch.as_tensor(pts_all[s:s + c["points_per_batch"]], dtype=torch.float32, device=dev)
+            sparse = dec.embed_points((p * scale)[:, None, :], torch.ones(len(p), 1))
+            low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, True)
+            masks = postprocess_masks(low, (in_h, in_w), (H, W), S).flatten(0, 1)
+            iou = iou.flatten(0, 1)
+            pp = p.repeat_interleave(3, dim=0)
+            k = iou > c["pred_iou_thresh"]
+            masks, iou, pp = masks[k], iou[k], pp[k]
+            stab = stability_score(masks, c["mask_threshold"], c["stability_score_offset"])
+            k = stab >= c["stability_score_thresh"]
+            masks, iou, pp, stab = masks[k], iou[k], pp[k], stab[k]
+            mb = masks > c["mask_threshold"]
+            boxes = batched_mask_to_box(mb)
+            k = ~is_box_near_crop_edge(boxes, crop_box, [0, 0, W, H])
+            keep["masks"].append(mb[k]); keep["iou"].append(iou[k]); keep["pts"].append(pp[k])
+            keep["stab"].append(stab[k]); keep["boxes"].append(boxes[k])
+        masks = torch.cat(keep["masks"]); iou = torch.cat(keep["iou"]); ppts = torch.cat(keep["pts"])
+        stab = torch.cat(keep["stab"]); boxes = torch.cat(keep["boxes"])
+        order = nms(boxes, iou, c["box_nms_thresh"]).to(dev)
+        masks, iou, ppts, stab, boxes = masks[order], iou[order], ppts[order], stab[order], boxes[order]
+        areas = masks.flatten(1).sum(1).cpu().tolist()
+        m_np, iou_l, pts_l, stab_l, box_l = masks.cpu().numpy(), iou.cpu().tolist(), ppts.cpu().tolist(), stab.cpu().tolist(), boxes.cpu().tolist()
+        return [dict(segmentation=m_np[i], area=int(areas[i]), bbox=[box_l[i][0], box_l[i][1], box_l[i][2] - box_l[i][0],
+                                                                      box_l[i][3] - box_l[i][1]],
+                     predicted_iou=float(iou_l[i]), point_coords=[pts_l[i]], stability_score=float(stab_l[i]),
+                     crop_box=[0, 0, W, H]) for i in range(len(iou_l))]
+
+
+class SamPredictor:
+    """`SamPredictor(sam)` click prompts (editany_lora.py:527-543): set_image + predict(point_coords, point_labels)."""
+
+    def __init__(self, encoder, decoder):
+        self._gen = SamAutomaticMaskGenerator(encoder, decoder)
+        self.decoder = decoder
+
+    def set_image(self, image_u8_hwc):
+        self._st = self._gen.set_image(image_u8_hwc)
+
+    @torch.no_grad()
+    def predict(self, point_coords, point_labels, multimask_output=True, return_logits=False):
+        st, dec = self._st, self.decoder
+        (H, W), (in_h, in_w) = st["orig"], st["inp"]
+        p = torch.as_tensor(np.asarray(point_coords), dtype=torch.float32, device=dec.device)
+        p = p * torch.tensor([in_w / W, in_h / H], device=dec.device)
+        lab = torch.as_tensor(np.asarray(point_labels), dtype=torch.float32)
+        sparse = dec.embed_points(p[None], lab[None])
+        low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, multimask_output)
+        masks = postprocess_masks(low, (in_h, in_w), (H, W), dec.img_size)
+        if not return_logits:
+            masks = masks > 0.0
+        return masks[0].cpu().numpy(), iou[0].cpu().numpy(), low[0].cpu().numpy()

@@ -306,3 +306,62 @@ def sam_encoder_param_shapes(cfg):
     sd["neck.3.weight"] = (oc,)
     sd["neck.3.bias"] = (oc,)
     return sd
+
+
+SAM_DECODER = dict(embed_dim=256, heads=8, depth=2, mlp_dim=2048, downsample=2, num_mask_tokens=4, iou_hidden=256)
+
+
+def sam_decoder_param_shapes(cfg=SAM_DECODER):
+    """segment_anything PromptEncoder + MaskDecoder state dict (keys as in a SAM checkpoint: `prompt_encoder.*`,
+    `mask_decoder.*`; the mask-prompt branch `mask_downscaling` is not on the path -- AMG and the click predictor pass no
+    mask input -- and is omitted)."""
+    C, mlp, ds, nt = cfg["embed_dim"], cfg["mlp_dim"], cfg["downsample"], cfg["num_mask_tokens"]
+    sd = OrderedDict()
+    sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = (2, C // 2)
+    for i in range(4):
+        sd[f"prompt_encoder.point_embeddings.{i}.weight"] = (1, C)
+    sd["prompt_encoder.not_a_point_embed.weight"] = (1, C)
+    sd["prompt_encoder.no_mask_embed.weight"] = (1, C)
+    sd["mask_decoder.iou_token.weight"] = (1, C)
+    sd["mask_decoder.mask_tokens.weight"] = (nt, C)
+
+    def attn(p, internal):
+        for n in ("q_proj", "k_proj", "v_proj"):
+            sd[f"{p}{n}.weight"] = (internal, C)
+            sd[f"{p}{n}.bias"] = (internal,)
+        sd[p + "out_proj.weight"] = (C, internal)
+        sd[p + "out_proj.bias"] = (C,)
+
+    t = "mask_decoder.transformer."
+    for i in range(cfg["depth"]):
+        lp = f"{t}layers.{i}."
+        attn(lp + "self_attn.", C)
+        attn(lp + "cross_attn_token_to_image.", C // ds)
+        attn(lp + "cross_attn_image_to_token.", C // ds)
+        for k in (1, 2, 3, 4):
+            sd[f"{lp}norm{k}.weight"] = (C,)
+            sd[f"{lp}norm{k}.bias"] = (C,)
+        sd[lp + "mlp.lin1.weight"] = (mlp, C)
+        sd[lp + "mlp.lin1.bias"] = (mlp,)
+        sd[lp + "mlp.lin2.weight"] = (C, mlp)
+        sd[lp + "mlp.lin2.bias"] = (C,)
+    attn(t + "final_attn_token_to_image.", C // ds)
+    sd[t + "norm_final_attn.weight"] = (C,)
+    sd[t + "norm_final_attn.bias"] = (C,)
+    sd["mask_decoder.output_upscaling.0.weight"] = (C, C // 4, 2, 2)       # ConvTranspose2d: [in, out, k, k]
+    sd["mask_decoder.output_upscaling.0.bias"] = (C // 4,)
+    sd["mask_decoder.output_upscaling.1.weight"] = (C // 4,)
+    sd["mask_decoder.output_upscaling.1.bias"] = (C // 4,)
+    sd["mask_decoder.output_upscaling.3.weight"] = (C // 4, C // 8, 2, 2)
+    sd["mask_decoder.output_upscaling.3.bias"] = (C // 8,)
+    for i in range(nt):
+        p = f"mask_decoder.output_hypernetworks_mlps.{i}."
+        for j, (o, n) in enumerate(((C, C), (C, C), (C // 8, C))):
+            sd[f"{p}layers.{j}.weight"] = (o, n)
+            sd[f"{p}layers.{j}.bias"] = (o,)
+    p = "mask_decoder.iou_prediction_head."
+    ih = cfg["iou_hidden"]
+    for j, (o, n) in enumerate(((ih, C), (ih, ih), (nt, ih))):
+        sd[f"{p}layers.{j}.weight"] = (o, n)
+        sd[f"{p}layers.{j}.bias"] = (o,)
+    return sd

@@ -154,6 +154,10 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
       // 64-row tiles re-read every weight tile twice as often: with deep split-K (few M tiles, weight-streaming
       // bound) they lose to 128-row tiles in every measured case
       if (bm == 64 && s > 2 && g_force_splits == 0) break;
+      // ... and they only pay while every workgroup is resident at once (<= 2 per CU): with a second round the
+      // 128-row tiles' better weight reuse wins again (M32768 x K1280: 44 us vs 38 us)
+      if (bm == 64 && g_force_splits == 0 &&
+          (double)((M + 63) / 64) * ((N + t.bn - 1) / t.bn) * batch * s > 512.0) continue;
       int kps, s_eff;
       const double c = plan_cost(bm, t.bn, M, N, K, batch, s, conv, &kps, &s_eff);
       if (c < best - 1e-9) {

@@ -43,6 +43,14 @@ def resize_image(input_image, resolution):
     return np.asarray(im)
 
 
+def resize_longest_side(image_u8_hwc, long_side=1024):
+    """segment_anything ResizeLongestSide.apply_image: `resize(to_pil_image(image), (newh, neww))` -- PIL bilinear."""
+    h, w = image_u8_hwc.shape[:2]
+    scale = long_side * 1.0 / max(h, w)
+    newh, neww = int(h * scale + 0.5), int(w * scale + 0.5)
+    return np.asarray(Image.fromarray(np.ascontiguousarray(image_u8_hwc)).resize((neww, newh), Image.BILINEAR))
+
+
 def show_anns(anns, rng=None):
     """-> (PIL preview, float64 [H,W,3] id-map with ch0 = id % 256, ch1 = id // 256).  Keeps the reference quirk:
     ids follow the (unsorted) list order, later masks overwrite earlier ones."""

@@ -13,6 +13,7 @@ embedding is a GEMM over 16x16x3 patches with bias and the absolute position emb
 residual.  Window (un)partition with the zero padding 64->70 is pure index plumbing (pad tokens are not
 masked, exactly as upstream).
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -96,7 +97,7 @@ class ImageEncoderViT:
     def preprocess(self, image):
         """Sam.preprocess: uint8 HWC (or a [B,H,W,3] batch) whose long side == img_size -> normalised, zero-padded
         NCHW fp32 on the device.  (ResizeLongestSide is host-side pre-processing, editanything_amd.host.)"""
-        x = torch.as_tensor(image)
+        x = torch.as_tensor(np.ascontiguousarray(image))
         if x.ndim == 3:
             x = x[None]
         x = x.to(self.device).permute(0, 3, 1, 2).float()

@@ -7,9 +7,10 @@
     num_images_per_prompt, :169-171) of which only the first n are returned -- the first n outputs are identical
     because samples are independent and the seeded CPU noise stream is consumed in the same order;
   * BLIP2 auto-prompting is outside the hot path (`enable_auto_prompt` needs a user-supplied `captioner`);
-  * SAM: the ViT image encoder (the expensive part of `SamAutomaticMaskGenerator.generate`) runs on the HIP
-    kernels; the prompt-encoder / mask-decoder / AMG post-processing (segment_anything, absent here; SURVEY.md
-    section 8f item 1) is injected as `mask_generator` -- any object with `.generate(image, image_embedding=None)`.
+  * SAM: `mask_generator` is any object with `.generate(image, image_embedding=None)` -- normally
+    `editanything_amd.amg.SamAutomaticMaskGenerator(encoder, decoder)` (ViT encoder + prompt encoder + mask decoder +
+    AMG post-processing on the device, upstream defaults); `SyntheticMaskGenerator` stays as the weight-free stand-in
+    the benchmark uses for its control image.
 """
 from collections import OrderedDict
 
@@ -67,10 +68,7 @@ class Demo:
             S = self.sam_encoder.cfg["img_size"]
             im = image
             if max(im.shape[:2]) != S:          # ResizeLongestSide(S)
-                from PIL import Image
-                k = S / max(im.shape[:2])
-                im = np.asarray(Image.fromarray(im).resize((int(im.shape[1] * k + 0.5), int(im.shape[0] * k + 0.5)),
-                                                           Image.BILINEAR))
+                im = host.resize_longest_side(im, S)
             emb = self.sam_encoder.encode_image(im)
             self.last_embedding = emb
         try:

@@ -194,6 +194,41 @@ def gen_sam():
     np.savez_compressed(os.path.join(GOLD, "sam_tiny_encoder.npz"), image=img, embedding=ref.numpy())
 
 
+def gen_sam_decoder():
+    """Prompt encoder + mask decoder: golden from the independent port (transformers SamPromptEncoder/SamMaskDecoder),
+    full-size decoder (256-d, 8 heads, 2 layers) on a 16x16 embedding grid, 6 single-point prompts."""
+    from transformers import SamConfig
+    from transformers.models.sam.modeling_sam import SamMaskDecoder, SamPromptEncoder
+    from oracle import amg_oracle
+    sd = synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), SEED + 5)
+    cfg = SamConfig()
+    pe, md = SamPromptEncoder(cfg).eval(), SamMaskDecoder(cfg.mask_decoder_config).eval()
+    hf = amg_oracle.to_hf_state_dict(sd)
+    r1 = pe.load_state_dict({k[len("prompt_encoder."):]: v for k, v in hf.items() if k.startswith("prompt_encoder.")}, strict=False)
+    r2 = md.load_state_dict({k[len("mask_decoder."):]: v for k, v in hf.items() if k.startswith("mask_decoder.")}, strict=False)
+    assert all(k.startswith("mask_embed.") for k in r1.missing_keys) and not r1.unexpected_keys, r1
+    assert not r2.missing_keys and not r2.unexpected_keys, r2
+    g = 16
+    emb = rnd((1, 256, g, g), 501)
+    pts = torch.from_numpy(np.random.default_rng(502).uniform(0, 1024, size=(6, 1, 2)).astype(np.float32))
+    with torch.no_grad():
+        sp_hf, dense_hf = pe(pts[None], torch.ones(1, 6, 1), None, None)
+        grid = torch.ones((g, g))
+        y_e, x_e = (grid.cumsum(dim=0) - 0.5) / g, (grid.cumsum(dim=1) - 0.5) / g
+        pe_hf = pe.shared_embedding(torch.stack([x_e, y_e], dim=-1)).permute(2, 0, 1)[None]
+        dense_hf = pe.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(1, -1, g, g)
+        low_hf, iou_hf = md(image_embeddings=emb, image_positional_embeddings=pe_hf, sparse_prompt_embeddings=sp_hf,
+                            dense_prompt_embeddings=dense_hf, multimask_output=True)
+        sparse = amg_oracle.embed_points(sd, pts, torch.ones(6, 1))
+        close(sparse, sp_hf[0], 1e-6, "SAM prompt encoder (points) vs HF port")
+        close(amg_oracle.dense_pe(sd, (g, g)), pe_hf, 1e-6, "SAM dense positional encoding vs HF port")
+        low, iou = amg_oracle.mask_decoder(sd, emb, amg_oracle.dense_pe(sd, (g, g)), sparse, True)
+        close(low, low_hf[0], 2e-4, "SAM mask decoder low-res masks vs HF port")
+        close(iou, iou_hf[0], 2e-4, "SAM mask decoder iou predictions vs HF port")
+    np.savez_compressed(os.path.join(GOLD, "sam_decoder.npz"), embedding=emb.numpy(), points=pts.numpy(),
+                        low_res_masks=low_hf[0].numpy(), iou=iou_hf[0].numpy())
+
+
 def gen_host():
     show_anns = ref_import.extract_function("sam2image.py", "show_anns")
     rng = np.random.default_rng(401)
@@ -215,6 +250,7 @@ def gen_host():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     print("SAM ..."); gen_sam()          # before the import stubs (transformers probes for a real torchvision)
+    print("SAM prompt encoder + mask decoder ..."); gen_sam_decoder()
     ns = ref_import.load()
     print("LDM (ControlNet/UNet/DDIM) ..."); gen_ldm(ns)
     print("VAE ..."); gen_vae(ns)
