@@ -129,7 +129,6 @@ def main():
     for name, ev in marks:
         phases["sam_encode(+resize)" if name == "start" else name] = round(prev.elapsed_time(ev), 2)
         prev = ev
-    pipe.decode_latents = orig_decode
     assert torch.isfinite(out.images if hasattr(out, "images") else out).all()
 
     n_images = args.batch * args.steps * world
@@ -148,37 +147,48 @@ def main():
                    "weights_setup_s": round(t_weights, 1), "phase_ms": phases},
     }
     if rank == 0:
-        result["roofline"] = roofline_leg(pipe, inp, init_image, args)
+        result["roofline"] = roofline_leg(one_step, pipe, args)
         result["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sds, args)
         print(json.dumps(result), flush=True)
+    pipe.decode_latents = orig_decode
     eadist.barrier()
 
 
-def roofline_leg(pipe, inp, init_image, args):
-    """Per-launch timing of the dominant kernel (ea_gemm_kernel: implicit-GEMM conv / linear) with HIP events on the
-    launch stream, over one eager ControlNet+UNet evaluation at the benchmark's network batch; algorithmic FLOPs are
-    2*M*N*K of each launch (unpadded)."""
+def roofline_leg(one_step, pipe, args):
+    """Dominant kernel = the MFMA contraction (ea_gemm2_kernel / ea_gemm_kernel: implicit-GEMM conv3x3/1x1 + linear),
+    ~76 % of the GPU time of a step.  One whole step (SAM encode + VAE encode + 20 evaluations + VAE decode) is run
+    eagerly -- same launches, same order as the graph-replayed timed region, single stream -- with a HIP event pair on
+    the launch stream around EVERY contraction launch; `achieved` = sum of the launches' algorithmic FLOPs (2*M*N*K,
+    unpadded; conv: M = B*Hout*Wout, K = taps*Cin) / sum of their durations.  The rocprofv3 kernel-trace summary of
+    this command (profiles/) lists the same launches under the three ea_gemm2_kernel<...> / ea_gemm_kernel<...>
+    instantiations; there the ControlNet-branch launches overlap the UNet-encoder launches, which lengthens them
+    individually, so its per-launch average sits above `avg_launch_us`."""
     from editanything_amd import ops
-    B2 = 2 * args.batch
-    x = torch.randn(B2, 4, 64, 64, device=pipe.device)
-    ts = torch.full((B2,), 501, dtype=torch.long, device=pipe.device)
-    pipe.denoiser.eps(x, ts)                       # warm
-    torch.cuda.synchronize()
-    ops.PROFILE = []
-    pipe.denoiser.eps(x, ts)
-    torch.cuda.synchronize()
-    recs, ops.PROFILE = ops.PROFILE, None
-    recs = [r for r in recs if r[3].startswith(("gemm", "conv"))]     # the MFMA contraction launches only
-    tot_f = sum(r[0] for r in recs)
-    tot_t = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
-    n = len(recs)
+    use_graph, pipe.use_graph = pipe.use_graph, False
+    no_graph, args.no_graph = args.no_graph, True
+    try:
+        one_step(args.seed + 7000)                     # warm (eager path allocations)
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        one_step(args.seed + 7001)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+    finally:
+        ops.PROFILE = None
+        pipe.use_graph, args.no_graph = use_graph, no_graph
+    mm = [r for r in recs if r[3].startswith(("gemm", "conv"))]     # the MFMA contraction launches only
+    tot_f = sum(r[0] for r in mm)
+    tot_t = sum(r[1].elapsed_time(r[2]) for r in mm) * 1e-3
+    other_t = sum(r[1].elapsed_time(r[2]) for r in recs if not r[3].startswith(("gemm", "conv"))) * 1e-3
+    n = len(mm)
     achieved = tot_f / tot_t / 1e12
-    return {"bound": "mfma", "kernel": "ea_gemm_kernel (MFMA implicit-GEMM conv3x3/1x1 + linear)", "achieved": round(achieved, 1),
-            "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None,
-            "launches_per_eval": n, "avg_launch_us": round(tot_t / n * 1e6, 2),
-            "algorithmic_gflop_per_launch": round(tot_f / n / 1e9, 3)}
+    return {"bound": "mfma", "kernel": "ea_gemm2_kernel / ea_gemm_kernel (MFMA implicit-GEMM conv3x3/1x1 + linear)",
+            "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+            "avg_launch_us": round(tot_t / n * 1e6, 2), "algorithmic_gflop_per_launch": round(tot_f / n / 1e9, 3),
+            "contraction_ms_per_step": round(tot_t * 1e3, 2), "attention_norm_ms_per_step": round(other_t * 1e3, 2)}
 
 
 def cpu_baseline(sds, args):

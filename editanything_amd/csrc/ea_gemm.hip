@@ -144,7 +144,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9) ? 64 : (g_variant <= 2 || g_variant == 7) ? 128 : 256;
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10) ? 128 : 256;
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
@@ -165,6 +165,12 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
         t.kind = forced_bm ? g_variant : (bm == 64 ? 9 : 1);
       }
     }
+  }
+  // 64x64-level convolutions (M >= 16384 rows, N = 320: two column tiles, four rounds of 64-row tiles): the
+  // loader-wave instantiation measured 4..9 % ahead of the two-workgroup 128-row tiles (profiles/r01_bench_ops_v3_loader_waves.json).
+  if (g_variant == 0 && conv && t.kind == 1 && t.splits == 1 && t.bn == 160 && N <= 320 && (long long)M * batch >= 16384) {
+    t.kind = 11;
+    t.bm = 64;
   }
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
@@ -197,13 +203,14 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     p.partial = (float*)workspace;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
-#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_)                                   \
+#define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
   do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_, IL_>;                    \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_>;               \
     const int smem = ST_ * (BM_ + BN_) * 128;                                         \
     ea_allow_big_lds(kfn, smem);                                                      \
-    EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64, 1, 1), smem, stream, p);                \
+    EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64 * (1 + LD_), 1, 1), smem, stream, p);    \
   } while (0)
+#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
   switch (t.kind) {
     case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
     case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 0); break;
@@ -214,9 +221,13 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 7: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 1); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 1); break;
     case 8: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32, 1); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32, 1); break;
     case 9: if (t.bn == 160) EA_LAUNCH_G2(64, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(64, 128, 2, 2, 2, 16, 0); break;
+    case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
+    case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
+    case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
     default: return EA_ERR_UNSUPPORTED;
   }
 #undef EA_LAUNCH_G2
+#undef EA_LAUNCH_G2L
   int st = ea_launch_status();
   if (st != EA_OK) return st;
   if (t.splits > 1) st = launch_reduce(p, stream);

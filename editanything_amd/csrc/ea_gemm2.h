@@ -124,9 +124,18 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
   return (nwaves == 4 && stages * (bm + bn) * 128 <= 80 * 1024) ? 2 : 1;
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV>
-__global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))) void ea_gemm2_kernel(EaGemmParams p) {
-  constexpr int NW = WM * WN, NT = NW * 64;
+// LDR = 1: wave specialisation.  The workgroup carries NW extra "loader" waves (one beside each MFMA wave on its SIMD)
+// that do nothing but issue the LDS-DMA of the tiles ahead; the NW compute waves run a pure ds_read + MFMA stream.
+// A wave's own DMA burst (~60 clk per 1-KiB piece, 9 pieces per tile) otherwise sits in front of its MFMAs every
+// iteration -- for a workgroup alone on its CU the K-loop iteration is issue + compute (0.7 us) instead of
+// max(issue, compute).  One barrier per K tile, 3-deep ring: at barrier kt the loaders have waited for tile kt
+// (counted vmcnt, tile kt + 1 still in flight), the compute waves have retired their reads of tile kt - 1, whose buffer
+// the loaders refill with tile kt + 2 right after.
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0>
+__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
+void ea_gemm2_kernel(EaGemmParams p) {
+  constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR);
+  static_assert(!LDR || !ILV, "loader waves replace the interleaved issue");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
   static_assert(MT == 16 || MT == 32, "MFMA tile");
@@ -140,7 +149,9 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = ea_uniform(tid >> 6);
+  const int wave_all = ea_uniform(tid >> 6);
+  const bool is_loader = LDR && wave_all >= NW;
+  const int wave = is_loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
   const int wm = wave / WN, wn = wave % WN;
 
   EA_STAMP(0);
@@ -346,7 +357,21 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
   };
 
   EA_STAMP(1);
-  if (STAGES == 2) {
+  if (STAGES == 2 && LDR) {
+    // loader waves + 2-deep ring: the tile after the one being multiplied is in flight during exactly one compute
+    // phase, so a single workgroup is DMA-latency bound -- this instantiation is built for TWO 8-wave workgroups per CU
+    // (64-row tiles: <= 128 registers, 56 KiB of LDS), whose compute phases fill each other's waits.
+    if (is_loader && nk > 0) issue_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      if (is_loader) ea_wait_dma<0>();
+      ea_raw_barrier();
+      if (is_loader) {
+        if (kt + 1 < nk) issue_tile((kt + 1) & 1);
+      } else {
+        compute_tile(kt & 1);
+      }
+    }
+  } else if (STAGES == 2) {
     if (nk > 0) issue_tile(0);
 #ifndef EA_EMU
     // Two co-resident workgroups that start together run their DMA-issue and MFMA phases in lockstep (both contend
@@ -370,18 +395,28 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
     constexpr int A_EXTRA = A_INSTR % NW;
     static_assert(A_EXTRA == 0, "A rows must divide evenly over the waves");
     constexpr int PER_TILE_LO = A_PW + B_INSTR / NW;
-    if (nk > 0) issue_tile(0);
-    if (nk > 1) issue_tile(1);
+    if (!LDR || is_loader) {
+      if (nk > 0) issue_tile(0);
+      if (nk > 1) issue_tile(1);
+    }
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 1 < nk) {
-        if (B_EXTRA != 0 && wave < B_EXTRA) ea_wait_dma<PER_TILE_LO + 1>();
-        else ea_wait_dma<PER_TILE_LO>();
-      } else {
-        ea_wait_dma<0>();
+      if (!LDR || is_loader) {
+        if (kt + 1 < nk) {
+          if (B_EXTRA != 0 && wave < B_EXTRA) ea_wait_dma<PER_TILE_LO + 1>();
+          else ea_wait_dma<PER_TILE_LO>();
+        } else {
+          ea_wait_dma<0>();
+        }
       }
       ea_raw_barrier();
-      if (ILV) {
+      if (LDR) {
+        if (is_loader) {
+          if (kt + 2 < nk) issue_tile(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
+        } else {
+          compute_tile(cur);
+        }
+      } else if (ILV) {
         const bool more = kt + 2 < nk;
         if (more) begin_issue(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
         compute_tile(cur, more);
@@ -459,6 +494,7 @@ __global__ __launch_bounds__(WM* WN * 64, (ea_gemm2_occ(BM, BN, WM* WN, STAGES))
 
   EA_STAMP(2);
   __syncthreads();  // every wave is done reading the K-loop stages: the ring becomes slab memory
+  if (is_loader) return;   // no workgroup barrier follows: the epilogue is wave-local
   EA_STAMP(3);
 #pragma unroll 1
   for (int slab = 0; slab < NSLAB; ++slab) {
