@@ -44,7 +44,7 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_aux = False   # True while ops are being issued on a side stream: they use the second workspace
+_aux = 0        # workspace tag of the stream ops are currently being issued on (0 = the main stream)
 
 
 def workspace(device):
@@ -59,11 +59,15 @@ def workspace(device):
 
 
 class aux_workspace:
-    """Context manager for work issued on a second stream that overlaps the main stream: same ops, other scratch."""
+    """Context manager for work issued on another stream that overlaps the main stream: same ops, scratch number
+    `tag` (every concurrently running stream needs its own)."""
+
+    def __init__(self, tag=1):
+        self.tag = tag
 
     def __enter__(self):
         global _aux
-        self._prev, _aux = _aux, True
+        self._prev, _aux = _aux, self.tag
 
     def __exit__(self, *exc):
         global _aux

@@ -338,8 +338,13 @@ class ControlledDenoiser:
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
         self.only_mid_control = False
-        self.overlap = True       # ControlNet trunk(s) on a side stream, concurrent with the UNet encoder
-        self._side = None
+        self.overlap = True       # concurrent streams: batch row groups x (UNet encoder | ControlNet trunk)
+        self.cn_overlap = True
+        # row groups of one evaluation run as independent stream sets (2 = the uncond / cond halves of a CFG batch).
+        # Measured at C2 (network batch 8): 2 groups 357 ms vs 1 group 336 ms per 20 evaluations -- halving M costs the
+        # contraction kernels more than the extra overlap returns, so the default stays 1.
+        self.split = 1
+        self._strm = []
 
     def static_state(self):
         """The per-call invariants a captured step reads (pipeline graph cache keeps them alive and refills them)."""
@@ -381,45 +386,100 @@ class ControlledDenoiser:
 
     def eps(self, x, timesteps, embs=None):
         """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32.  `embs`: optional precomputed
-        `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch)."""
+        `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch).
+
+        Stream layout (`overlap`): the batch is cut into `split` contiguous row groups (the uncond / cond halves of a CFG
+        batch) that run as independent evaluations, and inside each the ControlNet trunk runs beside the UNet encoder:
+        phase 1 forks {UNet encoder, ControlNet trunk} x groups from the caller's stream and joins them, phase 2 forks
+        the groups' {zero-conv adds + UNet decoder}.  Samples never interact, so this is the same arithmetic; the point
+        is occupancy: most launches at the 32x32 level and below fill fewer than 256 CUs or sit in prologue / epilogue
+        latency, and independent launch sequences pack into each other's gaps.  Every branch forks from and joins the
+        caller's stream only (edges between two forked streams crash hipStreamEndCapture on ROCm 7.2), so the same
+        code runs eagerly and inside the HIP-graph capture of a step."""
+        B = x.shape[0]
+        per_row = embs is not None and any(e.shape[0] != 1 for e in embs)
+        concurrent = self.overlap and ops.PROFILE is None
+        split = self.split if (concurrent and not per_row and B % self.split == 0 and B >= 2 * self.split) else 1
+        n = B // split
         u = self.unet
-        emb_u = u.time_embedding(timesteps) if embs is None else embs[0]
-        xin = u.to_nhwc(x)
-        jobs = []
-        for i, (cn, kv, gh, sc) in enumerate(zip(self.controlnets, self.kv_c, self.hints, self.control_scales)):
-            if gh is None:
-                continue
-            emb_c = cn.time_embedding(timesteps) if embs is None else embs[1 + i]
-            x_cn = xin if cn.cfg["in_channels"] == u.cfg["in_channels"] else cn.to_nhwc(x[:, :cn.cfg["in_channels"]])
-            if self.only_mid_control:
-                sc = [0.0] * (len(sc) - 1) + [sc[-1]]
-            jobs.append((cn, x_cn, emb_c, kv, gh, sc))
-        if not (self.overlap and jobs and ops.PROFILE is None):
-            hs, mid = u.encode(xin, emb_u, self.kv_u)
-            for cn, x_cn, emb_c, kv, gh, sc in jobs:
+        ctx = []
+        for g in range(split):
+            rows = slice(g * n, (g + 1) * n)
+            xg, tg = x[rows], timesteps[rows]
+            c = dict(xin=u.to_nhwc(xg), emb_u=u.time_embedding(tg) if embs is None else embs[0],
+                     kv_u=[kv[rows] for kv in self.kv_u], jobs=[])
+            for i, (cn, kv, gh, sc) in enumerate(zip(self.controlnets, self.kv_c, self.hints, self.control_scales)):
+                if gh is None:
+                    continue
+                emb_c = cn.time_embedding(tg) if embs is None else embs[1 + i]
+                x_cn = c["xin"] if cn.cfg["in_channels"] == u.cfg["in_channels"] else cn.to_nhwc(xg[:, :cn.cfg["in_channels"]])
+                if self.only_mid_control:
+                    sc = [0.0] * (len(sc) - 1) + [sc[-1]]
+                per = [s.numel() // gh.shape[0] if torch.is_tensor(s) else 0 for s in sc]
+                sc = [s[rows.start * k:rows.stop * k] if torch.is_tensor(s) else s for s, k in zip(sc, per)]
+                c["jobs"].append((cn, x_cn, emb_c, [k[rows] for k in kv], gh[rows], sc))
+            ctx.append(c)
+        if not concurrent:
+            c = ctx[0]
+            hs, mid = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+            for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]:
                 cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc)
-            return u.decode(mid, hs, emb_u, self.kv_u)
-        # The ControlNet trunks and the UNet encoder are independent until the zero-convs: run the ControlNets on a
-        # side stream (forked / joined inside a HIP-graph capture just the same).  Most launches at the 16x16 and 8x8
-        # levels fill fewer than 256 CUs or are latency-bound, so the two branches pack into each other's gaps.
+            return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         cur = torch.cuda.current_stream()
-        side = self._side_stream()
-        side.wait_stream(cur)
-        with torch.cuda.stream(side), ops.aux_workspace():
-            feats = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in jobs]
-        hs, mid = u.encode(xin, emb_u, self.kv_u)
-        cur.wait_stream(side)
-        for (cn, x_cn, emb_c, kv, gh, sc), f in zip(jobs, feats):
-            cn.add_features(f, hs, mid, sc)
-        out = u.decode(mid, hs, emb_u, self.kv_u)
-        del feats           # kept alive until here: side-stream tensors must not be recycled while the main stream reads them
+        streams = self._streams(split)
+        # ---- phase 1: encoders and ControlNet trunks (group 0's encoder stays on the caller's stream)
+        for g, c in enumerate(ctx):
+            enc_s, cn_s = streams[g]
+            if c["jobs"] and self.cn_overlap:
+                cn_s.wait_stream(cur)
+                with torch.cuda.stream(cn_s), ops.aux_workspace(2 * g + 1):
+                    c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+            if g > 0:
+                enc_s.wait_stream(cur)
+                with torch.cuda.stream(enc_s), ops.aux_workspace(2 * g):
+                    c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+                    if c["jobs"] and not self.cn_overlap:
+                        c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+        c = ctx[0]
+        c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+        if c["jobs"] and not self.cn_overlap:
+            c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+        for g in range(split):
+            if g > 0:
+                cur.wait_stream(streams[g][0])
+            if ctx[g]["jobs"] and self.cn_overlap:
+                cur.wait_stream(streams[g][1])
+        # ---- phase 2: zero-conv adds into the skips + decoders
+        outs = [None] * split
+
+        def finish(c):
+            for (cn, x_cn, emb_c, kv, gh, sc), f in zip(c["jobs"], c.get("feats", [])):
+                cn.add_features(f, c["hs"], c["mid"], sc)
+            return u.decode(c["mid"], c["hs"], c["emb_u"], c["kv_u"])
+        for g in range(1, split):
+            streams[g][0].wait_stream(cur)
+            with torch.cuda.stream(streams[g][0]), ops.aux_workspace(2 * g):
+                outs[g] = finish(ctx[g])
+        outs[0] = finish(ctx[0])
+        for g in range(1, split):
+            cur.wait_stream(streams[g][0])
+        out = outs[0] if split == 1 else torch.cat(outs, 0)
+        del ctx             # branch-stream tensors stay alive until every consumer has been issued
         return out
 
-    def _side_stream(self):
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-            with ops.aux_workspace():
-                ops.workspace(self.unet.device)      # allocate the second workspace now, never inside a capture
-        return self._side
+    @staticmethod
+    def _nrows(t):
+        return t.shape[0]
+
+    def _streams(self, ngroups):
+        """[(group stream, its ControlNet side stream)] per row group; group 0 runs on the caller's stream.  Streams and
+        workspaces are created here, eagerly -- never inside a capture."""
+        while len(self._strm) < ngroups:
+            g = len(self._strm)
+            self._strm.append((torch.cuda.Stream() if g > 0 else None, torch.cuda.Stream()))
+            for tag in (2 * g, 2 * g + 1):
+                with ops.aux_workspace(tag):
+                    ops.workspace(self.unet.device)
+        return self._strm
 
     apply_model = eps
