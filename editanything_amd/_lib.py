@@ -57,6 +57,7 @@ SIGNATURES = {
     "ea_ln_gemm_f16": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, C.POINTER(Epilogue), _vp, _sz, _vp]),
     "ea_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f,
                               _vp, _vp, _i, _vp]),
+    "ea_sam_window_attn_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp, _vp, _vp]),
     "ea_relpos_tables_f16": (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _vp, _vp]),
     "ea_softmax_rows_f32_f16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ea_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),

@@ -89,6 +89,15 @@ __device__ __forceinline__ void ea_lds_tr_wait() {
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// LDS hand-off between the lanes of one wave (the LDS pipeline is in order per wave)
+__device__ __forceinline__ void ea_wave_lds_sync_() {
+#ifdef EA_EMU
+  ea_emu::wave_sync();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
 __device__ __forceinline__ float ea_exp2(float x) {
 #ifdef EA_EMU
   return exp2f(x);
@@ -126,7 +135,7 @@ __device__ __forceinline__ bool ea_wave_any(bool v) {
 // 2 the S == ATT_BK == 64 case (SAM global attention): a key tile is exactly one key row, so bias_h is ONE value per
 // query per tile and bias_w is the same 32 values per lane for every tile -> registers, no per-score memory access.
 template <int D, int BIAS>
-__global__ __launch_bounds__(256, (D <= 64 && BIAS == 0 ? 3 : (D <= 80 ? 2 : 1))) void ea_attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D <= 64 && BIAS == 0 ? 3 : (D <= 80 && BIAS != 1 ? 2 : 1))) void ea_attn_kernel(AttnParams p) {
   constexpr int DQK = (D + 15) / 16 * 16;  // QK^T contraction length (zero padded)
   constexpr int NKS = DQK / 16;
   constexpr int NDT = (D + 31) / 32;       // 32-wide tiles of the head dim for O^T
@@ -409,6 +418,262 @@ static int launch_attn(const AttnParams& p, void* stream) {
   return ea_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SAM windowed attention, one workgroup per (window, head): the whole window (N = S*S <= 256 tokens, 14x14 = 196 in
+// SAM) lives in LDS, so there is ONE global-load latency per workgroup instead of one per key tile, no barrier in the
+// key loop, and the decomposed relative-position bias is computed in the kernel (no bias tables through HBM):
+//   attn[q][k] = scale * q.k + q.Rh[qh - kh + S - 1] + q.Rw[qw - kw + S - 1]        (unscaled q in the bias terms)
+// 8 waves; wave w owns the 32 queries [32w, 32w + 32).  Per wave: T^T = R Q^T (two 32-row MFMA tiles: the 2S - 1 <= 31
+// relative offsets of each axis) is scattered into a private LDS table T[q][kh | kw]; then the flash loop of
+// ea_attn_kernel over 32-key tiles read straight from the resident K / V images.
+struct WinParams {
+  const f16* q; const f16* k; const f16* v; f16* o;
+  const f16* rel_h; const f16* rel_w;   // [2S - 1][D]
+  int nbh, H, S, N;
+  long long q_sb, q_sn, k_sb, k_sn, v_sb, v_sn, o_sb, o_sn;
+  float scale;
+};
+
+// The bias is folded into the score MFMA chain: bias[q][key] = T[q][kh(key)] + T[q][16 + kw(key)] = (E^T T^T)[key][q]
+// with E the one-hot selector of a key's (kh, kw) -- so every K row in LDS carries 32 extra one-hot fp16 columns and
+// the Q^T operand 32 extra rows (the wave's bias table T, pre-divided by the softmax scale), and
+// S^T = [K | E^T] [Q ; T]^T comes out of NKS + 2 MFMAs per 32-key tile with no per-score integer or LDS work.
+template <int D>
+__global__ __launch_bounds__(512, 2) void ea_attn_window_kernel(WinParams p) {
+  constexpr int DQK = (D + 15) / 16 * 16;
+  constexpr int NKS = DQK / 16;
+  constexpr int NDT = (D + 31) / 32;
+  constexpr int DV = NDT * 32;
+  constexpr int KROW = DQK * 2 + 64 + 16;    // K row: DQK channels | 32 one-hot bias selectors | pad (odd multiple of 16 B)
+  static_assert((KROW / 16) % 2 == 1, "K row stride must be an odd number of 16-byte slots");
+  constexpr int RROW = DQK * 2 + 16;         // rel-pos table rows
+  constexpr int VROW = ((DV * 2) % 256 == 64 || (DV * 2) % 256 == 192) ? DV * 2 : DV * 2 + 64;
+  constexpr int KCH = DQK / 8 + 4, VCH = DV / 8, RCH = DQK / 8;
+  constexpr int NPMAX = 256;                 // padded token count limit
+  constexpr int TLD = 33;                    // fp32 words per query row of the bias table: [kh 0..15 | kw 0..15] + pad
+  constexpr float LOG2E = 1.4426950408889634f;
+  EA_SMEM(smem);
+  const int NP = (p.N + 31) & ~31;
+  char* ks = smem;
+  char* vs = ks + NPMAX * KROW;
+  char* rs = vs + NPMAX * VROW;                                  // rel_h rows 0..31, rel_w rows 32..63
+  float* tb = reinterpret_cast<float*>(rs + 64 * RROW);          // [8 waves][32][TLD]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, h = bh % p.H;
+  const f16* qp = p.q + b * p.q_sb + (long long)h * D;
+  const f16* kp = p.k + b * p.k_sb + (long long)h * D;
+  const f16* vp = p.v + b * p.v_sb + (long long)h * D;
+  const int R = 2 * p.S - 1;
+
+  // ---- stage K (+ selectors), V (zero beyond N rows / D columns) and the two relative-position tables.  All global
+  // loads of a thread are issued before its first LDS store (fully unrolled): one memory latency per workgroup.
+  constexpr int KIT = (NPMAX * KCH + 511) / 512, VIT = (NPMAX * VCH + 511) / 512, RIT = (64 * RCH + 511) / 512;
+  f16x8 kb[KIT], vb[VIT], rb[RIT];
+#pragma unroll
+  for (int i = 0; i < KIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / KCH, cc = c - row * KCH;
+    f16x8 x = ea_zero8();
+    if (c < NP * KCH && row < p.N) {
+      if (cc < DQK / 8) {
+        if (cc * 8 < D) x = ea_ld8(kp + (long long)row * p.k_sn + cc * 8);
+      } else {
+        const int kh = row / p.S, kw = row - kh * p.S;
+        const int j0 = (cc - DQK / 8) * 8;        // selector columns j0 .. j0 + 7 of [kh 0..15 | kw 0..15]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (j0 + j == kh || j0 + j == 16 + kw) ? (f16)1.0f : (f16)0.0f;
+      }
+    }
+    kb[i] = x;
+  }
+#pragma unroll
+  for (int i = 0; i < VIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / VCH, d0 = (c - row * VCH) * 8;
+    vb[i] = (c < NP * VCH && row < p.N && d0 < D) ? ea_ld8(vp + (long long)row * p.v_sn + d0) : ea_zero8();
+  }
+#pragma unroll
+  for (int i = 0; i < RIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / RCH, d0 = (c - row * RCH) * 8;
+    const int rr = row & 31;
+    rb[i] = (c < 64 * RCH && rr < R && d0 < D) ? ea_ld8((row < 32 ? p.rel_h : p.rel_w) + (long long)rr * D + d0) : ea_zero8();
+  }
+
+  const int q_row = wave * 32 + l31;
+  const bool q_ok = q_row < p.N;
+  const int q_ld = q_ok ? q_row : p.N - 1;
+  f16x8 qf[NKS + 2];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const int d0 = 16 * s + 8 * half;
+    if (wave * 32 < p.N && d0 < D) qf[s] = ea_ld8(qp + (long long)q_ld * p.q_sn + d0);
+    else qf[s] = ea_zero8();
+  }
+#pragma unroll
+  for (int i = 0; i < KIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / KCH, cc = c - row * KCH;
+    if (c < NP * KCH) *reinterpret_cast<f16x8*>(ks + row * KROW + cc * 16) = kb[i];
+  }
+#pragma unroll
+  for (int i = 0; i < VIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / VCH, d0 = (c - row * VCH) * 8;
+    if (c < NP * VCH) *reinterpret_cast<f16x8*>(vs + row * VROW + d0 * 2) = vb[i];
+  }
+#pragma unroll
+  for (int i = 0; i < RIT; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / RCH, d0 = (c - row * RCH) * 8;
+    if (c < 64 * RCH) *reinterpret_cast<f16x8*>(rs + row * RROW + d0 * 2) = rb[i];
+  }
+  __syncthreads();
+  if (wave * 32 >= p.N) return;     // no workgroup barrier below
+
+  // ---- bias table of this wave's 32 queries: T[q][kh] = q.Rh[qh - kh + S - 1], T[q][16 + kw] likewise, stored
+  // divided by the softmax scale (the score accumulator is scaled as a whole afterwards); unused entries stay 0
+  float* tq = tb + (wave * 32 + l31) * TLD;
+  const float sc2 = p.scale * LOG2E;
+  const float tscale = 1.0f / p.scale;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) tq[16 * half + j] = 0.0f;
+  const int qh = q_ld / p.S, qw = q_ld - qh * p.S;
+#pragma unroll
+  for (int ax = 0; ax < 2; ++ax) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(rs + (32 * ax + l31) * RROW + (16 * s + 8 * half) * 2);
+      acc = ea_mfma_32x32x16(a, qf[s], acc);
+    }
+    const int qa = ax == 0 ? qh : qw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = ea_mfma_row(r, lane);          // relative offset index held in register r
+      const int kk = qa + p.S - 1 - rho;             // key coordinate this offset belongs to
+      if (kk >= 0 && kk < p.S) tq[16 * ax + kk] = acc[r] * tscale;
+    }
+  }
+  ea_wave_lds_sync_();
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[NKS + s2][j] = (f16)tq[16 * s2 + 8 * half + j];
+
+  f32x16 oacc[NDT];
+#pragma unroll
+  for (int e = 0; e < NDT; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[e][r] = 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f;
+  const int vt_off = (4 * half + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+  const int nkt = NP / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NKS + 2; ++s) {
+      const f16x8 a = *reinterpret_cast<const f16x8*>(ks + (32 * kt + l31) * KROW + (16 * s + 8 * half) * 2);
+      sacc = ea_mfma_32x32x16(a, qf[s], sacc);
+    }
+    float mx = -INFINITY;
+    if (32 * kt + 32 > p.N) {        // ragged last tile (wave-uniform branch): keys >= N are -inf
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = 32 * kt + ea_mfma_row(r, lane);
+        const float sv = key < p.N ? sacc[r] * sc2 : -INFINITY;
+        sacc[r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] *= sc2;
+        mx = fmaxf(mx, sacc[r]);
+      }
+    }
+    mx = fmaxf(mx, ea_shfl_xor(mx, 32));
+    if (ea_wave_any(mx > m_run + ATT_DEFER)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = (m_new == -INFINITY) ? 1.0f : ea_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int e = 0; e < NDT; ++e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[e][r] *= alpha;
+    }
+    const float m_use = (m_run == -INFINITY) ? 0.0f : m_run;
+    float psum = 0.0f;
+    f16x8 pb[2];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f16x2 pp;
+      pp[0] = (f16)ea_exp2(sacc[r] - m_use);
+      pp[1] = (f16)ea_exp2(sacc[r + 1] - m_use);
+      psum = ea_dot2_ones(pp, psum);
+      pb[r >> 3][r & 7] = pp[0];
+      pb[r >> 3][(r & 7) + 1] = pp[1];
+    }
+    l_run += psum;
+    const char* vbase = vs + (32 * kt) * VROW + vt_off;
+    ea_static_for<NDT>([&](auto e_tag) {
+      constexpr int e = decltype(e_tag)::value;
+      f16x4 vlo[2], vhi[2];
+      ea_static_for<2>([&](auto u_tag) {
+        constexpr int u = decltype(u_tag)::value;
+        vlo[u] = ea_lds_read_tr16<(16 * u) * VROW + 64 * e>(vbase);
+        vhi[u] = ea_lds_read_tr16<(16 * u + 8) * VROW + 64 * e>(vbase);
+      });
+      ea_lds_tr_wait();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        f16x8 a;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = vlo[u][j]; a[4 + j] = vhi[u][j]; }
+        oacc[e] = ea_mfma_32x32x16(a, pb[u], oacc[e]);
+      }
+    });
+  }
+  const float l_tot = l_run + ea_shfl_xor(l_run, 32);
+  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (q_ok) {
+    f16* op = p.o + b * p.o_sb + (long long)q_row * p.o_sn + (long long)h * D;
+#pragma unroll
+    for (int e = 0; e < NDT; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * e + 8 * g + 4 * half;
+        if (d0 < D) {
+          f16x4 o4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o4[j] = (f16)(oacc[e][4 * g + j] * inv);
+          *reinterpret_cast<f16x4*>(op + d0) = o4;
+        }
+      }
+  }
+}
+
+template <int D>
+static int launch_attn_window(const WinParams& p, void* stream) {
+  constexpr int DQK = (D + 15) / 16 * 16;
+  constexpr int DV = (D + 31) / 32 * 32;
+  constexpr int KROW = DQK * 2 + 64 + 16, RROW = DQK * 2 + 16;
+  constexpr int VROW = ((DV * 2) % 256 == 64 || (DV * 2) % 256 == 192) ? DV * 2 : DV * 2 + 64;
+  const int smem = 256 * KROW + 256 * VROW + 64 * RROW + 8 * 32 * 33 * 4;
+  auto kfn = ea_attn_window_kernel<D>;
+  ea_allow_big_lds(kfn, smem);
+  EA_LAUNCH(kfn, dim3(p.nbh), dim3(512), smem, stream, p);
+  return ea_launch_status();
+}
+
 // rel-pos tables: one thread per (bh, q, k<2S): dot over D channels.
 struct RelposParams {
   const f16* q; int B, H, S, D;
@@ -504,4 +769,28 @@ extern "C" int ea_relpos_tables_f16(const void* q, int B, int H, int S, int D, l
   auto kfn = ea_relpos_kernel;
   EA_LAUNCH(kfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
   return ea_launch_status();
+}
+
+extern "C" int ea_sam_window_attn_f16(const void* q, const void* k, const void* v, void* out, int nWin, int heads, int S,
+                                      int D, long long q_sb, long long q_sn, long long k_sb, long long k_sn,
+                                      long long v_sb, long long v_sn, long long o_sb, long long o_sn, float scale,
+                                      const void* rel_h, const void* rel_w, void* stream) {
+  if (!q || !k || !v || !out || !rel_h || !rel_w) return EA_ERR_BAD_ARG;
+  if (nWin <= 0 || heads <= 0 || S <= 0 || S > 16) return EA_ERR_BAD_SHAPE;
+  if ((q_sn & 7) || (k_sn & 7) || (v_sn & 7) || (o_sn & 3) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (o_sb & 3))
+    return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 7) ||
+      ((uintptr_t)rel_h & 15) || ((uintptr_t)rel_w & 15))
+    return EA_ERR_BAD_ARG;
+  WinParams p;
+  p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.o = (f16*)out;
+  p.rel_h = (const f16*)rel_h; p.rel_w = (const f16*)rel_w;
+  p.nbh = nWin * heads; p.H = heads; p.S = S; p.N = S * S;
+  p.q_sb = q_sb; p.q_sn = q_sn; p.k_sb = k_sb; p.k_sn = k_sn; p.v_sb = v_sb; p.v_sn = v_sn; p.o_sb = o_sb; p.o_sn = o_sn;
+  p.scale = scale;
+  switch (D) {
+    case 64: return launch_attn_window<64>(p, stream);
+    case 80: return launch_attn_window<80>(p, stream);
+    default: return EA_ERR_UNSUPPORTED;
+  }
 }

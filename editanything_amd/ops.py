@@ -270,6 +270,25 @@ def attention(q, k, v, heads, dim_head, scale=None, bias_h=None, bias_w=None, S=
     return out
 
 
+def sam_window_attention(q, k, v, heads, dim_head, S, rel_h, rel_w, scale=None, out=None):
+    """SAM windowed attention with the decomposed rel-pos bias fused (one workgroup per (window, head)).  q/k/v:
+    [nWin, S*S, >= heads*dim_head] fp16 views (slices of the fused QKV buffer); rel_h/rel_w fp16 [2S-1, dim_head]."""
+    _check_dev(q, k, v, rel_h)
+    nW, N = q.shape[0], q.shape[1]
+    if N != S * S or k.shape[1] != N:
+        raise ValueError("sam_window_attention: tokens per window must be S*S")
+    if out is None:
+        out = torch.empty((nW, N, heads * dim_head), dtype=torch.float16, device=q.device)
+    scale = dim_head ** -0.5 if scale is None else scale
+    ev = _prof_begin()
+    st = _lib().ea_sam_window_attn_f16(_p(q), _p(k), _p(v), _p(out), nW, heads, S, dim_head, q.stride(0), q.stride(1),
+                                       k.stride(0), k.stride(1), v.stride(0), v.stride(1), out.stride(0), out.stride(1),
+                                       float(scale), _p(rel_h), _p(rel_w), _stream())
+    _prof_end(ev, 0.0, f"attn-window W{nW} H{heads} S{S} D{dim_head}")
+    L.check(st, f"ea_sam_window_attn_f16 W{nW} H{heads} S{S} D{dim_head}")
+    return out
+
+
 def relpos_tables(q, heads, dim_head, S, rel_h, rel_w):
     B = q.shape[0]
     bh = torch.empty((B * heads, S * S, S), dtype=torch.float32, device=q.device)

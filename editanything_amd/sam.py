@@ -61,8 +61,11 @@ class _Block:
             xn = xn.view(B, H * W, D)
         qkv = ops.gemm(xn, self.wqkv, self.bqkv)                                      # [Bw, N, 3*D] = [3, heads, d]
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
-        bh, bw = ops.relpos_tables(q, self.heads, self.d, self.S, self.rel_h, self.rel_w)
-        a = ops.attention(q, k, v, self.heads, self.d, bias_h=bh, bias_w=bw, S=self.S)
+        if ws > 0 and ws <= 16 and self.d in (64, 80):
+            a = ops.sam_window_attention(q, k, v, self.heads, self.d, self.S, self.rel_h, self.rel_w)
+        else:
+            bh, bw = ops.relpos_tables(q, self.heads, self.d, self.S, self.rel_h, self.rel_w)
+            a = ops.attention(q, k, v, self.heads, self.d, bias_h=bh, bias_w=bw, S=self.S)
         if ws > 0:
             pr = ops.gemm(a, self.wproj, self.bproj)
             pr = pr.view(B, Hp // ws, Wp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, D)

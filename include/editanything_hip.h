@@ -9,6 +9,7 @@
  *                                :163-194, cldm/hack.py:72-111; SAM Attention.forward
  *                                (segment_anything, 3rd party) with decomposed rel-pos
  *   ea_relpos_tables_f16      <- segment_anything add_decomposed_rel_pos (3rd party)
+ *   ea_sam_window_attn_f16    <- segment_anything Block.forward's windowed Attention (3rd party), bias fused
  *   ea_groupnorm_f16          <- GroupNorm32 + SiLU, ldm/modules/diffusionmodules/util.py:217-219,
  *                                openaimodel.py:200-204,221-224; attention.py:88-89; model.py:46-47
  *   ea_conv2d_f16             <- conv_nd 3x3/1x1 in ResBlock / Upsample / Downsample
@@ -127,6 +128,15 @@ int ea_attention_f16(const void* q, const void* k, const void* v, void* out, int
                      int D, long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb,
                      long long v_sn, long long o_sb, long long o_sn, float scale, const float* bias_h,
                      const float* bias_w, int S, void* stream);
+
+/* SAM windowed attention with the decomposed rel-pos bias computed in-kernel (segment_anything Attention.forward +
+ * add_decomposed_rel_pos over one window_partition()ed batch): one workgroup per (window, head), the whole S*S-token
+ * window resident in LDS.  q/k/v element (w, i, h, d) at ptr + w*s_b + i*s_n + h*D + d; rel_h/rel_w fp16 [2S-1][D]
+ * (16-byte aligned, already resized to 2S-1 rows); S <= 16; D in {64, 80}.  out [nWin][S*S][heads*D] fp16. */
+int ea_sam_window_attn_f16(const void* q, const void* k, const void* v, void* out, int nWin, int heads, int S, int D,
+                           long long q_sb, long long q_sn, long long k_sb, long long k_sn, long long v_sb,
+                           long long v_sn, long long o_sb, long long o_sn, float scale, const void* rel_h,
+                           const void* rel_w, void* stream);
 
 /* SAM decomposed rel-pos tables: bias_h[bh][q][kh] = sum_c q[bh,q,c]*Rh[qh - kh + S - 1][c] (same for w),
  * q strided like ea_attention_f16, rel_h/rel_w fp16 [2S-1][D], tokens q = qh*S + qw. */

@@ -399,6 +399,29 @@ def test_sam_window_attention_relpos(kb, S, D):
     assert relerr(kb.down(out), attn_ref(q, k, v, scale, bias).numpy()) < 3e-3
 
 
+@pytest.mark.parametrize("S,D,B,H", [(14, 80, 2, 2), (14, 64, 1, 3), (7, 64, 3, 1)])
+def test_sam_window_attention_fused(kb, S, D, B, H):
+    """ea_sam_window_attn_f16: whole window in LDS, rel-pos bias computed in-kernel from rel_h / rel_w; q/k/v are
+    slices of one fused QKV buffer (as sam.py passes them).  Reference = (q*scale)k^T + rel_h[...,None] + rel_w[...,None,:]."""
+    N = S * S
+    qkv = f16(B, N, 3, H, D)
+    rel_h, rel_w = f16(2 * S - 1, D, scale=0.3), f16(2 * S - 1, D, scale=0.3)
+    out = kb.zeros((B, N, H, D), np.float16)
+    sb, sn = N * 3 * H * D, 3 * H * D
+    base = ptr(qkv)
+    scale = D ** -0.5
+    st = kb.lib.ea_sam_window_attn_f16(base, base + H * D * 2, base + 2 * H * D * 2, ptr(out), B, H, S, D, sb, sn, sb, sn, sb, sn,
+                                       N * H * D, H * D, scale, ptr(rel_h), ptr(rel_w), kb.stream)
+    assert st == 0
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    idx = (torch.arange(S)[:, None] - torch.arange(S)[None, :]) + (S - 1)
+    rq = t(q).permute(0, 2, 1, 3).reshape(B * H, S, S, D)
+    ref_h = torch.einsum("bhwc,hkc->bhwk", rq, t(rel_h)[idx]).reshape(B * H, N, S)
+    ref_w = torch.einsum("bhwc,wkc->bhwk", rq, t(rel_w)[idx]).reshape(B * H, N, S)
+    bias = (ref_h[:, :, :, None] + ref_w[:, :, None, :]).reshape(B, H, N, N)
+    assert relerr(kb.down(out), attn_ref(q, k, v, scale, bias).numpy()) < 3e-3
+
+
 def test_sam_global_attention_bias_rows(kb):
     """S == 64 path (bias_w in registers, one bias_h value per key tile): 128 query rows against the full 64x64 key
     grid, bias tables given directly (random), ragged last query block."""

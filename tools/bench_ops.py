@@ -129,6 +129,19 @@ def bench_attn(B, H, N, Nk, D, S_=0):
     report(f"attn B{B} H{H} N{N} Nk{Nk} D{D} S{S_}", timeit(fn), flops=4.0 * B * H * N * Nk * D)
 
 
+def bench_attn_window(nW, H, S_, D):
+    N = S_ * S_
+    qkv = torch.randn(nW, N, 3, H, D, device=dev).half()
+    rh, rw = (torch.randn(2 * S_ - 1, D, device=dev) * 0.3).half(), (torch.randn(2 * S_ - 1, D, device=dev) * 0.3).half()
+    out = torch.empty(nW, N, H, D, device=dev, dtype=torch.half)
+    sb, sn = N * 3 * H * D, 3 * H * D
+    b0 = qkv.data_ptr()
+    fn = lambda: lib.ea_sam_window_attn_f16(b0, b0 + H * D * 2, b0 + 2 * H * D * 2, out.data_ptr(), nW, H, S_, D, sb, sn, sb, sn,
+                                            sb, sn, N * H * D, H * D, D ** -0.5, rh.data_ptr(), rw.data_ptr(), S())
+    assert fn() == 0
+    report(f"attn-window fused W{nW} H{H} S{S_} D{D}", timeit(fn), flops=4.0 * nW * H * N * N * D)
+
+
 def bench_gn(B, HW, Cc):
     x = torch.randn(B, HW, Cc, device=dev).half()
     g, b = torch.randn(Cc, device=dev), torch.randn(Cc, device=dev)
@@ -209,6 +222,8 @@ if __name__ == "__main__":
     bench_attn(B, 20, 256, 256, 64)
     bench_attn(B, 5, 4096, 77, 64)
     bench_attn(25, 16, 196, 196, 80, S_=14)
+    bench_attn_window(25, 16, 14, 80)
+    bench_attn_window(100, 16, 14, 80)
     bench_attn(1, 16, 4096, 4096, 80, S_=64)
     bench_attn(1, 16, 4096, 4096, 80)
     # HBM-bound
