@@ -68,6 +68,7 @@ struct EaGemmParams {
   int splits;
   int ktiles_per_split;
   int debug;       // bench-only ablation (EA_GEMM2_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
+  int epi_fast;    // host-checked: the launch qualifies for ea_gemm2's streamlined epilogue (see launch_fast)
   float* partial;  // [batch*splits][M][N] fp32 when splits > 1
   EaEpilogue epi;
 };

@@ -202,6 +202,19 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     if (!workspace || ws_bytes < (size_t)t.tiles * p.batch * 64) return EA_ERR_WORKSPACE;
     p.partial = (float*)workspace;
   }
+  // streamlined epilogue (ea_gemm2.h): every per-output option it does not implement must be off, offsets must fit
+  // 32 bits, rows of a workgroup tile must share one row-vector group
+  {
+    const EaEpilogue& e = p.epi;
+    const long long span = (long long)p.M * e.ldc + e.N;
+    bool ok = t.splits == 1 && !e.out_f32 && !e.residual32 && !e.row_scale && !e.bias_per_row && e.act != EA_ACT_GEGLU &&
+              (e.N & 7) == 0 && (e.ldc & 7) == 0 && (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 &&
+              span < 0x7fffffffLL && p.debug != 9;
+    if (ok && e.residual)
+      ok = (e.ldr & 7) == 0 && (((uintptr_t)e.residual) & 15) == 0 && (p.strideR & 7) == 0 && (long long)p.M * e.ldr < 0x7fffffffLL;
+    if (ok && e.rowvec) ok = p.batch == 1 && e.rows_per_group > 0 && (e.rows_per_group % t.bm) == 0;
+    p.epi_fast = ok ? 1 : 0;
+  }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
   do {                                                                                \

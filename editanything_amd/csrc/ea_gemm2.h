@@ -496,6 +496,87 @@ void ea_gemm2_kernel(EaGemmParams p) {
   __syncthreads();  // every wave is done reading the K-loop stages: the ring becomes slab memory
   if (is_loader) return;   // no workgroup barrier follows: the epilogue is wave-local
   EA_STAMP(3);
+  // ---- streamlined epilogue for the common launch (fp16 out, optional fp16 residual, bias / per-sample row vector /
+  // SiLU / GELU / scalar scale, everything 16-byte aligned, no split-K; checked on the host -> p.epi_fast).  The general
+  // path below evaluates every option per output vector behind wave-uniform branches and waits on each vector's LDS
+  // reads in turn (measured ~3 us per 32-row slab per wave, as much as a 5-tile K loop).  Here the per-COLUMN terms
+  // (bias + row vector) and the activation are applied while the accumulators are scattered to the LDS slab, and the
+  // gather side is a fully unrolled {all LDS reads + all residual loads} -> {add, convert, 16-byte store} sequence.
+  if (MT == 16 && p.epi_fast) {
+    constexpr int SLABF = 16;   // rows per slab: 3 output vectors per lane in flight (32 rows spill the 128x160 kernel)
+    constexpr int NSLABF = WTM / SLABF;
+    constexpr int SLDF = WTN + 4;
+    constexpr int VPR = WTN / 8;                            // 16-byte output vectors per row
+    constexpr int NV = (SLABF * VPR + 63) / 64;             // vectors per lane per slab
+    static_assert(NW * SLABF * SLDF * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    float* wst = reinterpret_cast<float*>(smem) + wave * (SLABF * SLDF);
+    const int colbase = n0 + wn * WTN;
+    const float* rvp = e.rowvec ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
+    float cb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = colbase + j * 16 + frow;
+      cb[j] = 0.0f;
+      if (col < e.N) cb[j] = (e.bias ? e.bias[col] : 0.0f) + (rvp ? rvp[col] : 0.0f);
+    }
+    const long long cb0 = (long long)batch * p.strideC, rb0 = (long long)batch * p.strideR;
+    f16* outp = (f16*)e.out + cb0;
+    const f16* resp = e.residual ? e.residual + rb0 : nullptr;
+    // fully unrolled over the slabs: with a runtime slab index the compiler hoists the (slab-invariant) bias /
+    // activation arithmetic of ALL accumulators out of the loop and spills
+#pragma unroll
+    for (int slab = 0; slab < NSLABF; ++slab) {
+      constexpr int TPS = SLABF / 16;
+#pragma unroll
+      for (int ii = 0; ii < (MT == 16 ? MI : 1); ++ii) {
+        if (ii / TPS != slab) continue;
+        const int il = ii % TPS;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[MT == 16 ? ii : 0][MT == 16 ? j : 0][r] + cb[j];
+            if (e.act == EA_ACT_SILU) x = ea_silu(x);
+            else if (e.act == EA_ACT_GELU) x = ea_gelu_erf(x);
+            wst[(il * 16 + fq * 4 + r) * SLDF + j * 16 + frow] = x * e.scale;
+          }
+      }
+      ea_wave_lds_sync();
+      const int mrow0 = m0 + wm * WTM + slab * SLABF;
+      f32x4 lo[NV], hi[NV];
+      f16x8 rr[NV];
+      int off[NV];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int id = lane + 64 * v;
+        const int row = id / VPR, c = id - row * VPR;
+        const int m = mrow0 + row, n = colbase + c * 8;
+        const bool ok = id < SLABF * VPR && m < p.M && n < e.N;
+        off[v] = ok ? m * e.ldc + n : -1;
+        const float* sp = wst + (ok ? row * SLDF + c * 8 : 0);
+        lo[v] = *reinterpret_cast<const f32x4*>(sp);
+        hi[v] = *reinterpret_cast<const f32x4*>(sp + 4);
+        if (resp && ok) rr[v] = ea_ld8(resp + (long long)m * e.ldr + n);
+      }
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (off[v] < 0) continue;
+        f16x8 h;
+        if (resp) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { h[j] = (f16)(lo[v][j] + (float)rr[v][j]); h[4 + j] = (f16)(hi[v][j] + (float)rr[v][4 + j]); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { h[j] = (f16)lo[v][j]; h[4 + j] = (f16)hi[v][j]; }
+        }
+        ea_st8(outp + off[v], h);
+      }
+      ea_wave_lds_sync();
+    }
+    EA_STAMP(4);
+    return;
+  }
+
 #pragma unroll 1
   for (int slab = 0; slab < NSLAB; ++slab) {
     // ---- scatter this slab's accumulators (MFMA C layout) into the wave's LDS slab

@@ -237,6 +237,33 @@ def test_gemm_rowvec_rowscale_bias_per_row(kb):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("variant", [0, 1, 9, 11])
+@pytest.mark.parametrize("act,res", [(0, False), (1, True), (2, True)])
+def test_gemm_streamlined_epilogue(kb, variant, act, res, monkeypatch):
+    """The common-launch epilogue of ea_gemm2 (bias + per-sample row vector + activation applied in the accumulator
+    layout, scalar scale, fp16 residual; ragged M edge; the last column tile partly outside N) against the same formula,
+    and against the general epilogue of the same kernel (EA_GEMM2_DEBUG=9 disables the streamlined one)."""
+    if variant:
+        monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    M, N, K, hw = 3 * 256 - 40, 200, 128, 256
+    A, W = f16(M, K), f16(N, K, scale=0.1)
+    bias, rowvec = f32(N), f32(3, N)
+    R = f16(M, N) if res else None
+    ws = workspace(kb, 0)
+    outs = []
+    for dbg in ("0", "9"):
+        monkeypatch.setenv("EA_GEMM2_DEBUG", dbg)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias, act=act, rowvec=rowvec, rows_per_group=hw, scale=0.75, residual=R)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).astype(np.float32))
+    ref = t(A) @ t(W).T + t(bias) + t(rowvec).repeat_interleave(hw, 0)[:M]
+    ref = F.silu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    ref = ref * 0.75 + (t(R) if res else 0)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+    assert relerr(outs[0], outs[1]) < 1e-3
+
+
 def test_gemm_rejects_bad_args(kb):
     out = kb.zeros((8, 8), np.float16)
     e = epilogue(out)

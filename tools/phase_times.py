@@ -46,7 +46,6 @@ def gemm(M, N, K, act=0):
 
 if __name__ == "__main__":
     bo.set_variant("1")
-    gemm(32768, 320, 320)
-    gemm(32768, 320, 1280)
-    gemm(32768, 2560, 320, act=3)
-    gemm(8192, 640, 640)
+    for a in (sys.argv[1:] or ["32768,320,320", "32768,320,1280", "32768,2560,320,3", "8192,640,640"]):
+        v = [int(x) for x in a.split(",")]
+        gemm(v[0], v[1], v[2], act=v[3] if len(v) > 3 else 0)
