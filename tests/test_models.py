@@ -213,3 +213,58 @@ def test_graph_cache_reuse_across_calls(tiny):
     for og, oe in calls:
         check(og, oe, l2=1e-3, mx=3e-3)
     assert rel_l2(calls[0][0], calls[2][0]) > 1e-2, "calls with different inputs must differ"
+
+
+def _idmap_hint(rng, B, res):
+    ids = rng.integers(0, 300, size=(B, res // 32, res // 32)).repeat(32, 1).repeat(32, 2)
+    hint = np.zeros((B, 3, res, res), np.float32)
+    hint[:, 0], hint[:, 1] = ids % 256, ids // 256
+    return t(hint)
+
+
+def test_config4_sd15_two_controlnets_768_vs_oracle():
+    """BASELINE config 4 shape: SD1.5 (context 768, 8 heads -> head dims 40/80/160, 1x1-conv proj_in/out), 96x96
+    latents (768^2), TWO ControlNets (SAM id map + inpaint condition) whose residuals are summed with per-net scales
+    (MultiControlNetModel, utils/stable_diffusion_controlnet_inpaint.py:437-438), one evaluation, batch 1."""
+    from editanything_amd.unet import ControlledDenoiser, ControlledUnetModel, ControlNet
+    from oracle import ldm_oracle
+    un_sd = synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_UNET), 31)
+    c1_sd = synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_CONTROLNET, True), 32)
+    c2_sd = synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_CONTROLNET, True), 33)
+    rng = np.random.default_rng(9)
+    x = t(rng.standard_normal((1, 4, 96, 96)).astype(np.float32))
+    h1 = _idmap_hint(rng, 1, 768)
+    h2 = t(rng.uniform(-1, 1, size=(1, 3, 768, 768)).astype(np.float32))      # inpaint condition: image/255 with -1 holes
+    ctx = t(rng.standard_normal((1, 77, 768)).astype(np.float32))
+    ts = torch.tensor([521])
+    s1, s2 = 1.0, 0.6
+    with torch.no_grad():
+        k1 = ldm_oracle.controlnet_forward(c1_sd, arch.SD15_CONTROLNET, x, h1, ts, ctx)
+        k2 = ldm_oracle.controlnet_forward(c2_sd, arch.SD15_CONTROLNET, x, h2, ts, ctx)
+        ref = ldm_oracle.controlled_unet_forward(un_sd, arch.SD15_UNET, x, ts, ctx, [a * s1 + b * s2 for a, b in zip(k1, k2)])
+        den = ControlledDenoiser(ControlledUnetModel(arch.SD15_UNET, un_sd, DEV),
+                                 [ControlNet(arch.SD15_CONTROLNET, c1_sd, DEV), ControlNet(arch.SD15_CONTROLNET, c2_sd, DEV)])
+        n = len(k1)
+        den.prepare(ctx.to(DEV), [h1.to(DEV), h2.to(DEV)], [[s1] * n, [s2] * n])
+        out = den.eps(x.to(DEV), ts.to(DEV))
+    check(out, ref, l2=1e-2, mx=2e-2)
+
+
+def test_config5_sd21_1024_latent128_vs_oracle():
+    """BASELINE config 5 shape: the SD2.1 UNet + ControlNet at 128x128 latents (1024^2; 16384-token self-attention at
+    level 0 -- the LDS / tile stress shape), one evaluation, batch 1."""
+    from editanything_amd.unet import ControlledDenoiser, ControlledUnetModel, ControlNet
+    from oracle import ldm_oracle
+    cn_sd = synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_CONTROLNET, True), 41)
+    un_sd = synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_UNET), 42)
+    rng = np.random.default_rng(10)
+    x = t(rng.standard_normal((1, 4, 128, 128)).astype(np.float32))
+    hint = _idmap_hint(rng, 1, 1024)
+    ctx = t(rng.standard_normal((1, 77, 1024)).astype(np.float32))
+    ts = torch.tensor([441])
+    with torch.no_grad():
+        ref = ldm_oracle.apply_model(un_sd, arch.SD21_UNET, cn_sd, arch.SD21_CONTROLNET, x, ts, ctx, hint)
+        den = ControlledDenoiser(ControlledUnetModel(arch.SD21_UNET, un_sd, DEV), [ControlNet(arch.SD21_CONTROLNET, cn_sd, DEV)])
+        den.prepare(ctx.to(DEV), [hint.to(DEV)])
+        out = den.eps(x.to(DEV), ts.to(DEV))
+    check(out, ref, l2=1e-2, mx=2e-2)
