@@ -54,6 +54,8 @@ SIGNATURES = {
     "ea_groupnorm_silu_conv3x3": (_i, [C.POINTER(ConvSrc), _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(Epilogue),
                                        _vp, _sz, _vp]),
     "ea_layernorm_f16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "ea_layernorm_rows_f16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "ea_gather_add_rows_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "ea_ln_gemm_f16": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, C.POINTER(Epilogue), _vp, _sz, _vp]),
     "ea_attention_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f,
                               _vp, _vp, _i, _vp]),

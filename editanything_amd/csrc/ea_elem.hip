@@ -160,6 +160,32 @@ extern "C" int ea_add_f16(const void* a, const void* b, void* out, long long n, 
   return ea_launch_status();
 }
 
+// x[t][:] += src[rows[t]][:]  (fp32 residual stream += gathered fp16 rows): SAM window_unpartition + residual add
+__global__ __launch_bounds__(256) void ea_gather_add_rows_kernel(float* x, const f16* src, const int* rows, int T, int C8) {
+  const long long total = (long long)T * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / C8), c = (int)(i - (long long)t * C8) * 8;
+    const int r = rows[t];
+    if (r < 0) continue;
+    const f16x8 s8 = ea_ld8(src + (long long)r * C8 * 8 + c);
+    float* xp = x + (long long)t * C8 * 8 + c;
+    f32x4 lo = *reinterpret_cast<f32x4*>(xp), hi = *reinterpret_cast<f32x4*>(xp + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo[j] += (float)s8[j]; hi[j] += (float)s8[4 + j]; }
+    *reinterpret_cast<f32x4*>(xp) = lo;
+    *reinterpret_cast<f32x4*>(xp + 4) = hi;
+  }
+}
+
+extern "C" int ea_gather_add_rows_f32(float* x, const void* src, const int* rows, int T, int C, void* stream) {
+  if (!x || !src || !rows) return EA_ERR_BAD_ARG;
+  if (T <= 0 || C <= 0 || (C & 7)) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)src & 15)) return EA_ERR_BAD_ARG;
+  auto kfn = ea_gather_add_rows_kernel;
+  EA_LAUNCH(kfn, dim3(grid_for((long long)T * (C / 8))), dim3(256), 0, stream, x, (const f16*)src, rows, T, C / 8);
+  return ea_launch_status();
+}
+
 // ---- fused entry points (several launches on the caller's stream, one call) ----
 extern "C" int ea_groupnorm_silu_conv3x3(const ea_conv_src* src, const float* gamma, const float* beta, int groups,
                                          float eps, void* norm_out, const void* W, int Cout, const ea_epilogue* epi,

@@ -341,6 +341,7 @@ struct LnParams {
   f16* out;
   int M, C;
   float eps;
+  const int* out_rows;   // optional: output row of input row m (negative = drop the row); NULL = identity
 };
 
 // One wave per row, ROWS rows per wave in flight (all their loads are issued before the first reduction: the kernel
@@ -416,10 +417,12 @@ __global__ __launch_bounds__(256) void ea_layernorm_kernel(LnParams p) {
       for (int rr = 0; rr < ROWS; ++rr) {
         const int row = row0 + rr;
         if (row < p.M) {
+          const int orow = p.out_rows ? p.out_rows[row] : row;
+          if (orow < 0) continue;
           f16x8 y;
 #pragma unroll
           for (int j = 0; j < 8; ++j) y[j] = (f16)((vals[rr][i][j] - mean[rr]) * rstd[rr] * ga[j] + be[j]);
-          ea_st8(p.out + (long long)row * p.C + v * 8, y);
+          ea_st8(p.out + (long long)orow * p.C + v * 8, y);
         }
       }
     }
@@ -505,12 +508,17 @@ extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, 
 
 extern "C" int ea_layernorm_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
                                 int M, int C, float eps, void* stream) {
+  return ea_layernorm_rows_f16(x, in_f32, gamma, beta, out, M, C, eps, nullptr, stream);
+}
+
+extern "C" int ea_layernorm_rows_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
+                                     int M, int C, float eps, const int* out_rows, void* stream) {
   if (!x || !gamma || !beta || !out) return EA_ERR_BAD_ARG;
   if (M <= 0 || C <= 0 || (C & 7) || C > 4096) return EA_ERR_BAD_SHAPE;
   if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return EA_ERR_BAD_ARG;
   LnParams p;
   p.x = x; p.in_f32 = in_f32; p.gamma = gamma; p.beta = beta; p.out = (f16*)out;
-  p.M = M; p.C = C; p.eps = eps;
+  p.M = M; p.C = C; p.eps = eps; p.out_rows = out_rows;
   if (C <= 512) {
     auto kfn = ea_layernorm_kernel<1, 4>;
     EA_LAUNCH(kfn, dim3((M + 15) / 16), dim3(256), 0, stream, p);

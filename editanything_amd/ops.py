@@ -231,6 +231,31 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
+def layernorm_rows(x, gamma, beta, out, rows, eps=1e-5):
+    """LayerNorm whose row m lands in row rows[m] (int32, device) of the pre-allocated fp16 `out` [R, C]."""
+    _check_dev(x, gamma, out, rows)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    ev = _prof_begin()
+    st = _lib().ea_layernorm_rows_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), _p(out), M, Cc, eps, _p(rows),
+                                      _stream())
+    _prof_end(ev, 0.0, f"layernorm-rows M{M} C{Cc}")
+    L.check(st, "ea_layernorm_rows_f16")
+    return out
+
+
+def gather_add_rows(x32, src16, rows):
+    """x32[t] += src16[rows[t]] in place (fp32 [T, C] residual stream, fp16 source rows, int32 map on the device)."""
+    _check_dev(x32, src16, rows)
+    Cc = x32.shape[-1]
+    T = x32.numel() // Cc
+    ev = _prof_begin()
+    st = _lib().ea_gather_add_rows_f32(_p(x32), _p(src16), _p(rows), T, Cc, _stream())
+    _prof_end(ev, 0.0, f"gather-add-rows T{T} C{Cc}")
+    L.check(st, "ea_gather_add_rows_f32")
+    return x32
+
+
 def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None, out_dtype=torch.float16):
     """LayerNorm -> Linear as one C-ABI call (BasicTransformerBlock norm -> to_q / GEGLU proj)."""
     _check_dev(x, w)

@@ -46,19 +46,28 @@ class _Block:
         self.w1, self.b1 = _f16(sd[p + "mlp.lin1.weight"], dev), _f32(sd[p + "mlp.lin1.bias"], dev)
         self.w2, self.b2 = _f16(sd[p + "mlp.lin2.weight"], dev), _f32(sd[p + "mlp.lin2.bias"], dev)
 
-    def forward(self, x):
-        """x: fp32 [B, H, W, D] residual stream."""
+    def forward(self, x, maps=None):
+        """x: fp32 [B, H, W, D] residual stream.  `maps(B, H, W, ws)` (ImageEncoderViT._window_maps) supplies the cached
+        token -> window-row map and the zero-padded window buffer of the fused partition / unpartition path."""
         B, H, W, D = x.shape
-        xn = ops.layernorm(x, self.n1[0], self.n1[1], eps=1e-6)                      # fp16
         ws = self.window
-        if ws > 0:
-            ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
-            if ph or pw:
-                xn = F.pad(xn, (0, 0, 0, pw, 0, ph))
-            Hp, Wp = H + ph, W + pw
-            xn = xn.view(B, Hp // ws, ws, Wp // ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, D)
+        fused = ws > 0 and maps is not None and x.dtype == torch.float32 and x.is_contiguous()
+        if fused:
+            # norm1 writes straight into the window_partition() layout (pad tokens stay zero: never written);
+            # window_unpartition() + residual add is one gather-add pass over the fp32 stream
+            rows, xw, nwin = maps(B, H, W, ws, D)
+            ops.layernorm_rows(x, self.n1[0], self.n1[1], xw, rows, eps=1e-6)
+            xn = xw.view(nwin, ws * ws, D)
         else:
-            xn = xn.view(B, H * W, D)
+            xn = ops.layernorm(x, self.n1[0], self.n1[1], eps=1e-6)                      # fp16
+            if ws > 0:
+                ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+                if ph or pw:
+                    xn = F.pad(xn, (0, 0, 0, pw, 0, ph))
+                Hp, Wp = H + ph, W + pw
+                xn = xn.view(B, Hp // ws, ws, Wp // ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, D)
+            else:
+                xn = xn.view(B, H * W, D)
         qkv = ops.gemm(xn, self.wqkv, self.bqkv)                                      # [Bw, N, 3*D] = [3, heads, d]
         q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
         if ws > 0 and ws <= 16 and self.d in (64, 80):
@@ -66,7 +75,10 @@ class _Block:
         else:
             bh, bw = ops.relpos_tables(q, self.heads, self.d, self.S, self.rel_h, self.rel_w)
             a = ops.attention(q, k, v, self.heads, self.d, bias_h=bh, bias_w=bw, S=self.S)
-        if ws > 0:
+        if fused:
+            pr = ops.gemm(a, self.wproj, self.bproj)
+            x = ops.gather_add_rows(x, pr.view(-1, D), rows).view(B, H, W, D)
+        elif ws > 0:
             pr = ops.gemm(a, self.wproj, self.bproj)
             pr = pr.view(B, Hp // ws, Wp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, D)
             x = x + pr[:, :H, :W, :].float()
@@ -94,6 +106,7 @@ class ImageEncoderViT:
         self.neck2 = pack_conv(sd["neck.2.weight"], dev)
         self.ln2 = (_f32(sd["neck.3.weight"], dev), _f32(sd["neck.3.bias"], dev))
         self._graphs = {}
+        self._wmaps = {}
         self.mean = torch.tensor(PIXEL_MEAN, device=dev).view(1, 3, 1, 1)
         self.std = torch.tensor(PIXEL_STD, device=dev).view(1, 3, 1, 1)
 
@@ -116,7 +129,7 @@ class ImageEncoderViT:
         pos = self.pos if B == 1 else self.pos.repeat(B, 1)
         h = ops.gemm(patches, self.pe_w, self.pe_b, residual=pos, out_dtype=torch.float32).view(B, g, g, D)
         for blk in self.blocks:
-            h = blk.forward(h).view(B, g, g, D)
+            h = blk.forward(h, self._window_maps).view(B, g, g, D)
         h16 = h.half()
         n = ops.conv2d(h16, self.neck0, None, ksize=1, pad=0)
         n = ops.layernorm(n, self.ln1[0], self.ln1[1], eps=1e-6)
@@ -125,6 +138,20 @@ class ImageEncoderViT:
         return ops.nhwc_to_nchw(n)
 
     __call__ = forward
+
+    def _window_maps(self, B, H, W, ws, D):
+        """(token -> window row map int32 [B*H*W], zero-initialised window buffer fp16 [nwin*ws*ws, D], nwin), cached per
+        shape: pad rows of the buffer are never written, so they stay zero across blocks, calls and graph replays."""
+        key = (B, H, W, ws, D)
+        if key not in self._wmaps:
+            ny, nx = (H + ws - 1) // ws, (W + ws - 1) // ws
+            b = torch.arange(B).view(B, 1, 1)
+            y = torch.arange(H).view(1, H, 1)
+            xx = torch.arange(W).view(1, 1, W)
+            rows = ((b * ny + y // ws) * nx + xx // ws) * (ws * ws) + (y % ws) * ws + (xx % ws)
+            buf = torch.zeros(B * ny * nx * ws * ws, D, dtype=torch.float16, device=self.device)
+            self._wmaps[key] = (rows.reshape(-1).to(torch.int32).to(self.device), buf, B * ny * nx)
+        return self._wmaps[key]
 
     def forward_graph(self, x):
         """`forward` replayed from a HIP graph captured once per input shape (~450 launches per ViT-H pass otherwise;

@@ -16,6 +16,9 @@
  *                                openaimodel.py:108-152,200-231,254-274; model.py:68-149;
  *                                ControlNet hint block + zero-convs cldm/cldm.py:147-163,281-305
  *   ea_groupnorm_silu_conv3x3 <- ResBlock in_layers / out_layers as one call (openaimodel.py:254-274)
+ *   ea_layernorm_rows_f16, ea_gather_add_rows_f32
+ *                             <- segment_anything window_partition / window_unpartition around the windowed
+ *                                Attention (3rd party), fused into norm1 and the residual add
  *   ea_layernorm_f16, ea_gemm_f16, ea_ln_gemm_f16
  *                             <- BasicTransformerBlock / GEGLU / SpatialTransformer Linears
  *                                ldm/modules/attention.py:49-76,152-160,263-275,316-339
@@ -114,6 +117,15 @@ int ea_groupnorm_silu_conv3x3(const ea_conv_src* src, const float* gamma, const 
 /* LayerNorm over the last dim of [M][C]; in_f32 selects an fp32 input (residual stream). Output fp16. */
 int ea_layernorm_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
                      int M, int C, float eps, void* stream);
+
+/* The same with an output row map: normalised row m is written to row out_rows[m] of `out` (negative = dropped).
+ * SAM: norm1 writes straight into the zero-padded window_partition() layout. */
+int ea_layernorm_rows_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
+                          int M, int C, float eps, const int* out_rows, void* stream);
+
+/* x[t][:] += src[rows[t]][:] for t < T (x fp32 [T][C] in place, src fp16 rows of C, rows[t] < 0 = skip).
+ * SAM: window_unpartition() of the attention projection + residual add in one pass. */
+int ea_gather_add_rows_f32(float* x, const void* src, const int* rows, int T, int C, void* stream);
 
 /* LayerNorm followed by GEMM (BasicTransformerBlock norm -> to_q / GEGLU proj). `ln_out` scratch [M][K] fp16. */
 int ea_ln_gemm_f16(const void* x, int in_f32, const float* gamma, const float* beta, float eps, void* ln_out,

@@ -370,6 +370,35 @@ def attn_ref(q, k, v, scale, bias=None):
     return torch.einsum("bhij,bjhd->bihd", p, t(v))
 
 
+def test_layernorm_rows_and_gather_add(kb):
+    """SAM window_partition / window_unpartition fused into norm1 and the residual add: LayerNorm with an output row map
+    (dropped rows, untouched pad rows) and x32[t] += src16[rows[t]]."""
+    M, Cdim, R = 11, 320, 17
+    x = f32(M, Cdim)
+    gamma, beta = f32(Cdim), f32(Cdim)
+    rows = np.array([3, 0, -1, 16, 5, 7, 1, -1, 9, 12, 2], np.int32)
+    rows_d = kb.up(rows)
+    out = kb.zeros((R, Cdim), np.float16)
+    assert kb.lib.ea_layernorm_rows_f16(ptr(x), 1, ptr(gamma), ptr(beta), ptr(out), M, Cdim, 1e-6, ptr(rows_d), kb.stream) == 0
+    ref = F.layer_norm(t(x), (Cdim,), t(gamma), t(beta), 1e-6).numpy()
+    got = kb.down(out).astype(np.float32)
+    want = np.zeros((R, Cdim), np.float32)
+    for m, r in enumerate(rows):
+        if r >= 0:
+            want[r] = ref[m]
+    assert relerr(got, want) < 2e-3
+    assert not got[[4, 6, 8, 10, 11, 13, 14, 15]].any(), "rows no input maps to stay zero"
+    src = f16(R, Cdim)
+    acc0 = f32(M, Cdim)
+    acc = kb.up(acc0.copy())
+    assert kb.lib.ea_gather_add_rows_f32(ptr(acc), ptr(src), ptr(rows_d), M, Cdim, kb.stream) == 0
+    want2 = acc0.copy()
+    for m, r in enumerate(rows):
+        if r >= 0:
+            want2[m] += src[r].astype(np.float32)
+    assert np.allclose(kb.down(acc), want2, atol=1e-6)
+
+
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [
     (1, 2, 128, 64, 64),
     (2, 1, 70, 77, 64),     # ragged: cross-attention to 77 text tokens
