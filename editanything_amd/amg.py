@@ -55,6 +55,11 @@ class _Attn:
         B, Nq, Ci = q.shape
         h, d = self.heads, Ci // self.heads
         sp = lambda t: t.reshape(B, t.shape[1], h, d).transpose(1, 2)
+        if Nq * k.shape[1] >= 4096:
+            # image side (4096 queries x 7 keys or 7 x 4096): fused fp16 attention, fp32 softmax inside; no fp32 copies of
+            # the [B, 4096, C] operands
+            o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), scale=1.0 / math.sqrt(d))
+            return o.transpose(1, 2).reshape(B, Nq, Ci)
         a = torch.matmul(sp(q).float(), sp(k).float().transpose(-2, -1)) * (1.0 / math.sqrt(d))
         o = torch.matmul(torch.softmax(a, dim=-1), sp(v).float())
         return o.transpose(1, 2).reshape(B, Nq, Ci).half()
@@ -197,7 +202,8 @@ class SamPromptDecoder:
         u = ops.gemm(u, self.up1_w, self.up1_b, act=ops.ACT_GELU)                                     # [B*4T, 4*c1]
         u = u.reshape(B, 2 * h, 2 * w, 2, 2, self.c1).permute(0, 1, 3, 2, 4, 5).reshape(B, 16 * T, self.c1)
         hyper = torch.stack([self._mlp3(self.hyper[i], mask_toks[:, i]) for i in range(len(self.hyper))], dim=1)
-        masks = torch.bmm(u.float(), hyper.transpose(1, 2)).transpose(1, 2).reshape(B, -1, 4 * h, 4 * w)
+        # [B, 16T, c1] x [B, c1, 4] on the fp16 feature map (fp32 accumulate in the library GEMM; no fp32 copy of u)
+        masks = torch.bmm(u, hyper.half().transpose(1, 2)).float().transpose(1, 2).reshape(B, -1, 4 * h, 4 * w)
         iou = self._mlp3(self.iou_head, iou_tok)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         return masks[:, sl], iou[:, sl]

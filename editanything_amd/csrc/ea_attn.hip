@@ -682,31 +682,31 @@ struct RelposParams {
   float* bias_h; float* bias_w;
 };
 
+// grid = (ceil(N * 2S / 256), B*H): 32-bit index math only (the first version's 64-bit div/mod per output dominated its
+// run time); the 2S outputs of one query are consecutive threads, so the query row is a broadcast load and the table rows
+// (2S-1 x D fp16, L1-resident) are read back to back.
 __global__ __launch_bounds__(256) void ea_relpos_kernel(RelposParams p) {
   const int N = p.S * p.S;
-  const long long total = (long long)p.B * p.H * N * 2 * p.S;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int kk = (int)(idx % (2 * p.S));
-    const long long rest = idx / (2 * p.S);
-    const int qi = (int)(rest % N);
-    const int bh = (int)(rest / N);
-    const int b = bh / p.H, h = bh % p.H;
-    const int qh = qi / p.S, qw = qi % p.S;
-    const bool is_w = kk >= p.S;
-    const int kpos = is_w ? kk - p.S : kk;
-    const int rel = (is_w ? qw : qh) - kpos + p.S - 1;
-    const f16* qv = p.q + b * p.q_sb + (long long)qi * p.q_sn + (long long)h * p.D;
-    const f16* rv = (is_w ? p.rel_w : p.rel_h) + (long long)rel * p.D;
-    float acc = 0.0f;
-    for (int c = 0; c < p.D; c += 8) {
-      f16x8 a = ea_ld8(qv + c), r8 = ea_ld8(rv + c);
+  const int twoS = 2 * p.S;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= N * twoS) return;
+  const int bh = blockIdx.y;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int qi = idx / twoS, kk = idx - qi * twoS;
+  const int qh = qi / p.S, qw = qi - qh * p.S;
+  const bool is_w = kk >= p.S;
+  const int kpos = is_w ? kk - p.S : kk;
+  const int rel = (is_w ? qw : qh) - kpos + p.S - 1;
+  const f16* qv = p.q + b * p.q_sb + (long long)qi * p.q_sn + (long long)h * p.D;
+  const f16* rv = (is_w ? p.rel_w : p.rel_h) + rel * p.D;
+  float acc = 0.0f;
+  for (int c = 0; c < p.D; c += 8) {
+    f16x8 a = ea_ld8(qv + c), r8 = ea_ld8(rv + c);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)r8[j];
-    }
-    float* dst = (is_w ? p.bias_w : p.bias_h) + ((long long)bh * N + qi) * p.S + kpos;
-    *dst = acc;
+    for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)r8[j];
   }
+  float* dst = (is_w ? p.bias_w : p.bias_h) + ((long long)bh * N + qi) * p.S + kpos;
+  *dst = acc;
 }
 
 }  // namespace
@@ -763,11 +763,10 @@ extern "C" int ea_relpos_tables_f16(const void* q, int B, int H, int S, int D, l
   RelposParams p;
   p.q = (const f16*)q; p.B = B; p.H = H; p.S = S; p.D = D; p.q_sb = q_sb; p.q_sn = q_sn;
   p.rel_h = (const f16*)rel_h; p.rel_w = (const f16*)rel_w; p.bias_h = bias_h; p.bias_w = bias_w;
-  const long long total = (long long)B * H * S * S * 2 * S;
-  long long nb = (total + 255) / 256;
-  if (nb > 8192) nb = 8192;
+  if (S > 256) return EA_ERR_BAD_SHAPE;          // N * 2S must fit 32 bits
+  const int per_bh = S * S * 2 * S;
   auto kfn = ea_relpos_kernel;
-  EA_LAUNCH(kfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  EA_LAUNCH(kfn, dim3((unsigned)((per_bh + 255) / 256), (unsigned)(B * H)), dim3(256), 0, stream, p);
   return ea_launch_status();
 }
 
