@@ -12,8 +12,10 @@ Device work: the image encoder is `editanything_amd.sam.ImageEncoderViT`; in the
 4096 image tokens of a point batch (k/v/q projections of the two-way transformer's image side, out-projection +
 residual, both transposed-conv upscalers as GEMMs with a fused GELU) runs through the C-ABI MFMA kernels (fp16
 operands, fp32 accumulate); LayerNorms through `ea_layernorm_f16`.  The 7-token side (self-attention, token MLPs,
-hypernetwork heads) and the mask post-processing (bilinear resizes, thresholds, stability score, boxes, NMS) are
-short torch-on-device expressions -- HBM-bound scans (section 8f item 1 lists fusing them as the next step).
+hypernetwork heads) are short torch-on-device expressions; the mask post-processing (both bilinear resizes of
+`postprocess_masks`, threshold, stability counts, boxes) is ONE C-ABI pass (`ea_sam_mask_postprocess`) that writes
+only the 1-byte masks instead of materialising the 1024^2 fp32 upsampling of every candidate; box NMS computes the IoU
+matrix on the device and sweeps the few hundred candidates on the host.
 The encoder and decoder run fp16 where the reference runs fp32: masks agree with the fp32 oracle to a few pixels per
 mask on the `logits > 0` boundary (tests/test_amg.py states the tolerance); `show_anns` itself stays bit-exact.
 """
@@ -198,7 +200,7 @@ class SamPromptDecoder:
         # upscaling: two stride-2 transposed convs == per-pixel GEMMs + pixel shuffle (NHWC)
         u = ops.gemm(keys.reshape(B * T, C), self.up0_w, self.up0_b)                                  # [B*T, 4*c0]
         u = u.reshape(B, h, w, 2, 2, self.c0).permute(0, 1, 3, 2, 4, 5).reshape(B * 4 * T, self.c0)
-        u = F.gelu(ops.layernorm(u, self.up_ln[0], self.up_ln[1], eps=1e-6).float()).half()
+        u = F.gelu(ops.layernorm(u, self.up_ln[0], self.up_ln[1], eps=1e-6))      # fp16 in / out, evaluated in fp32
         u = ops.gemm(u, self.up1_w, self.up1_b, act=ops.ACT_GELU)                                     # [B*4T, 4*c1]
         u = u.reshape(B, 2 * h, 2 * w, 2, 2, self.c1).permute(0, 1, 3, 2, 4, 5).reshape(B, 16 * T, self.c1)
         hyper = torch.stack([self._mlp3(self.hyper[i], mask_toks[:, i]) for i in range(len(self.hyper))], dim=1)
@@ -335,19 +337,24 @@ class SamAutomaticMaskGenerator:
             p = torch.as_tensor(pts_all[s:s + c["points_per_batch"]], dtype=torch.float32, device=dev)
             sparse = dec.embed_points((p * scale)[:, None, :], torch.ones(len(p), 1))
             low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, True)
-            masks = postprocess_masks(low, (in_h, in_w), (H, W), S).flatten(0, 1)
-            iou = iou.flatten(0, 1)
+            low, iou = low.flatten(0, 1), iou.flatten(0, 1)
             pp = p.repeat_interleave(3, dim=0)
+            # the predicted-IoU filter does not depend on the upsampled mask: apply it first, then post-process only
+            # the survivors -- resize to the original resolution, threshold, stability counts and box in one pass
             k = iou > c["pred_iou_thresh"]
-            masks, iou, pp = masks[k], iou[k], pp[k]
-            stab = stability_score(masks, c["mask_threshold"], c["stability_score_offset"])
+            low, iou, pp = low[k], iou[k], pp[k]
+            if low.shape[0] == 0:
+                continue
+            mb, stats = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"])
+            stab = stats[:, 0] / stats[:, 1]
             k = stab >= c["stability_score_thresh"]
-            masks, iou, pp, stab = masks[k], iou[k], pp[k], stab[k]
-            mb = masks > c["mask_threshold"]
-            boxes = batched_mask_to_box(mb)
+            mb, iou, pp, stab, stats = mb[k].bool(), iou[k], pp[k], stab[k], stats[k]
+            boxes = torch.where((stats[:, 4:5] < 0), torch.zeros_like(stats[:, 2:6]), stats[:, 2:6])
             k = ~is_box_near_crop_edge(boxes, crop_box, [0, 0, W, H])
             keep["masks"].append(mb[k]); keep["iou"].append(iou[k]); keep["pts"].append(pp[k])
             keep["stab"].append(stab[k]); keep["boxes"].append(boxes[k])
+        if not keep["iou"]:
+            return []
         masks = torch.cat(keep["masks"]); iou = torch.cat(keep["iou"]); ppts = torch.cat(keep["pts"])
         stab = torch.cat(keep["stab"]); boxes = torch.cat(keep["boxes"])
         order = nms(boxes, iou, c["box_nms_thresh"]).to(dev)

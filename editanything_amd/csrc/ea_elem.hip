@@ -186,6 +186,134 @@ extern "C" int ea_gather_add_rows_f32(float* x, const void* src, const int* rows
   return ea_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// SAM mask post-processing in ONE pass (segment_anything Sam.postprocess_masks + utils/amg.py calculate_stability_score
+// + batched_mask_to_box, as SamAutomaticMaskGenerator._process_batch chains them):
+//   logits = bilinear(bilinear(low -> S x S)[:in_h, :in_w] -> H x W)        (both align_corners=False, torch's formula)
+//   mask = logits > thr;  inter = #(logits > thr + off);  union = #(logits > thr - off);  box = extent of mask
+// The reference materialises the S x S (1024^2) fp32 upsampling of every candidate mask (805 MB per 64-point batch) and
+// re-reads it four times; here each output pixel evaluates the two bilinear stages analytically from the (cache
+// resident) low-res logits and only the 1-byte mask is written.  Integer atomics -> deterministic.
+struct MaskPostParams {
+  const float* low;
+  unsigned char* mask;
+  int* stats;   // [Nm][6]: inter, union, xmin, ymin, xmax, ymax (caller-initialised to 0, 0, W, H, -1, -1)
+  int lh, lw, S, in_h, in_w, H, W;
+  float thr, off;
+};
+
+__device__ __forceinline__ void ea_bilin_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;     // area_pixel_compute_source_index, align_corners = false
+  if (src < 0.0f) src = 0.0f;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__device__ __forceinline__ void ea_atomic_add_i(int* p, int v) {
+#ifdef EA_EMU
+  *p += v;
+#else
+  atomicAdd(p, v);
+#endif
+}
+__device__ __forceinline__ void ea_atomic_min_i(int* p, int v) {
+#ifdef EA_EMU
+  if (v < *p) *p = v;
+#else
+  atomicMin(p, v);
+#endif
+}
+__device__ __forceinline__ void ea_atomic_max_i(int* p, int v) {
+#ifdef EA_EMU
+  if (v > *p) *p = v;
+#else
+  atomicMax(p, v);
+#endif
+}
+
+__global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
+  EA_SMEM(smem);
+  int* red = reinterpret_cast<int*>(smem);   // [256][6]
+  const int tid = threadIdx.x;
+  const int m = blockIdx.y;
+  const float* low = p.low + (long long)m * p.lh * p.lw;
+  unsigned char* out = p.mask + (long long)m * p.H * p.W;
+  const float s1y = (float)p.lh / (float)p.S, s1x = (float)p.lw / (float)p.S;
+  const float s2y = (float)p.in_h / (float)p.H, s2x = (float)p.in_w / (float)p.W;
+  int inter = 0, uni = 0, xmin = p.W, ymin = p.H, xmax = -1, ymax = -1;
+  const int npix = p.H * p.W;
+  for (int i = blockIdx.x * 256 + tid; i < npix; i += gridDim.x * 256) {
+    const int y = i / p.W, x = i - y * p.W;
+    int Y[2], X[2];
+    float ly, lx;
+    ea_bilin_index(s2y, y, p.in_h, Y[0], Y[1], ly);
+    ea_bilin_index(s2x, x, p.in_w, X[0], X[1], lx);
+    float up[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      int y0, y1;
+      float my;
+      ea_bilin_index(s1y, Y[a], p.lh, y0, y1, my);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        int x0, x1;
+        float mx;
+        ea_bilin_index(s1x, X[b], p.lw, x0, x1, mx);
+        const float v00 = low[y0 * p.lw + x0], v01 = low[y0 * p.lw + x1];
+        const float v10 = low[y1 * p.lw + x0], v11 = low[y1 * p.lw + x1];
+        up[a][b] = (1.0f - my) * ((1.0f - mx) * v00 + mx * v01) + my * ((1.0f - mx) * v10 + mx * v11);
+      }
+    }
+    const float v = (1.0f - ly) * ((1.0f - lx) * up[0][0] + lx * up[0][1]) + ly * ((1.0f - lx) * up[1][0] + lx * up[1][1]);
+    const bool on = v > p.thr;
+    out[i] = on ? 1 : 0;
+    inter += (v > p.thr + p.off) ? 1 : 0;
+    uni += (v > p.thr - p.off) ? 1 : 0;
+    if (on) {
+      xmin = x < xmin ? x : xmin;
+      xmax = x > xmax ? x : xmax;
+      ymin = y < ymin ? y : ymin;
+      ymax = y > ymax ? y : ymax;
+    }
+  }
+  red[tid * 6 + 0] = inter; red[tid * 6 + 1] = uni; red[tid * 6 + 2] = xmin;
+  red[tid * 6 + 3] = ymin; red[tid * 6 + 4] = xmax; red[tid * 6 + 5] = ymax;
+  __syncthreads();
+  if (tid < 6) {
+    int acc = red[tid];
+    for (int t = 1; t < 256; ++t) {
+      const int v = red[t * 6 + tid];
+      if (tid < 2) acc += v;
+      else if (tid < 4) acc = v < acc ? v : acc;
+      else acc = v > acc ? v : acc;
+    }
+    int* dst = p.stats + m * 6 + tid;
+    if (tid < 2) ea_atomic_add_i(dst, acc);
+    else if (tid < 4) ea_atomic_min_i(dst, acc);
+    else ea_atomic_max_i(dst, acc);
+  }
+}
+
+extern "C" int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
+                                       int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
+                                       void* stream) {
+  if (!low_res || !mask || !stats) return EA_ERR_BAD_ARG;
+  if (n_masks <= 0 || lh <= 0 || lw <= 0 || img_size <= 0 || in_h <= 0 || in_w <= 0 || H <= 0 || W <= 0) return EA_ERR_BAD_SHAPE;
+  if (in_h > img_size || in_w > img_size || (long long)H * W > 0x3fffffffLL) return EA_ERR_BAD_SHAPE;
+  MaskPostParams p;
+  p.low = low_res; p.mask = mask; p.stats = stats;
+  p.lh = lh; p.lw = lw; p.S = img_size; p.in_h = in_h; p.in_w = in_w; p.H = H; p.W = W;
+  p.thr = threshold; p.off = offset;
+  int bx = (H * W + 256 * 8 - 1) / (256 * 8);      // ~8 pixels per thread
+  if (bx < 1) bx = 1;
+  if (bx > 1024) bx = 1024;
+  auto kfn = ea_mask_post_kernel;
+  EA_LAUNCH(kfn, dim3((unsigned)bx, (unsigned)n_masks), dim3(256), 256 * 6 * (int)sizeof(int), stream, p);
+  return ea_launch_status();
+}
+
 // ---- fused entry points (several launches on the caller's stream, one call) ----
 extern "C" int ea_groupnorm_silu_conv3x3(const ea_conv_src* src, const float* gamma, const float* beta, int groups,
                                          float eps, void* norm_out, const void* W, int Cout, const ea_epilogue* epi,

@@ -324,6 +324,22 @@ def relpos_tables(q, heads, dim_head, S, rel_h, rel_w):
     return bh, bw
 
 
+def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, offset):
+    """low fp32 [n, lh, lw] -> (mask uint8 [n, H, W], stats int32 [n, 6] = inter, union, xmin, ymin, xmax, ymax)."""
+    _check_dev(low)
+    low = low.contiguous()
+    n, lh, lw = low.shape
+    H, W = original_size
+    mask = torch.empty((n, H, W), dtype=torch.uint8, device=low.device)
+    stats = torch.tensor([0, 0, W, H, -1, -1], dtype=torch.int32, device=low.device).repeat(n, 1).contiguous()
+    ev = _prof_begin()
+    st = _lib().ea_sam_mask_postprocess(_p(low), n, lh, lw, img_size, input_size[0], input_size[1], H, W, float(threshold),
+                                        float(offset), _p(mask), _p(stats), _stream())
+    _prof_end(ev, 0.0, f"sam-mask-post n{n} {H}x{W}")
+    L.check(st, "ea_sam_mask_postprocess")
+    return mask, stats
+
+
 def softmax_rows(x, scale):
     rows, cols = x.shape[-2] * (x.numel() // (x.shape[-1] * x.shape[-2])), x.shape[-1]
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)

@@ -19,6 +19,8 @@
  *   ea_layernorm_rows_f16, ea_gather_add_rows_f32
  *                             <- segment_anything window_partition / window_unpartition around the windowed
  *                                Attention (3rd party), fused into norm1 and the residual add
+ *   ea_sam_mask_postprocess   <- Sam.postprocess_masks + utils/amg.py calculate_stability_score /
+ *                                batched_mask_to_box (segment_anything, 3rd party), one pass
  *   ea_layernorm_f16, ea_gemm_f16, ea_ln_gemm_f16
  *                             <- BasicTransformerBlock / GEGLU / SpatialTransformer Linears
  *                                ldm/modules/attention.py:49-76,152-160,263-275,316-339
@@ -166,6 +168,14 @@ int ea_softmax_rows_f32_f16(const float* x, void* out, int rows, int cols, float
 int ea_cfg_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise,
                      const float* coef, const float* mask, const float* x_orig, const float* noise_orig,
                      float* x_prev, float* pred_x0, long long n, void* stream);
+
+/* SAM mask post-processing in one pass (Sam.postprocess_masks + calculate_stability_score + batched_mask_to_box of
+ * segment_anything, third party): low_res fp32 [n][lh][lw] logits -> mask uint8 [n][H][W] (logit > threshold at the
+ * original resolution, through the img_size^2 intermediate cropped to in_h x in_w, both resizes bilinear
+ * align_corners=False) and stats int32 [n][6] = {#(> thr+off), #(> thr-off), xmin, ymin, xmax, ymax}.
+ * `stats` must be initialised by the caller to {0, 0, W, H, -1, -1} per mask (accumulated with integer atomics). */
+int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
+                            int H, int W, float threshold, float offset, unsigned char* mask, int* stats, void* stream);
 
 /* Layout plumbing on device: NCHW fp32 -> NHWC fp16 with channel padding, and back. */
 int ea_nchw_f32_to_nhwc_f16(const float* x, void* out, int B, int C, int H, int W, int Cpad, float mul,

@@ -370,6 +370,37 @@ def attn_ref(q, k, v, scale, bias=None):
     return torch.einsum("bhij,bjhd->bihd", p, t(v))
 
 
+@pytest.mark.parametrize("hw,lres,S", [((48, 64), 16, 64), ((37, 29), 16, 64), ((64, 64), 8, 32)])
+def test_sam_mask_postprocess(kb, hw, lres, S):
+    """One-pass mask post-processing == F.interpolate(F.interpolate(low, S)[:in_h,:in_w], (H,W)) > thr, stability counts,
+    boxes (segment_anything postprocess_masks / calculate_stability_score / batched_mask_to_box)."""
+    H, W = hw
+    n = 5
+    scale = S / max(H, W)
+    in_h, in_w = int(H * scale + 0.5), int(W * scale + 0.5)
+    low = f32(n, lres, lres, scale=2.0)
+    low[3] = -5.0                                              # an empty mask
+    thr, off = 0.1, 0.7
+    mask = kb.zeros((n, H, W), np.uint8)
+    stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (n, 1)))
+    st = kb.lib.ea_sam_mask_postprocess(ptr(low), n, lres, lres, S, in_h, in_w, H, W, thr, off, ptr(mask), ptr(stats), kb.stream)
+    assert st == 0
+    up = F.interpolate(t(low)[None], (S, S), mode="bilinear", align_corners=False)[0][..., :in_h, :in_w]
+    ref = F.interpolate(up[None], (H, W), mode="bilinear", align_corners=False)[0]
+    got_m, got_s = kb.down(mask).astype(bool), kb.down(stats)
+    margin = (ref - thr).abs() > 1e-4                         # pixels not within float round-off of the threshold
+    assert (got_m == (ref > thr).numpy())[margin.numpy()].all()
+    inter, union = (ref > thr + off).sum((1, 2)).numpy(), (ref > thr - off).sum((1, 2)).numpy()
+    assert np.abs(got_s[:, 0] - inter).max() <= 2 and np.abs(got_s[:, 1] - union).max() <= 2
+    for i in range(n):
+        ys, xs = np.nonzero(got_m[i])
+        if len(ys) == 0:
+            assert got_s[i, 2:].tolist() == [W, H, -1, -1]
+        else:
+            assert got_s[i, 2:].tolist() == [xs.min(), ys.min(), xs.max(), ys.max()]
+    assert not got_m[3].any()
+
+
 def test_layernorm_rows_and_gather_add(kb):
     """SAM window_partition / window_unpartition fused into norm1 and the residual add: LayerNorm with an output row map
     (dropped rows, untouched pad rows) and x32[t] += src16[rows[t]]."""
