@@ -384,8 +384,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
       // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
       __syncthreads();
-      if (kt + 1 < nk) issue_tile((kt + 1) & 1);
-      compute_tile(kt & 1);
+      if (kt + 1 < nk && p.debug != 11) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
+      if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
     }
   } else {
     // 3-deep ring, two tiles in flight: at iteration kt wait until only tile kt+1's DMA group is outstanding (counted
