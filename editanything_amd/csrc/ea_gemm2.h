@@ -383,8 +383,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
       // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
-      __syncthreads();
-      if (kt + 1 < nk && p.debug != 11) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
+      if (p.debug != 12) __syncthreads();                               // debug 12: compute only, no barrier either
+      if (kt + 1 < nk && p.debug != 11 && p.debug != 12) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
       if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
     }
   } else {

@@ -1,5 +1,5 @@
 """K-loop ablation of the 2-stage ea_gemm2 kernel (EA_GEMM2_DEBUG): 0 full, 1 no epilogue, 10 staging only (no MFMA /
-fragment reads), 11 compute only (no staging after the first tile).  Timing only -- ablated runs compute garbage."""
+fragment reads), 11 compute only (no staging after the first tile), 12 compute only without the per-tile barrier.  Timing only -- ablated runs compute garbage."""
 import os
 import sys
 
@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_ops as bo  # noqa: E402
 
 bo.timeit.__defaults__ = (20, 3)
-for dbg in ("0", "1", "10", "11"):
+for dbg in (sys.argv[1:] or ["0", "1", "10", "11", "12"]):
     os.environ["EA_GEMM2_DEBUG"] = dbg
     bo.set_variant("1")
     bo.VARIANT = "dbg" + dbg
