@@ -128,3 +128,82 @@ def numpy_to_pil(images):
         images = images[None]
     images = (images * 255).round().astype("uint8")
     return [Image.fromarray(im) for im in images]
+
+
+# ---------------------------------------------------------------------------------------------- editany_lora.py helpers
+def resize_linear_u8(img, width, height):
+    """`cv2.resize(img, (width, height), interpolation=cv2.INTER_LINEAR)` for uint8 HWC / HW arrays
+    (editany_lora.py:742-752, 801-805, 892-897: SAM id map, inpaint mask and scale map onto the working resolution).
+    OpenCV's 8-bit path restated: half-pixel centres, NO antialiasing when shrinking, 11-bit fixed-point tap weights,
+    horizontal pass in int32 then `((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2`.  cv2 is not installed here, so the
+    fixed-point rounding is not pinned against OpenCV itself; an unchanged size is an exact copy, which
+    is the case of every BASELINE config."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8
+    sh, sw = img.shape[:2]
+    if (sh, sw) == (height, width):
+        return img.copy()
+    squeeze = img.ndim == 2
+    src = img[:, :, None] if squeeze else img
+
+    def taps(dst_n, src_n):
+        scale = src_n / dst_n
+        f = (np.arange(dst_n, dtype=np.float64) + 0.5) * scale - 0.5
+        s = np.floor(f).astype(np.int64)
+        f = f - s
+        lo = s < 0
+        s[lo], f[lo] = 0, 0.0
+        hi = s >= src_n - 1
+        s[hi], f[hi] = src_n - 1, 0.0
+        s1 = np.minimum(s + 1, src_n - 1)
+        w1 = np.clip(np.rint(f * 2048.0), -32768, 32767).astype(np.int64)
+        w0 = np.clip(np.rint((1.0 - f) * 2048.0), -32768, 32767).astype(np.int64)
+        return s, s1, w0, w1
+
+    x0, x1, a0, a1 = taps(width, sw)
+    y0, y1, b0, b1 = taps(height, sh)
+    s64 = src.astype(np.int64)
+    hor = s64[:, x0, :] * a0[None, :, None] + s64[:, x1, :] * a1[None, :, None]         # [sh, width, C] int
+    r0, r1 = hor[y0], hor[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out[:, :, 0] if squeeze else out
+
+
+def resize_points(clicked_points, original_shape, resolution):
+    """annotator/util.py:40-55."""
+    oh, ow = float(original_shape[0]), float(original_shape[1])
+    k = float(resolution) / min(oh, ow)
+    return [(int(round(x * k)), int(round(y * k)), lab) for x, y, lab in clicked_points]
+
+
+def get_bounding_box(mask):
+    """annotator/util.py:57-74 -> [xmin, ymin, xmax, ymax] of the non-zero region of channel 0."""
+    m = np.array(mask).astype(np.uint8)[:, :, 0]
+    xs = np.where(np.any(m, axis=0))[0]
+    ys = np.where(np.any(m, axis=1))[0]
+    return [xs[0], ys[0], xs[-1], ys[-1]]
+
+
+def make_inpaint_condition(image, image_mask):
+    """editany_lora.py:330-338: image / 255 with the masked pixels set to -1 -> float64 [1, 3, H, W] (the inpaint
+    ControlNet's conditioning image)."""
+    image = np.asarray(image) / 255.0
+    assert image.shape[0:1] == image_mask.shape[0:1], "image and image_mask must have the same image size"
+    image[np.asarray(image_mask) > 128] = -1.0
+    return torch.from_numpy(np.expand_dims(image, 0).transpose(0, 3, 1, 2).copy())
+
+
+def draw_click_overlay(input_image, mask_image, clicked_points, radius=20, opacity_mask=0.75, opacity_edited=1.0):
+    """editany_lora.py:587-607: filled circles at the clicks (red = foreground, blue = background), then
+    `addWeighted(edited, 1.0, mask * green, 0.75, 0)` with uint8 saturation."""
+    from PIL import ImageDraw
+    edited = Image.fromarray(np.ascontiguousarray(input_image))
+    d = ImageDraw.Draw(edited)
+    for x, y, lab in clicked_points:
+        color = (255, 0, 0) if lab == 1 else (0, 0, 255)
+        d.ellipse([x - radius, y - radius, x + radius, y + radius], fill=color)
+    edited = np.asarray(edited).astype(np.float64)
+    green = (mask_image * np.array([0.0, 1.0, 0.0])).astype(np.uint8).astype(np.float64)
+    out = np.rint(edited * opacity_edited + green * opacity_mask)
+    return np.clip(out, 0, 255).astype(np.uint8)

@@ -41,15 +41,67 @@ def synthetic_weights(name, seed=0):
             synth.synth_state_dict_torch(arch.vae_param_shapes(cfg["vae"]), seed + 2))
 
 
+def build_pipeline_from_configs(unet_cfg, unet_sd, controlnets, vae_cfg, vae_sd, device="cuda", inpaint=True,
+                                use_graph=True, text_encoder=None, tokenizer=None, scheduler_config=None,
+                                text_encoder_path=None, tokenizer_path=None):
+    """`controlnets`: one (cfg, state_dict) pair, or a LIST of pairs -- a list (even of one) makes a multi-ControlNet
+    pipeline that takes list-valued conditioning images / scales, like diffusers' MultiControlNetModel
+    (...inpaint.py:437-438).  State dicts are LDM-named (convert.from_diffusers for diffusers checkpoints)."""
+    unet = ControlledUnetModel(unet_cfg, unet_sd, device)
+    multi = isinstance(controlnets, list)
+    cns = [ControlNet(c, s, device) for c, s in (controlnets if multi else [controlnets])]
+    vae = AutoencoderKL(vae_cfg, vae_sd, device)
+    sch = DDIMScheduler()
+    if scheduler_config:
+        sch = DDIMScheduler(num_train_timesteps=scheduler_config.get("num_train_timesteps", 1000),
+                            beta_start=scheduler_config.get("beta_start", 0.00085),
+                            beta_end=scheduler_config.get("beta_end", 0.012),
+                            prediction_type=scheduler_config.get("prediction_type", "epsilon"))
+    if text_encoder is None and text_encoder_path is not None and tokenizer_path is not None:
+        text_encoder, tokenizer = load_text_encoder(text_encoder_path, tokenizer_path, device)
+    cls = StableDiffusionControlNetInpaintPipeline if inpaint else StableDiffusionControlNetPipeline
+    return cls(vae, unet, cns if multi else cns[0], sch, text_encoder=text_encoder, tokenizer=tokenizer, device=device,
+               use_graph=use_graph)
+
+
+def load_text_encoder(text_encoder_path, tokenizer_path, device="cuda"):
+    """The CLIP text encoder is outside the hot path (text encode is not on it): it stays the
+    `transformers` module the reference's pipelines use, moved to the device, and is called once per request."""
+    from transformers import CLIPTextModel, CLIPTokenizer
+    tok = CLIPTokenizer.from_pretrained(tokenizer_path)
+    enc = CLIPTextModel.from_pretrained(text_encoder_path).to(device).eval()
+    return enc, tok
+
+
 def build_pipeline(name, unet_sd, controlnet_sd, vae_sd, device="cuda", inpaint=True, use_graph=True, text_encoder=None):
     cfg = CONFIGS[name]
-    unet = ControlledUnetModel(cfg["unet"], unet_sd, device)
-    cn_sds = controlnet_sd if isinstance(controlnet_sd, (list, tuple)) else [controlnet_sd]
-    cns = [ControlNet(cfg["controlnet"], s, device) for s in cn_sds]
-    vae = AutoencoderKL(cfg["vae"], vae_sd, device)
-    cls = StableDiffusionControlNetInpaintPipeline if inpaint else StableDiffusionControlNetPipeline
-    return cls(vae, unet, cns if len(cns) > 1 else cns[0], DDIMScheduler(), text_encoder=text_encoder, device=device,
-               use_graph=use_graph)
+    if isinstance(controlnet_sd, (list, tuple)):
+        cns = [(cfg["controlnet"], s) for s in controlnet_sd]
+        cns = cns if len(cns) > 1 else cns[0]
+    else:
+        cns = (cfg["controlnet"], controlnet_sd)
+    return build_pipeline_from_configs(cfg["unet"], unet_sd, cns, cfg["vae"], vae_sd, device, inpaint, use_graph,
+                                       text_encoder=text_encoder)
+
+
+def from_pretrained(base_model_path, controlnet, device="cuda", inpaint=True, lora=None, lora_weight=1.0, use_graph=True):
+    """`Pipe.from_pretrained(base, controlnet=ControlNetModel2.from_pretrained(path) | [..])` of the reference
+    (sam2image.py:36-46, editany_lora.py:340-386) for LOCAL diffusers-format folders: `controlnet` is a folder path or a
+    list of folder paths; `lora` an optional kohya `.safetensors` path (or list), merged at load time."""
+    from . import convert, lora as lora_mod
+    base = convert.load_diffusers_folder(base_model_path)
+    ucfg, usd = base["unet"]
+    if lora is not None:
+        paths = lora if isinstance(lora, (list, tuple)) else [lora]
+        usd, _ = lora_mod.merge_lora(usd, [convert.load_state_dict_file(p) for p in paths], lora_weight,
+                                     layers_per_block=ucfg["num_res_blocks"])
+    if isinstance(controlnet, (list, tuple)):
+        cns = [convert.load_diffusers_component(p, "controlnet")[:2] for p in controlnet]
+    else:
+        cns = convert.load_diffusers_component(controlnet, "controlnet")[:2]
+    return build_pipeline_from_configs(ucfg, usd, cns, base["vae"][0], base["vae"][1], device=device, inpaint=inpaint,
+                                       use_graph=use_graph, scheduler_config=base["scheduler"],
+                                       text_encoder_path=base["text_encoder"], tokenizer_path=base["tokenizer"])
 
 
 def synthetic_pipeline(name="sd21", seed=0, device="cuda", inpaint=True, use_graph=True):

@@ -92,7 +92,7 @@ class StableDiffusionControlNetInpaintPipeline:
                 prompt_embeds.shape != negative_prompt_embeds.shape:
             raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape.")
         n = len(self.controlnets)
-        if n == 1:
+        if not isinstance(self.controlnet, (list, tuple)):
             if isinstance(cond_scale, (list, tuple)):
                 raise TypeError("For single controlnet: `controlnet_conditioning_scale` must be type `float`.")
         else:
@@ -105,19 +105,28 @@ class StableDiffusionControlNetInpaintPipeline:
         if (image is None) != (mask_image is None):
             raise ValueError("`image` and `mask_image` must be given together (inpainting) or both omitted.")
 
+    def _encode_text(self, prompts):
+        """list[str] -> [B, L, ctx].  Two conventions: a plain callable `text_encoder(list[str])`, or the diffusers pair
+        `tokenizer(...)` + `text_encoder(input_ids)[0]` (…inpaint.py:585-618: padded / truncated to `model_max_length`)."""
+        if self.tokenizer is None:
+            return self.text_encoder(prompts)
+        ids = self.tokenizer(prompts, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                             return_tensors="pt").input_ids
+        return self.text_encoder(ids.to(getattr(self.text_encoder, "device", "cpu")))[0]
+
     def _encode_prompt(self, prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds, negative_prompt_embeds):
         """…inpaint.py:551-703: -> [uncond || cond] embeddings, each repeated num_images_per_prompt times."""
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise ValueError("This pipeline has no text encoder (outside the hot path): pass `prompt_embeds`.")
             prompts = [prompt] if isinstance(prompt, str) else list(prompt)
-            prompt_embeds = self.text_encoder(prompts)
+            prompt_embeds = self._encode_text(prompts)
             if do_cfg and negative_prompt_embeds is None:
                 neg = negative_prompt if negative_prompt is not None else ""
                 negs = [neg] * len(prompts) if isinstance(neg, str) else list(neg)
                 if len(negs) != len(prompts):
                     raise ValueError("`negative_prompt` batch size must match `prompt`.")
-                negative_prompt_embeds = self.text_encoder(negs)
+                negative_prompt_embeds = self._encode_text(negs)
         prompt_embeds = prompt_embeds.to(self.device, torch.float32)
         b, L, _ = prompt_embeds.shape
         prompt_embeds = prompt_embeds.repeat(1, num_images_per_prompt, 1).view(b * num_images_per_prompt, L, -1)
@@ -163,6 +172,16 @@ class StableDiffusionControlNetInpaintPipeline:
             latents = latents.to(self.device, torch.float32)
         return latents * self.scheduler.init_noise_sigma
 
+    def _vae_noise(self, vae_noise, shape, generator):
+        """Noise of the VAE posterior sample (`DiagonalGaussianDistribution.sample`, …inpaint.py:1079-1081).  Drawn from
+        the call's generator right after the initial latents, as the reference does; `vae_noise=` lets a caller that
+        batches several reference calls into one hand in the values those calls would have drawn (editany_lora.py)."""
+        if vae_noise is not None:
+            if tuple(vae_noise.shape) != tuple(shape):
+                raise ValueError(f"Unexpected vae_noise shape, got {tuple(vae_noise.shape)}, expected {tuple(shape)}")
+            return vae_noise.to(self.device, torch.float32)
+        return randn_tensor(shape, generator if not isinstance(generator, list) else generator[0], self.device)
+
     def decode_latents(self, latents):
         """…inpaint.py:718-724 -> float32 NHWC numpy in [0, 1]."""
         img = self.vae.decode_nhwc(latents / self.vae.scale_factor)
@@ -191,7 +210,7 @@ class StableDiffusionControlNetInpaintPipeline:
                  num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
                  cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
-                 guess_mode=False, controlnet_conditioning_scale_map=None, **unused):
+                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, **unused):
         if controlnet_conditioning_image is None and "control_image" in unused:
             controlnet_conditioning_image = unused.pop("control_image")
         cond_images = controlnet_conditioning_image
@@ -248,14 +267,14 @@ class StableDiffusionControlNetInpaintPipeline:
             if unet_in != 4:    # SD2-inpainting 9-channel UNet (…inpaint.py:1448-1468, 1550-1558)
                 masked = img * (msk < 0.5)
                 m_lat = F.interpolate(msk, size=(h8, w8))
-                vnoise = randn_tensor((masked.shape[0], 4, h8, w8), generator if not isinstance(generator, list) else generator[0], self.device)
+                vnoise = self._vae_noise(vae_noise, (masked.shape[0], 4, h8, w8), generator)
                 mi_lat = self.vae.encode(masked, vnoise)
                 rep = n_img // m_lat.shape[0]
                 m_lat, mi_lat = m_lat.repeat(rep, 1, 1, 1), mi_lat.repeat(n_img // mi_lat.shape[0], 1, 1, 1)
                 extra = torch.cat([m_lat, mi_lat], dim=1)
                 extra = torch.cat([extra] * 2) if do_cfg else extra
             else:               # 4-channel UNet: blend with the re-noised original (…inpaint.py:1469-1489, 1647-1664)
-                vnoise = randn_tensor((img.shape[0], 4, h8, w8), generator if not isinstance(generator, list) else generator[0], self.device)
+                vnoise = self._vae_noise(vae_noise, (img.shape[0], 4, h8, w8), generator)
                 x_orig = self.vae.encode(img, vnoise)
                 x_orig = x_orig.repeat(n_img // x_orig.shape[0], 1, 1, 1).contiguous()
                 keep = 1 - F.interpolate(msk, size=(h8, w8), mode="nearest")
