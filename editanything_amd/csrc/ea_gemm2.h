@@ -32,6 +32,9 @@
 #pragma once
 #include "ea_gemm.h"
 
+#ifndef EA_EXP
+#define EA_EXP 0   // bit mask of compile-time experiments (tools/build_exp.sh builds side libraries; 0 in the product)
+#endif
 #define EA_OOB 0xFFFFFFF0u  // per-lane byte offset beyond any descriptor: the DMA writes zeros
 #define EA_BUF_BYTES 0x80000000u
 
@@ -312,6 +315,30 @@ void ea_gemm2_kernel(EaGemmParams p) {
   // every few MFMAs, instead of as one burst in front of them.  A wave's DMA burst occupies the CU's single
   // address/texture path (64 B/clk: 576 clk for a 36-KiB tile) while the wave sits in VMEM issue, i.e. burst + MFMA
   // phases add up (measured: tile time = 576 + 640 clk); interleaved, the path drains while the matrix pipe works.
+#if (EA_EXP & 4) && !defined(EA_EMU)
+  constexpr int KSTEPS = (MT == 16) ? 2 : 4;
+  constexpr int CH_PER_STEP = (MT == 16) ? 4 : 2;
+  f16x8 fa[2][MI], fb[2][NI];
+  auto load_frags = [&](int buf, int ks, int slot) {
+    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sb = sa + BM * 128;
+    const int ch = ks * CH_PER_STEP + fq;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int r = wm * WTM + i * MT + frow;
+      fa[slot][i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int r = wn * WTN + j * MT + frow;
+      fb[slot][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+    }
+  };
+  // `prefetched`: the caller already issued load_frags(buf, 0, 0) (EA_EXP & 4: ahead of the next tile's DMA burst)
+  auto compute_tile = [&](int buf, bool ilv_issue = false, bool prefetched = false) {
+    if (!prefetched) load_frags(buf, 0, 0);
+#define EA_LOADF(ks_, slot_) load_frags(buf, (ks_), (slot_))
+#else
   auto compute_tile = [&](int buf, bool ilv_issue = false) {
     const char* sa = smem + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
@@ -332,9 +359,14 @@ void ea_gemm2_kernel(EaGemmParams p) {
       }
     };
     load_frags(0, 0);
+#define EA_LOADF(ks_, slot_) load_frags((ks_), (slot_))
+#endif
+#if (EA_EXP & 2) && !defined(EA_EMU)
+    __builtin_amdgcn_s_setprio(1);   // experiment: the MFMA stream outranks the co-resident workgroup's issue phases
+#endif
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if (ks + 1 < KSTEPS) load_frags(ks + 1, (ks + 1) & 1);
+      if (ks + 1 < KSTEPS) EA_LOADF(ks + 1, (ks + 1) & 1);
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -354,7 +386,30 @@ void ea_gemm2_kernel(EaGemmParams p) {
         }
       }
     }
+#if (EA_EXP & 2) && !defined(EA_EMU)
+    __builtin_amdgcn_s_setprio(0);
+#endif
+#if (EA_EXP & 1) && !defined(EA_EMU)
+    // experiment: pin the fragment double-buffering.  hipcc otherwise re-fuses the two K steps to save registers and
+    // leaves 3-4 exposed `ds_read -> s_waitcnt lgkmcnt -> MFMA` round trips per K tile (seen in the ISA): step s+1's
+    // reads are spread one per two MFMAs of step s; only the first step's reads stay exposed.
+    if (!ILV && !LDR) {
+      constexpr int RD = MI + NI, MF = MI * NI;
+      __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+      for (int ks = 0; ks + 1 < KSTEPS; ++ks) {
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (MF >= 2 * RD) ? 2 : 1, 0);
+        }
+        if (MF > ((MF >= 2 * RD) ? 2 : 1) * RD) __builtin_amdgcn_sched_group_barrier(0x008, MF - ((MF >= 2 * RD) ? 2 : 1) * RD, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+    }
+#endif
   };
+#undef EA_LOADF
 
   EA_STAMP(1);
   if (STAGES == 2 && LDR) {
@@ -384,8 +439,18 @@ void ea_gemm2_kernel(EaGemmParams p) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
       // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
       if (p.debug != 12) __syncthreads();                               // debug 12: compute only, no barrier either
+#if (EA_EXP & 4) && !defined(EA_EMU)
+      // experiment: the first K step's fragment reads go out BEFORE the next tile's DMA burst (whose ~9 x 60 clk of
+      // VMEM issue then covers their LDS latency) instead of after it
+      load_frags(kt & 1, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nk) issue_tile((kt + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_tile(kt & 1, false, true);
+#else
       if (kt + 1 < nk && p.debug != 11 && p.debug != 12) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
       if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
+#endif
     }
   } else {
     // 3-deep ring, two tiles in flight: at iteration kt wait until only tile kt+1's DMA group is outstanding (counted
@@ -569,7 +634,11 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { h[j] = (f16)lo[v][j]; h[4 + j] = (f16)hi[v][j]; }
         }
+#if (EA_EXP & 8) && !defined(EA_EMU)
+        __builtin_nontemporal_store(h, reinterpret_cast<f16x8*>(outp + off[v]));   // experiment: streaming output stores
+#else
         ea_st8(outp + off[v], h);
+#endif
       }
       ea_wave_lds_sync();
     }
