@@ -156,7 +156,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
       if (bm == 64 && s > 2 && g_force_splits == 0) break;
       // ... and they only pay while every workgroup is resident at once (<= 2 per CU): with a second round the
       // 128-row tiles' better weight reuse wins again (M32768 x K1280: 44 us vs 38 us)
-      if (bm == 64 && g_force_splits == 0 &&
+      if (bm == 64 && g_force_splits == 0 && !forced_bm &&
           (double)((M + 63) / 64) * ((N + t.bn - 1) / t.bn) * batch * s > 512.0) continue;
       int kps, s_eff;
       const double c = plan_cost(bm, t.bn, M, N, K, batch, s, conv, &kps, &s_eff);
@@ -166,12 +166,10 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
       }
     }
   }
-  // 64x64-level convolutions (M >= 16384 rows, N = 320: two column tiles, four rounds of 64-row tiles): the
-  // loader-wave instantiation measured 4..9 % ahead of the two-workgroup 128-row tiles (profiles/r01_bench_ops_v3_loader_waves.json).
-  if (g_variant == 0 && conv && t.kind == 1 && t.splits == 1 && t.bn == 160 && N <= 320 && (long long)M * batch >= 16384) {
-    t.kind = 11;
-    t.bm = 64;
-  }
+  // (The loader-wave instantiation, kind 11, used to be picked here for the 64x64-level convolutions on the strength of
+  // a +4..9 % microbenchmark.  Re-measured with tools/gemm_bench in graph replay -- how the product runs -- it is 1.65x
+  // SLOWER than the two-workgroup 128-row tiles on exactly those launches (117 vs 70 us for conv3x3 B8 64x64 320->320,
+  // profiles/r01x_gemm_bench.jsonl): kind 11 stays reachable through EA_GEMM2_VARIANT only.)
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
@@ -214,6 +212,11 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
       ok = (e.ldr & 7) == 0 && (((uintptr_t)e.residual) & 15) == 0 && (p.strideR & 7) == 0 && (long long)p.M * e.ldr < 0x7fffffffLL;
     if (ok && e.rowvec) ok = p.batch == 1 && e.rows_per_group > 0 && (e.rows_per_group % t.bm) == 0;
     p.epi_fast = ok ? 1 : 0;
+    // streamlined GEGLU epilogue: 80-row packing on 160-wide tiles, plain fp16 output, nothing else per output
+    if (e.act == EA_ACT_GEGLU && e.geglu_block == 80 && t.bn == 160 && t.splits == 1 && !e.out_f32 && !e.residual &&
+        !e.residual32 && !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 &&
+        (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 && p.debug != 9)
+      p.epi_fast = 2;
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \

@@ -389,11 +389,13 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #if (EA_EXP & 2) && !defined(EA_EMU)
     __builtin_amdgcn_s_setprio(0);
 #endif
-#if (EA_EXP & 1) && !defined(EA_EMU)
-    // experiment: pin the fragment double-buffering.  hipcc otherwise re-fuses the two K steps to save registers and
+#if !(EA_EXP & 16) && !defined(EA_EMU)
+    // Pin the fragment double-buffering (guide T19).  hipcc otherwise re-fuses the two K steps to save registers and
     // leaves 3-4 exposed `ds_read -> s_waitcnt lgkmcnt -> MFMA` round trips per K tile (seen in the ISA): step s+1's
-    // reads are spread one per two MFMAs of step s; only the first step's reads stay exposed.
-    if (!ILV && !LDR) {
+    // reads are spread one per two MFMAs of step s; only the first step's reads stay exposed.  Same register count, no
+    // change in arithmetic order (bit-identical results); +1..3 % on every 2-stage launch measured
+    // (profiles/r01x_gemm_bench.jsonl, "exp1").  EA_EXP & 16 switches it off for A/B builds.
+    if (!ILV && !LDR && STAGES == 2) {
       constexpr int RD = MI + NI, MF = MI * NI;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
@@ -567,7 +569,64 @@ void ea_gemm2_kernel(EaGemmParams p) {
   // reads in turn (measured ~3 us per 32-row slab per wave, as much as a 5-tile K loop).  Here the per-COLUMN terms
   // (bias + row vector) and the activation are applied while the accumulators are scattered to the LDS slab, and the
   // gather side is a fully unrolled {all LDS reads + all residual loads} -> {add, convert, 16-byte store} sequence.
-  if (MT == 16 && p.epi_fast) {
+  // ---- streamlined GEGLU epilogue (p.epi_fast == 2; attention.py:54-56 `x, gate = proj(x).chunk(2); x * gelu(gate)`).
+  // Weight rows are packed [40 value | 40 gate] per 80, so one wave's 64 x 80 accumulator tile holds value and gate of
+  // the same 40 outputs.  bias + GELU(gate) are applied while the accumulators are scattered to the wave's LDS slab
+  // (each element once, in the MFMA layout: the gate test is per lane, no divergence); the gather side reads a value
+  // vector and its gate vector, multiplies and writes 16 bytes.  The general path below spends 74 us of a 131-us
+  // [32768 x 2560 x 320] launch in its per-vector wait chains (tools/gemm_bench --debug 0,1).
+  if (MT == 16 && WTN == 80 && p.epi_fast == 2) {
+    constexpr int SLABG = 16;
+    constexpr int NSLABG = WTM / SLABG;
+    constexpr int SLDG = WTN + 4;
+    constexpr int VPRG = 5;                                  // 16-byte output vectors per row (40 outputs)
+    constexpr int NVG = (SLABG * VPRG + 63) / 64;            // 2
+    static_assert(NW * SLABG * SLDG * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    float* wst = reinterpret_cast<float*>(smem) + wave * (SLABG * SLDG);
+    const int colbase = n0 + wn * WTN;                       // packed weight row of this wave's first column
+    const int obase = colbase >> 1;                          // first output column
+    float cb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = colbase + j * 16 + frow;
+      cb[j] = (e.bias && col < p.N) ? e.bias[col] : 0.0f;
+    }
+    f16* outp = (f16*)e.out + (long long)batch * p.strideC;
+#pragma unroll
+    for (int slab = 0; slab < NSLABG; ++slab) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const bool gate = (j * 16 + frow) >= 40;             // compile-time for j != 2
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[MT == 16 ? (MI > slab ? slab : 0) : 0][MT == 16 ? j : 0][r] + cb[j];
+          if (j >= 2) { const float g = ea_gelu_erf(x); x = gate ? g : x; }
+          wst[(fq * 4 + r) * SLDG + j * 16 + frow] = x;
+        }
+      }
+      ea_wave_lds_sync();
+      const int mrow0 = m0 + wm * WTM + slab * SLABG;
+#pragma unroll
+      for (int v = 0; v < NVG; ++v) {
+        const int id = lane + 64 * v;
+        const int row = id / VPRG, c = id - row * VPRG;
+        const int m = mrow0 + row, n = obase + c * 8;
+        if (id < SLABG * VPRG && m < p.M && n < e.N) {
+          const float* sp = wst + row * SLDG + c * 8;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 40), g1 = *reinterpret_cast<const f32x4*>(sp + 44);
+          f16x8 h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] * g0[q] * e.scale); h[4 + q] = (f16)(v1[q] * g1[q] * e.scale); }
+          ea_st8(outp + (long long)m * e.ldc + n, h);
+        }
+      }
+      ea_wave_lds_sync();
+    }
+    EA_STAMP(4);
+    return;
+  }
+  if (MT == 16 && p.epi_fast == 1) {
     constexpr int SLABF = 16;   // rows per slab: 3 output vectors per lane in flight (32 rows spill the 128x160 kernel)
     constexpr int NSLABF = WTM / SLABF;
     constexpr int SLDF = WTN + 4;

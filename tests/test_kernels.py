@@ -82,6 +82,8 @@ def test_gemm(kb, M, N, K, batch, act, res, f32out):
 @pytest.mark.parametrize("M,N,K,batch,act,res,f32out,gb", [
     (200, 160, 128, 1, 0, True, False, 0),     # 128x160 tile, ragged M
     (128, 320, 64, 1, 3, True, False, 80),     # GEGLU, 80-row packing (value | gate inside one wave's columns)
+    (200, 320, 128, 1, 3, False, False, 80),   # GEGLU, streamlined epilogue (no residual), ragged M
+    (64, 160, 64, 1, 3, False, False, 80),     # GEGLU, streamlined epilogue, 64-row tiles
     (130, 192, 192, 1, 2, False, True, 0),     # 128x128 tile, ragged M and N, fp32 out
     (128, 160, 2048, 1, 0, True, False, 0),    # split-K through the LDS-DMA kernel + reduce
     (96, 160, 64, 2, 1, False, False, 0),      # batched
@@ -108,6 +110,25 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
         ref = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(batch, M, No)
     if res:
         ref = ref + t(R)
+    assert relerr(kb.down(out), ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 9, 10, 11])
+def test_gemm_geglu_streamlined_epilogue_variants(kb, variant, monkeypatch):
+    """The streamlined GEGLU epilogue (no residual, 80-row packing) in every instantiation that carries it, with a
+    scalar scale and ragged M; kinds 5 (32x32x16 MFMA) takes the general path and must agree too."""
+    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    M, N, K, gb = 150, 480, 128, 80
+    A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
+    bias = f32(N)
+    out = kb.zeros((1, M, N // 2), np.float16)
+    e = epilogue(out, bias=bias, act=3, geglu_block=gb, scale=0.75)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws),
+                              kb.stream) == 0
+    ref = torch.einsum("bmk,bnk->bmn", t(A), t(W)) + t(bias)
+    r = ref.reshape(1, M, N // gb, 2, gb // 2)
+    ref = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(1, M, N // 2) * 0.75
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 

@@ -2,7 +2,8 @@
 # Side builds of the contraction kernel with compile-time experiment flags (ea_gemm2.h EA_EXP bit mask), for
 # tools/gemm_bench A/B runs.  Usage: bash tools/build_exp.sh 1 5 7   ->  gpurun_exp/libea_exp<N>.so (one per mask).
 # The product library (editanything_amd/csrc/libeditanything_hip.so) is EA_EXP=0 and is never touched here.
-#   bit 0 (1): pinned fragment double-buffering (sched_group_barrier)     bit 1 (2): s_setprio around the MFMA stream
+#   bit 0 (1): (adopted into the product; bit 4 (16) switches the pinned fragment double-buffering OFF)
+#   bit 1 (2): s_setprio around the MFMA stream
 #   bit 2 (4): first K step's fragment reads issued before the next tile's DMA burst (2-stage loop)
 #   bit 3 (8): non-temporal output stores in the streamlined epilogue
 set -e
