@@ -96,7 +96,8 @@ static bool fast_eligible(const EaGemmParams& p) {
 //        3: 256 x bn, 8 waves 4x2 (64x80), 3-stage                        4: 256 x bn, 4 waves 2x2 (128x80), 3-stage
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
-static int g_force_generic = 0, g_variant = 0, g_force_splits = 0;
+//        13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG (two wave groups alternate MFMA / load phases, ea_gemm2.h)
+static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
   g_force_generic = (f && !strcmp(f, "generic")) ? 1 : 0;
@@ -104,6 +105,8 @@ static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B
   g_variant = (v && *v) ? atoi(v) : 0;
   const char* sp = getenv("EA_GEMM2_SPLITS");   // tuning sweeps only: force the split-K factor
   g_force_splits = (sp && *sp) ? atoi(sp) : 0;
+  const char* bn = getenv("EA_GEMM2_BN");         // tuning sweeps only: 128 forces 128-wide column tiles
+  g_force_bn = (bn && *bn) ? atoi(bn) : 0;
 }
 
 // Cost model (microseconds) that picks tile height (64 / 128 rows) and split-K factor.  Fitted to the forced
@@ -135,16 +138,17 @@ static double plan_cost(int bm, int bn, int M, int N, int K, int batch, int s, i
   return cost;
 }
 
-static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv) {
+static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv, int geglu = 0) {
   read_env();
   Plan2 t;
   t.bn = (N % 160 == 0) ? 160 : 128;
+  if (g_force_bn == 128 && !geglu) t.bn = 128;   // tuning sweeps only (EA_GEMM2_BN)
   const int nk = K / EA_BK;
   double best = 1e30;
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10) ? 128 : 256;
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10) ? 128 : 256;   // 3..6, 8, 13: 256 rows
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
@@ -184,7 +188,7 @@ static int launch_reduce(EaGemmParams& p, void* stream) {
 }
 
 static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
-  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv);
+  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU);
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
@@ -239,6 +243,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 9: if (t.bn == 160) EA_LAUNCH_G2(64, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(64, 128, 2, 2, 2, 16, 0); break;
     case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
     case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
+    case 13: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 2); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 2); break;   // ping-pong
     case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
     default: return EA_ERR_UNSUPPORTED;
   }

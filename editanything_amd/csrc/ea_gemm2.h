@@ -374,7 +374,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
           if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[ks & 1][i], fb[ks & 1][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
           else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[ks & 1][i], fb[ks & 1][j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
         }
-        if (ILV) {
+        if (ILV == 1) {
           // MFMA group g of G: issue the pieces [g*PIECES/G, (g+1)*PIECES/G) of the next tile
           constexpr int G = KSTEPS * MI;
           const int g = ks * MI + i;
@@ -454,6 +454,120 @@ void ea_gemm2_kernel(EaGemmParams p) {
       if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
 #endif
     }
+  } else if (ILV == 2) {
+    // ---- ping-pong (8 waves, 3-deep ring).  The waves form two groups, G0 = waves [0, NW/2) and G1 = the rest; the
+    // hardware places wave i on SIMD i % 4, so every SIMD hosts one wave of each group.  A K tile takes two barrier
+    // intervals ("slots"): in slot A group 0 runs its 40 MFMAs for tile kt purely from registers while group 1 is in
+    // its load phase (all fragment reads of tile kt into registers + the DMA issue of its pieces of tile kt + 2); in
+    // slot B the roles swap.  The matrix pipe of a SIMD therefore alternates between its two waves and never waits
+    // for an LDS read or a VMEM issue burst of the wave that feeds it (the lock-step structure above pays DMA issue +
+    // LDS latency + MFMA in sequence, all waves at once).
+    //   G0, tile kt:  slot A  MFMA(kt); vmcnt(0) [its pieces of tile kt+1, issued a slot ago]; barrier
+    //                 slot B  read frags(kt+1); issue its pieces of tile kt+2; lgkmcnt(0); barrier
+    //   G1, tile kt:  slot A  read frags(kt);   issue its pieces of tile kt+2; lgkmcnt(0); barrier
+    //                 slot B  MFMA(kt); vmcnt(0) [its pieces of tile kt+2]; barrier
+    // RAW: every piece of tile t is waited for (by its issuing wave) before a barrier that precedes the first read of
+    // tile t (G0 reads it in slot B(t-1), G1 in slot A(t)).  WAR: tile kt+2 reuses the buffer of tile kt-1, whose last
+    // reads (G1 in slot A(kt-1), G0 in slot B(kt-2)) retired -- lgkmcnt(0) before a barrier -- at least one barrier
+    // before the first piece of tile kt+2 is issued (G1 in slot A(kt)).
+    static_assert(ILV != 2 || (NW == 8 && MT == 16 && !LDR), "ping-pong: 8 MFMA waves, 16x16x32");
+    constexpr int B_EXTRA = B_INSTR % NW;
+    static_assert(A_INSTR % NW == 0, "A rows must divide evenly over the waves");
+    constexpr int PER_TILE_LO = A_PW + B_INSTR / NW;
+    const int grp = wave / (NW / 2);
+    // Fragments of one K tile: both K steps of B (2 x NI) and the FIRST step of A are read in the load phase; the second
+    // step's A fragments are read inside the MFMA phase, each into the register of the first-step fragment it replaces
+    // (row tile i is finished after NI MFMAs), 15+ MFMAs before their first use -- 56 fragment registers instead of 72
+    // (at 72 the kernel spilled into the K loop: two waves per SIMD leave 256 registers per wave).
+    f16x8 pfa[MI], pfb[2][NI];
+    const char* pp_sa = smem;
+    auto pp_load = [&](int buf) {
+      const char* sa = smem + buf * STAGE_BYTES;
+      const char* sb = sa + BM * 128;
+      pp_sa = sa;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int r = wm * WTM + i * MT + frow;
+        pfa[i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((fq ^ ea_swz(r)) << 4));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks * 4 + fq;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int r = wn * WTN + j * MT + frow;
+          pfb[ks][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        }
+      }
+    };
+    auto pp_mfma = [&]() {
+#ifndef EA_EMU
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(pfa[i], pfb[ks][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+          if (ks == 0) {
+            const int r = wm * WTM + i * MT + frow;
+            pfa[i] = *reinterpret_cast<const f16x8*>(pp_sa + r * 128 + (((4 + fq) ^ ea_swz(r)) << 4));
+          }
+        }
+#ifndef EA_EMU
+      // pin the source order (row tile i's NI MFMAs, then its second-step read): left alone, hipcc sinks two of the four
+      // reads to just before their first use and stalls the matrix pipe on the LDS round trip
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+    auto ring = [](int t) { return t % 3; };
+    // prologue = the virtual tile -1: everyone stages tile 0, G1 also tile 1; G0 loads frags(0) and stages tile 1
+    if (nk > 0) issue_tile(0);
+    if (grp == 1 && nk > 1) issue_tile(1);
+    if (grp == 1 && nk > 1) {
+      if (B_EXTRA != 0 && wave < B_EXTRA) ea_wait_dma<PER_TILE_LO + 1>();
+      else ea_wait_dma<PER_TILE_LO>();
+    } else {
+      ea_wait_dma<0>();
+    }
+    ea_raw_barrier();
+    if (grp == 0) {
+      if (nk > 0) pp_load(0);
+      if (nk > 1) issue_tile(1);
+    } else {
+      ea_wait_dma<0>();
+    }
+    ea_raw_barrier();
+    // one loop per group (no control-flow merges inside the K loop: a shared loop makes the fragment registers loop-
+    // carried PHIs of both roles and hipcc spills ~36 registers into the loop); both execute two barriers per tile
+    const bool do_mfma = p.debug != 10, do_dma = p.debug != 11;   // ablation knobs (tools/gemm_bench --debug): staging only / compute only
+    if (grp == 0) {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (do_mfma) pp_mfma();                                 // slot A
+        ea_wait_dma<0>();
+        ea_raw_barrier();
+        if (kt + 1 < nk && do_mfma) pp_load(ring(kt + 1));      // slot B
+        if (kt + 2 < nk && do_dma) issue_tile(ring(kt + 2));
+        ea_raw_barrier();
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (do_mfma) pp_load(ring(kt));                         // slot A
+        if (kt + 2 < nk && do_dma) issue_tile(ring(kt + 2));
+        ea_raw_barrier();
+        if (do_mfma) pp_mfma();                                 // slot B
+        ea_wait_dma<0>();
+        ea_raw_barrier();
+      }
+    }
   } else {
     // 3-deep ring, two tiles in flight: at iteration kt wait until only tile kt+1's DMA group is outstanding (counted
     // vmcnt), barrier (tile kt visible to all waves; all waves are past compute(kt-1), whose buffer tile kt+2 reuses),
@@ -483,7 +597,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
         } else {
           compute_tile(cur);
         }
-      } else if (ILV) {
+      } else if (ILV == 1) {
         const bool more = kt + 2 < nk;
         if (more) begin_issue(cur >= 1 ? cur - 1 : 2);   // (cur + 2) % 3
         compute_tile(cur, more);
@@ -646,6 +760,24 @@ void ea_gemm2_kernel(EaGemmParams p) {
     const long long cb0 = (long long)batch * p.strideC, rb0 = (long long)batch * p.strideR;
     f16* outp = (f16*)e.out + cb0;
     const f16* resp = e.residual ? e.residual + rb0 : nullptr;
+    // Residual rows are fetched up to RD slabs ahead: with the load inside the slab body every slab paid a full memory
+    // round trip (all waves of the chip are in their epilogues at once, nothing else hides it) -- 4 slabs x ~1.5 us of
+    // a 15-us epilogue on the [32768 x 320] residual launches.
+    constexpr int RD = NSLABF < 4 ? NSLABF : 4;
+    f16x8 rq[RD][NV];
+    auto res_load = [&](int slab_, int slot_) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int id = lane + 64 * v;
+        const int row = id / VPR, c = id - row * VPR;
+        const int m = m0 + wm * WTM + slab_ * SLABF + row, n = colbase + c * 8;
+        if (id < SLABF * VPR && m < p.M && n < e.N) rq[slot_][v] = ea_ld8(resp + (long long)m * e.ldr + n);
+      }
+    };
+    if (resp) {
+#pragma unroll
+      for (int s_ = 0; s_ < RD; ++s_) res_load(s_, s_);
+    }
     // fully unrolled over the slabs: with a runtime slab index the compiler hoists the (slab-invariant) bias /
     // activation arithmetic of ALL accumulators out of the loop and spills
 #pragma unroll
@@ -668,7 +800,6 @@ void ea_gemm2_kernel(EaGemmParams p) {
       ea_wave_lds_sync();
       const int mrow0 = m0 + wm * WTM + slab * SLABF;
       f32x4 lo[NV], hi[NV];
-      f16x8 rr[NV];
       int off[NV];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -680,15 +811,15 @@ void ea_gemm2_kernel(EaGemmParams p) {
         const float* sp = wst + (ok ? row * SLDF + c * 8 : 0);
         lo[v] = *reinterpret_cast<const f32x4*>(sp);
         hi[v] = *reinterpret_cast<const f32x4*>(sp + 4);
-        if (resp && ok) rr[v] = ea_ld8(resp + (long long)m * e.ldr + n);
       }
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         if (off[v] < 0) continue;
         f16x8 h;
         if (resp) {
+          const f16x8 rr = rq[slab % RD][v];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { h[j] = (f16)(lo[v][j] + (float)rr[v][j]); h[4 + j] = (f16)(hi[v][j] + (float)rr[v][4 + j]); }
+          for (int j = 0; j < 4; ++j) { h[j] = (f16)(lo[v][j] + (float)rr[j]); h[4 + j] = (f16)(hi[v][j] + (float)rr[4 + j]); }
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { h[j] = (f16)lo[v][j]; h[4 + j] = (f16)hi[v][j]; }
@@ -699,6 +830,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
         ea_st8(outp + off[v], h);
 #endif
       }
+      if (resp && slab + RD < NSLABF) res_load(slab + RD, slab % RD);
       ea_wave_lds_sync();
     }
     EA_STAMP(4);

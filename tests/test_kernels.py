@@ -113,7 +113,7 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 9, 10, 11, 13])
 def test_gemm_geglu_streamlined_epilogue_variants(kb, variant, monkeypatch):
     """The streamlined GEGLU epilogue (no residual, 80-row packing) in every instantiation that carries it, with a
     scalar scale and ragged M; kinds 5 (32x32x16 MFMA) takes the general path and must agree too."""
@@ -132,7 +132,7 @@ def test_gemm_geglu_streamlined_epilogue_variants(kb, variant, monkeypatch):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("M,N,K,act,gb", [(300, 160, 512, 0, 0), (256, 320, 192, 3, 80), (260, 128, 64, 1, 0),
                                           (128, 160, 2048, 0, 0)])
 def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
@@ -158,7 +158,7 @@ def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
     assert relerr(kb.down(out), ref.numpy()) < 2e-3
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_conv_fast_path_variants(kb, variant, monkeypatch):
     monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
     B, H, W_, c1, c2, cout = 2, 12, 12, 64, 64, 160
@@ -174,7 +174,7 @@ def test_conv_fast_path_variants(kb, variant, monkeypatch):
     assert relerr(kb.down(out), ref.permute(0, 2, 3, 1).numpy()) < 3e-3
 
 
-@pytest.mark.parametrize("variant", [1, 4, 5, 9, 10, 12])
+@pytest.mark.parametrize("variant", [1, 4, 5, 9, 10, 12, 13])
 def test_gemm_fast_epilogue_options(kb, variant, monkeypatch):
     """Every epilogue operand of the LDS-DMA kernel's vector path: time-embedding row vector, per-row scale map,
     scalar scale, fp32 residual, fp32 out; then bias-per-row; then a ragged N (N % 8 != 0 -> scalar-capable path)."""

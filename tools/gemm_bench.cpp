@@ -130,16 +130,18 @@ int main(int argc, char** argv) {
     return 1;
   }
   std::string cases_sel = "all", out_path;
-  std::vector<std::string> variants = {"auto"}, debugs = {"0"};
+  std::vector<std::string> variants = {"auto"}, debugs = {"0"}, splits_opt = {"0"};
   int iters = 20, rounds = 3, check = 0;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--cases" && i + 1 < argc) cases_sel = argv[++i];
     else if (a == "--variants" && i + 1 < argc) variants = split(argv[++i], ',');
     else if (a == "--debug" && i + 1 < argc) debugs = split(argv[++i], ',');
+    else if (a == "--splits" && i + 1 < argc) splits_opt = split(argv[++i], ',');   // EA_GEMM2_SPLITS (0 = plan's own)
     else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
     else if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (a == "--check") check = 1;
+    else if (a == "--bn" && i + 1 < argc) setenv("EA_GEMM2_BN", argv[++i], 1);
     else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
   }
   std::vector<Lib> libs;
@@ -218,14 +220,19 @@ int main(int argc, char** argv) {
       HIP_CHECK(hipMemcpy(h_ref.data(), o_ref, h_ref.size() * 2, hipMemcpyDeviceToHost));
     }
     // ---- every (lib, variant, debug) configuration gets a graph; rounds interleave the configurations
-    struct Cfg { int lib; std::string variant, debug; hipGraphExec_t exec; std::vector<float> us; double maxdiff; long long bad; int st; };
+    struct Cfg { int lib; std::string variant, debug, splits; hipGraphExec_t exec; std::vector<float> us; double maxdiff; long long bad; int st; };
     std::vector<Cfg> cfgs;
     for (size_t li = 0; li < libs.size(); ++li)
       for (auto& v : variants)
-        for (auto& d : debugs) cfgs.push_back(Cfg{(int)li, v, d, nullptr, {}, 0.0, 0, 0});
+        for (auto& d : debugs)
+          for (auto& sp : splits_opt) {
+            if (sp != "0" && c.act == EA_ACT_GEGLU && sp != "1") continue;   // GEGLU launches never split
+            cfgs.push_back(Cfg{(int)li, v, d, sp, nullptr, {}, 0.0, 0, 0});
+          }
     for (auto& cf : cfgs) {
       if (cf.variant == "auto") unsetenv("EA_GEMM2_VARIANT"); else setenv("EA_GEMM2_VARIANT", cf.variant.c_str(), 1);
       if (cf.debug == "0") unsetenv("EA_GEMM2_DEBUG"); else setenv("EA_GEMM2_DEBUG", cf.debug.c_str(), 1);
+      if (cf.splits == "0") unsetenv("EA_GEMM2_SPLITS"); else setenv("EA_GEMM2_SPLITS", cf.splits.c_str(), 1);
       cf.st = launch(libs[cf.lib], o_test);   // warm-up (module load, LDS attribute)
       HIP_CHECK(hipStreamSynchronize(stream));
       if (cf.st != 0) continue;
@@ -238,6 +245,7 @@ int main(int argc, char** argv) {
     }
     unsetenv("EA_GEMM2_VARIANT");
     unsetenv("EA_GEMM2_DEBUG");
+    unsetenv("EA_GEMM2_SPLITS");
     for (int r = 0; r < rounds; ++r) {
       for (auto& cf : cfgs) {
         if (!cf.exec) continue;
@@ -262,15 +270,15 @@ int main(int argc, char** argv) {
     for (auto& cf : cfgs) {
       char line[768];
       if (!cf.exec) {
-        snprintf(line, sizeof line, "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"debug\": \"%s\", \"error\": %d}",
-                 c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), cf.debug.c_str(), cf.st);
+        snprintf(line, sizeof line, "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"debug\": \"%s\", \"splits\": \"%s\", \"error\": %d}",
+                 c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), cf.debug.c_str(), cf.splits.c_str(), cf.st);
       } else {
         std::sort(cf.us.begin(), cf.us.end());
         const float best = cf.us.front(), med = cf.us[cf.us.size() / 2];
         int n = snprintf(line, sizeof line,
-                         "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"debug\": \"%s\", \"us\": %.2f, \"us_median\": %.2f, "
+                         "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"debug\": \"%s\", \"splits\": \"%s\", \"us\": %.2f, \"us_median\": %.2f, "
                          "\"tflops\": %.1f, \"mfma_frac\": %.4f",
-                         c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), cf.debug.c_str(), best, med,
+                         c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), cf.debug.c_str(), cf.splits.c_str(), best, med,
                          c.flops / best * 1e-6, c.flops / best * 1e-6 / 2500.0);
         if (check && cf.debug == "0") n += snprintf(line + n, sizeof line - n, ", \"max_abs_diff_vs_generic\": %.5g, \"nan_outputs\": %lld", cf.maxdiff, cf.bad);
         snprintf(line + n, sizeof line - n, "}");
