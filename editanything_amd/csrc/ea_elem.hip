@@ -81,6 +81,32 @@ __global__ __launch_bounds__(256) void ea_add_kernel(const f16* a, const f16* b,
     ea_st8(out + i * 8, ea_ld8(a + i * 8) + ea_ld8(b + i * 8));
 }
 
+// out = sum_k coef[k] * src[k]  (k < 5, NULL sources skipped), optionally blended through a mask with a second
+// combination: out = mask * main + (1 - mask) * (coef[5] * alt0 + coef[6] * alt1).  The multistep sampler update
+// (UniPC predictor / corrector: a linear combination of the sample and the stored x0 predictions with per-step scalar
+// coefficients) and the inpaint re-noise blend; coefficients come from a device buffer so a captured step replays.
+__global__ __launch_bounds__(256) void ea_lincomb_kernel(const float* s0, const float* s1, const float* s2, const float* s3,
+                                                        const float* s4, const float* coef, const float* mask,
+                                                        const float* alt0, const float* alt1, float* out, long long n) {
+  const float c0 = coef[0], c1 = coef[1], c2 = coef[2], c3 = coef[3], c4 = coef[4], e0 = coef[5], e1 = coef[6];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = 0.0f;
+    if (s0) v += c0 * s0[i];
+    if (s1) v += c1 * s1[i];
+    if (s2) v += c2 * s2[i];
+    if (s3) v += c3 * s3[i];
+    if (s4) v += c4 * s4[i];
+    if (mask) {
+      float a = 0.0f;
+      if (alt0) a += e0 * alt0[i];
+      if (alt1) a += e1 * alt1[i];
+      const float mk = mask[i];
+      v = mk * v + (1.0f - mk) * a;
+    }
+    out[i] = v;
+  }
+}
+
 static unsigned grid_for(long long n) {
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;  // 256 CUs x 8 workgroups, grid-stride the rest
@@ -120,6 +146,16 @@ extern "C" int ea_cfg_ddim_step(const float* x, const float* eps_c, const float*
   auto kfn = ea_cfg_ddim_kernel;
   EA_LAUNCH(kfn, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, noise, coef, mask, x_orig, noise_orig,
             x_prev, pred_x0, n);
+  return ea_launch_status();
+}
+
+extern "C" int ea_lincomb_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
+                              const float* coef, const float* mask, const float* alt0, const float* alt1, float* out,
+                              long long n, void* stream) {
+  if (!coef || !out) return EA_ERR_BAD_ARG;
+  if (n <= 0) return EA_ERR_BAD_SHAPE;
+  auto kfn = ea_lincomb_kernel;
+  EA_LAUNCH(kfn, dim3(grid_for(n)), dim3(256), 0, stream, s0, s1, s2, s3, s4, coef, mask, alt0, alt1, out, n);
   return ea_launch_status();
 }
 

@@ -28,7 +28,7 @@ import torch
 from PIL import Image
 
 from . import host
-from .pipeline import randn_tensor
+from .pipeline import StableDiffusionControlNetInpaintMixingPipeline, randn_tensor
 
 config_dict = OrderedDict([
     ("LAION Pretrained(v0-4)-SD15", "shgao/edit-anything-v0-4-sd15"),
@@ -274,6 +274,8 @@ class EditAnythingLoraModel:
             kw = {}
             if scale_map is not None:
                 kw["controlnet_conditioning_scale_map"] = scale_map
+            if isinstance(self.pipe, StableDiffusionControlNetInpaintMixingPipeline):     # :812-828
+                kw["alpha_weight"] = alpha_weight
             x_samples = self.pipe(image=img, mask_image=mask_image, prompt_embeds=pe, negative_prompt_embeds=ne,
                                   num_images_per_prompt=num_samples, num_inference_steps=ddim_steps,
                                   generator=generator, controlnet_conditioning_image=cond_images, height=H, width=W,
@@ -293,6 +295,10 @@ class EditAnythingLoraModel:
             common = dict(mask_image=mask_tile, prompt_embeds=tpe, negative_prompt_embeds=tne,
                           num_inference_steps=ddim_steps, height=th, width=tw, controlnet_conditioning_scale=1.0,
                           alignment_ratio=refine_alignment_ratio, guidance_scale=scale, guess_mode=guess_mode)
+            if isinstance(self.pipe, StableDiffusionControlNetInpaintMixingPipeline):     # :900-917
+                common["alpha_weight"] = alpha_weight
+                if scale_map is not None:
+                    common["controlnet_conditioning_scale_map"] = scale_map
             if self.batch_tile and num_samples > 1:
                 lat, vn = draw_call_noise(generator, num_samples, (1, 4, th // 8, tw // 8), self.device)
                 batch = np.stack(tiles)

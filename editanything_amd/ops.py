@@ -356,6 +356,20 @@ def cfg_ddim_step(x, eps_c, eps_u, coef, noise=None, mask=None, x_orig=None, noi
     return x_prev
 
 
+def lincomb(srcs, coef, out=None, mask=None, alt=(None, None)):
+    """out = sum coef[k] * srcs[k] (k < 5; None skipped) [blended: mask * that + (1 - mask) * (coef[5] * alt[0] +
+    coef[6] * alt[1])].  fp32 tensors of one shape; `coef` a device fp32 tensor of 7."""
+    srcs = list(srcs) + [None] * (5 - len(srcs))
+    ref = next(t for t in srcs if t is not None)
+    _check_dev(ref)
+    if out is None:
+        out = torch.empty_like(ref)
+    st = _lib().ea_lincomb_f32(_p(srcs[0]), _p(srcs[1]), _p(srcs[2]), _p(srcs[3]), _p(srcs[4]), _p(coef), _p(mask),
+                               _p(alt[0]), _p(alt[1]), _p(out), ref.numel(), _stream())
+    L.check(st, "ea_lincomb_f32")
+    return out
+
+
 def nchw_to_nhwc(x, cpad=None, mul=1.0, add=0.0):
     """fp32 NCHW (reference API) -> fp16 NHWC with channels zero-padded to `cpad`."""
     _check_dev(x)

@@ -10,8 +10,10 @@ list-valued `controlnet_conditioning_image` / `controlnet_conditioning_scale` fo
 
 What is different underneath: the per-step work is `ControlledDenoiser.eps` (NHWC fp16 HIP kernels) plus ONE
 fused CFG + sampler-step (+ inpaint blend) kernel, and the whole step is captured once in a HIP graph and
-replayed (several hundred launches per step otherwise).  Sampler: DDIM in the reference LDM convention
-(cldm/ddim_hacked.py); UniPC exists only inside diffusers (absent) and is not provided.
+replayed (several hundred launches per step otherwise).  Samplers: DDIM in the reference LDM convention
+(cldm/ddim_hacked.py, the parity sampler) and UniPC (`scheduler.UniPCMultistepScheduler`, the one the reference installs;
+restated from the published algorithm because diffusers is absent -- parity unpinned): `pipe.scheduler =
+UniPCMultistepScheduler.from_config(pipe.scheduler)` as in sam2image.py:42.
 Text encoding is outside the hot path: pass `prompt_embeds` / `negative_prompt_embeds`, or give
 the pipeline a `text_encoder` callable (list[str] -> [B, 77, ctx_dim]).
 """
@@ -20,7 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import host, ops
-from .scheduler import DDIMScheduler
+from .scheduler import DDIMScheduler, UniPCMultistepScheduler
 from .unet import ControlledDenoiser
 
 
@@ -199,8 +201,21 @@ class StableDiffusionControlNetInpaintPipeline:
             e_u, e_c = eps.chunk(2)
         else:
             e_u, e_c = None, eps
-        ops.cfg_ddim_step(lat, e_c.contiguous(), None if e_u is None else e_u.contiguous(), st["coef"], noise=st["noise"],
-                          mask=st["blend_mask"], x_orig=st["x_orig"], noise_orig=st["noise_orig"], x_prev=st["lat_out"])
+        e_c, e_u = e_c.contiguous(), None if e_u is None else e_u.contiguous()
+        if st.get("unipc") is None:
+            ops.cfg_ddim_step(lat, e_c, e_u, st["coef"], noise=st["noise"], mask=st["blend_mask"], x_orig=st["x_orig"],
+                              noise_orig=st["noise_orig"], x_prev=st["lat_out"])
+        else:
+            # UniPC (scheduler.py): CFG + x0 prediction from the fused kernel, then corrector and predictor as two
+            # linear combinations whose coefficients sit in device buffers (rows copied in per step)
+            u = st["unipc"]
+            ops.cfg_ddim_step(lat, e_c, e_u, st["coef"], x_prev=u["scratch"], pred_x0=u["m_t"])
+            ops.lincomb([u["last"], u["m0"], u["m1"], u["m_t"], lat], u["coefC"], out=u["lat_c"])
+            u["m1"].copy_(u["m0"])
+            u["m0"].copy_(u["m_t"])
+            u["last"].copy_(u["lat_c"])
+            ops.lincomb([u["lat_c"], u["m0"], u["m1"]], u["coefP"], out=st["lat_out"], mask=st["blend_mask"],
+                        alt=(st["x_orig"], st["noise_orig"]))
         lat.copy_(st["lat_out"])
 
     # ------------------------------------------------------------------ __call__
@@ -210,7 +225,7 @@ class StableDiffusionControlNetInpaintPipeline:
                  num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
                  cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
-                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, **unused):
+                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None, **unused):
         if controlnet_conditioning_image is None and "control_image" in unused:
             controlnet_conditioning_image = unused.pop("control_image")
         cond_images = controlnet_conditioning_image
@@ -282,8 +297,14 @@ class StableDiffusionControlNetInpaintPipeline:
                 blend_mask = (1 - keep).contiguous()         # 1 where the sample is generated
         self._mark("inputs+vae_encode")
         self.denoiser.only_mid_control = False
-        step_noise = eta > 0
-        in_loop_blend = x_orig is not None and alignment_ratio is not None
+        unipc = isinstance(sch, UniPCMultistepScheduler)
+        step_noise = eta > 0 and not unipc          # UniPC's step() takes no eta (prepare_extra_step_kwargs drops it)
+        # alpha-weighted mixing (StableDiffusionControlNetInpaintMixingPipeline, …inpaint.py:1707-2088): its own blend
+        # after every step (below) replaces the alignment_ratio blend of the plain pipeline and the final fill
+        mixing = alpha_weight is not None and x_orig is not None
+        if mixing and alignment_ratio is None:
+            raise TypeError("the mixing pipeline compares `i < len(timesteps) * alignment_ratio`: pass alignment_ratio")
+        in_loop_blend = x_orig is not None and alignment_ratio is not None and not mixing
         # One denoising step is captured ONCE per (shapes, mode) and replayed by every later call: the graph reads the
         # latents / text K,V / hint features / inpaint tensors from static buffers that later calls overwrite in place.
         # Control scales are baked into the captured launches, so they are part of the key; per-pixel scale maps are
@@ -291,10 +312,13 @@ class StableDiffusionControlNetInpaintPipeline:
         gkey = None
         if self.use_graph and not step_noise and not in_loop_blend and \
                 all(not torch.is_tensor(v) for sc in per_net for v in sc):
-            gkey = (n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
+            gkey = (type(sch).__name__, n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
                     tuple(tuple(h.shape) for h in hints), tuple(tuple(sc) for sc in per_net))
         ent = self._graphs.get(gkey) if gkey is not None else None
-        coef_table = sch.coef_table(guidance_scale, self.device)
+        if unipc:
+            coef_table, coef_c_table, coef_p_table = sch.coef_tables(guidance_scale, self.device)
+        else:
+            coef_table = sch.coef_table(guidance_scale, self.device)
         nb = 2 * n_img if do_cfg else n_img
         if ent is not None:
             self.denoiser.prepare(embeds, hints, per_net, static=ent["den"])
@@ -307,6 +331,9 @@ class StableDiffusionControlNetInpaintPipeline:
                 st["noise_orig"].copy_(noise0)
             x_orig = st["x_orig"]
             graph = ent["graph"]
+            if unipc:
+                for k in ("m_t", "m0", "m1", "last", "lat_c"):
+                    st["unipc"][k].zero_()
         else:
             self.denoiser.prepare(embeds, hints, per_net)
             st = dict(lat=lat.contiguous(), lat_out=torch.empty_like(lat),
@@ -314,14 +341,24 @@ class StableDiffusionControlNetInpaintPipeline:
                       extra=extra, noise=None, blend_mask=None, x_orig=x_orig,
                       noise_orig=noise0 if x_orig is not None else None)
             graph = None
+            if unipc:
+                z = lambda: torch.zeros_like(st["lat"])
+                st["unipc"] = dict(m_t=z(), m0=z(), m1=z(), last=z(), lat_c=z(), scratch=z(),
+                                   coefC=coef_c_table[0].clone(), coefP=coef_p_table[0].clone())
         # every step's time-embedding rows in one shot; step i copies row i into the static [1, sum(Cout)] buffers
         emb_tables = self.denoiser.time_embeddings(torch.as_tensor(timesteps.astype(np.int64), device=self.device))
         if st.get("embs") is None:
             st["embs"] = [tb[:1].clone() for tb in emb_tables]
         self._mark("prepare(hint,text kv)")
+        mix_gen = generator if not isinstance(generator, list) else generator[0]
+        if mixing:   # …inpaint.py:1968-1975: the kept region starts from the re-noised original, the rest from pure noise
+            self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[0])]), 0.0, True, mix_gen)
         for i in range(nsteps):
             st["t"].fill_(int(timesteps[i]))
             st["coef"].copy_(coef_table[i])
+            if unipc:
+                st["unipc"]["coefC"].copy_(coef_c_table[i])
+                st["unipc"]["coefP"].copy_(coef_p_table[i])
             for dst, tb in zip(st["embs"], emb_tables):
                 dst.copy_(tb[i:i + 1])
             st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
@@ -338,9 +375,12 @@ class StableDiffusionControlNetInpaintPipeline:
                 self._step(st)
             if callback is not None and i % callback_steps == 0:
                 callback(i, int(timesteps[i]), st["lat"])
+            if mixing and i < nsteps - 1:     # …inpaint.py:2039-2051
+                self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[i + 1])]),
+                                float(alpha_weight), i < nsteps * alignment_ratio, mix_gen)
         lat = st["lat"]
         self._mark("denoise loop")
-        if x_orig is not None and (alignment_ratio is None or alignment_ratio == 1.0):
+        if x_orig is not None and not mixing and (alignment_ratio is None or alignment_ratio == 1.0):
             lat = x_orig * (1 - blend_mask) + lat * blend_mask     # fill the kept region with the original
         if output_type == "latent":
             images = lat.clone() if lat is st["lat"] else lat      # never hand out the graph's static buffer
@@ -352,6 +392,22 @@ class StableDiffusionControlNetInpaintPipeline:
         if not return_dict:
             return images, None
         return StableDiffusionPipelineOutput(images, None)
+
+    def _mix_blend(self, lat, x_orig, gen_mask, a_next, alpha, renoise_kept, generator):
+        """In place, with proper = sqrt(a) * x_orig + sqrt(1 - a) * fresh noise (scheduler.add_noise at the next timestep):
+            generated region (gen_mask = 1):  (1 - alpha) * lat + alpha * proper
+            kept region      (gen_mask = 0):  proper if `renoise_kept` else lat
+        One `ea_lincomb_f32` launch.  The reference draws the fresh noise with torch.randn_like on the device's global
+        RNG (…inpaint.py:1975, 2041); here it comes from the call's generator, so a seeded call is reproducible."""
+        noise = randn_tensor(lat.shape, generator, self.device)
+        c1, c2 = a_next ** 0.5, (1.0 - a_next) ** 0.5
+        if renoise_kept:
+            coef, alt = [1.0 - alpha, alpha * c1, alpha * c2, 0.0, 0.0, c1, c2], (x_orig, noise)
+        else:
+            coef, alt = [1.0 - alpha, alpha * c1, alpha * c2, 0.0, 0.0, 1.0, 0.0], (lat, None)
+        out = ops.lincomb([lat, x_orig, noise], torch.tensor(coef, dtype=torch.float32, device=self.device),
+                          mask=gen_mask, alt=alt)
+        lat.copy_(out)
 
     def _capture(self, st):
         """Warm up once on a side stream (restoring the latents), then capture ONE step into a HIP graph."""
@@ -388,6 +444,15 @@ class StableDiffusionControlNetInpaintPipeline:
             m = F.interpolate(sm, size=(hh, ww), mode="bilinear", align_corners=False).reshape(-1) * b
             rows.append(m.repeat(nb).contiguous())
         return rows
+
+
+class StableDiffusionControlNetInpaintMixingPipeline(StableDiffusionControlNetInpaintPipeline):
+    """…inpaint.py:1707-2088: the same call with `alpha_weight` (default 0.5) -- after every step the generated region is
+    pulled towards the re-noised original by alpha and the kept region is re-noised (first `alignment_ratio` of the
+    steps) or left alone.  4-channel UNets only (the 9-channel inpainting UNet has no such blend, :2039)."""
+
+    def __call__(self, *args, alpha_weight=0.5, **kw):
+        return super().__call__(*args, alpha_weight=alpha_weight, **kw)
 
 
 class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline):

@@ -25,6 +25,8 @@
  *                             <- BasicTransformerBlock / GEGLU / SpatialTransformer Linears
  *                                ldm/modules/attention.py:49-76,152-160,263-275,316-339
  *   ea_cfg_ddim_step          <- DDIMSampler.p_sample_ddim, cldm/ddim_hacked.py:187-231
+ *   ea_lincomb_f32            <- UniPCMultistepScheduler.step (diffusers, 3rd party; set at sam2image.py:42) and the
+ *                                alpha-weighted latent blends of ...inpaint.py:2039-2051
  *
  * Conventions: every pointer is a DEVICE pointer owned by the caller (PyTorch
  * allocates; the library never allocates, frees or synchronises); activations
@@ -168,6 +170,15 @@ int ea_softmax_rows_f32_f16(const float* x, void* out, int rows, int cols, float
 int ea_cfg_ddim_step(const float* x, const float* eps_c, const float* eps_u, const float* noise,
                      const float* coef, const float* mask, const float* x_orig, const float* noise_orig,
                      float* x_prev, float* pred_x0, long long n, void* stream);
+
+/* Multistep sampler update / inpaint blend: out = sum_{k<5} coef[k] * s_k (NULL sources skipped); with `mask`:
+ * out = mask * (that sum) + (1 - mask) * (coef[5] * alt0 + coef[6] * alt1).  All fp32 [n]; `coef` is a DEVICE buffer of
+ * 7 floats (a captured step replays with new coefficients).  Replaces the per-step tensor arithmetic of diffusers'
+ * UniPCMultistepScheduler.step (the scheduler sam2image.py:42 / editany_lora.py:384 install; third party) and the
+ * re-noise blend of utils/stable_diffusion_controlnet_inpaint.py:1647-1664, 2039-2051. */
+int ea_lincomb_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
+                   const float* coef, const float* mask, const float* alt0, const float* alt1, float* out,
+                   long long n, void* stream);
 
 /* SAM mask post-processing in one pass (Sam.postprocess_masks + calculate_stability_score + batched_mask_to_box of
  * segment_anything, third party): low_res fp32 [n][lh][lw] logits -> mask uint8 [n][H][W] (logit > threshold at the

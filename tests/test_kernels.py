@@ -581,6 +581,27 @@ def test_cfg_ddim_step(kb, cfg, vpred, inpaint, eta):
     assert relerr(kb.down(xp), rp) < 1e-5 and relerr(kb.down(x0), r0) < 1e-5
 
 
+@pytest.mark.parametrize("blend", [False, True])
+def test_lincomb(kb, blend):
+    """ea_lincomb_f32: the multistep-sampler update (linear combination with device-resident coefficients, NULL sources
+    skipped) and the masked re-noise blend."""
+    n = 3 * 4 * 8 * 8 + 5
+    srcs = [f32(n) for _ in range(5)]
+    alt0, alt1 = f32(n), f32(n)
+    mask = (RNG.random(n) > 0.4).astype(np.float32)
+    coef = np.array([0.7, -1.3, 0.25, 2.0, -0.5, 0.9, 0.1], np.float32)
+    out = kb.zeros(n, np.float32)
+    st = kb.lib.ea_lincomb_f32(ptr(srcs[0]), ptr(srcs[1]), None, ptr(srcs[3]), ptr(srcs[4]), ptr(coef),
+                               ptr(mask) if blend else None, ptr(alt0) if blend else None, ptr(alt1) if blend else None,
+                               ptr(out), n, kb.stream)
+    assert st == 0
+    ref = coef[0] * srcs[0] + coef[1] * srcs[1] + coef[3] * srcs[3] + coef[4] * srcs[4]      # source 2 is NULL: skipped
+    if blend:
+        ref = mask * ref + (1 - mask) * (coef[5] * alt0 + coef[6] * alt1)
+    assert relerr(kb.down(out), ref) < 1e-6
+    assert kb.lib.ea_lincomb_f32(ptr(srcs[0]), None, None, None, None, None, None, None, None, ptr(out), n, kb.stream) == -2
+
+
 def test_layout_roundtrip(kb):
     B, Cc, H, W, Cpad = 2, 4, 5, 6, 8
     x = f32(B, Cc, H, W)
