@@ -221,3 +221,47 @@ def test_state_dict_file_unwraps_nesting(tmp_path):
     p2 = str(tmp_path / "x.safetensors")
     convert.save_state_dict_file(sd, p2)
     assert torch.equal(convert.load_state_dict_file(p2)["a"], sd["a"])
+
+
+@pytest.mark.gpu
+def test_gpu_from_pretrained_diffusers_folders_equals_direct_construction(tmp_path):
+    """`Pipe.from_pretrained(base, controlnet=[...])` (sam2image.py:36-46, editany_lora.py:340-386) for LOCAL
+    diffusers-format folders, LoRA merged at load time (editany_lora.py:197-329): the pipeline built from the folders
+    must reproduce the pipeline built directly from the same (LDM-named, LoRA-merged) state dicts."""
+    from safetensors.torch import save_file
+    from editanything_amd import lora, models
+    ucfg, ccfg, vcfg = arch.TINY_UNET, arch.TINY_CONTROLNET, arch.TINY_VAE
+    usd = synth.synth_state_dict_torch(arch.unet_param_shapes(ucfg), 11)
+    vsd = synth.synth_state_dict_torch(arch.vae_param_shapes(vcfg), 12)
+    c1 = synth.synth_state_dict_torch(arch.unet_param_shapes(ccfg, controlnet=True), 13)
+    c2 = synth.synth_state_dict_torch(arch.unet_param_shapes(ccfg, controlnet=True), 14)
+    base = str(tmp_path / "base")
+    convert.save_diffusers_component(os.path.join(base, "unet"), "unet", ucfg, usd)
+    convert.save_diffusers_component(os.path.join(base, "vae"), "vae", vcfg, vsd)
+    os.makedirs(os.path.join(base, "scheduler"))
+    json.dump({"prediction_type": "epsilon", "beta_start": 0.00085, "beta_end": 0.012, "num_train_timesteps": 1000},
+              open(os.path.join(base, "scheduler", "scheduler_config.json"), "w"))
+    cdirs = [str(tmp_path / "cn1"), str(tmp_path / "cn2")]
+    convert.save_diffusers_component(cdirs[0], "controlnet", ccfg, c1)
+    convert.save_diffusers_component(cdirs[1], "controlnet", ccfg, c2, safetensors=False)
+    # a kohya-style LoRA on one attention projection (rank 4)
+    g = torch.Generator().manual_seed(0)
+    key = "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight"
+    n = usd[key].shape[0]
+    lsd = {"lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_up.weight": 0.05 * torch.randn(n, 4, generator=g),
+           "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.lora_down.weight": 0.05 * torch.randn(4, n, generator=g),
+           "lora_unet_down_blocks_0_attentions_0_transformer_blocks_0_attn1_to_q.alpha": torch.tensor(2.0)}
+    lpath = str(tmp_path / "lora.safetensors")
+    save_file(lsd, lpath)
+    pipe = models.from_pretrained(base, cdirs, device="cuda", lora=lpath, lora_weight=0.8)
+    merged, _ = lora.merge_lora(usd, lsd, 0.8, layers_per_block=ucfg["num_res_blocks"])
+    assert float((merged[key] - usd[key]).abs().max()) > 0
+    direct = models.build_pipeline_from_configs(ucfg, merged, [(ccfg, c1), (ccfg, c2)], vcfg, vsd, device="cuda")
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    hint = torch.rand(1, 3, 128, 128, generator=g) * 255
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, controlnet_conditioning_image=[hint, hint / 255],
+              controlnet_conditioning_scale=[1.0, 0.5], num_inference_steps=4, guidance_scale=7.5, height=128, width=128,
+              output_type="latent", latents=torch.randn(1, 4, 16, 16, generator=g))
+    a, b = pipe(**kw).images, direct(**kw).images
+    assert not torch.isnan(a).any() and float((a - b).norm() / b.norm()) <= 1e-5
+    assert isinstance(pipe.controlnet, list) and len(pipe.controlnets) == 2 and pipe.text_encoder is None
