@@ -184,11 +184,34 @@ def roofline_leg(one_step, pipe, args):
     other_t = sum(r[1].elapsed_time(r[2]) for r in recs if not r[3].startswith(("gemm", "conv"))) * 1e-3
     n = len(mm)
     achieved = tot_f / tot_t / 1e12
+    traffic, traffic_note = pmc_traffic()
     return {"bound": "mfma", "kernel": "ea_gemm2_kernel / ea_gemm_kernel (MFMA implicit-GEMM conv3x3/1x1 + linear)",
             "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": None, "launches_per_step": n,
+            "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
+            "launches_per_step": n,
             "avg_launch_us": round(tot_t / n * 1e6, 2), "algorithmic_gflop_per_launch": round(tot_f / n / 1e9, 3),
             "contraction_ms_per_step": round(tot_t * 1e3, 2), "attention_norm_ms_per_step": round(other_t * 1e3, 2)}
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_summary.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE ...` runs of tools/pmc_cases.py, per-dispatch averages).
+    Counters cannot be read inside this process, so this is the mean over the PMC population (six dominant launch
+    shapes of one evaluation), NOT over this run's launches: bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB), FETCH_SIZE
+    doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950.  null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, "no PMC summary under profiles/"
+    vals = [(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in ks.items()
+            if "ea_gemm2_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
+    if not vals:
+        return None, "no ea_gemm2_kernel dispatches in the PMC summary"
+    return round(sum(vals) / len(vals)), ("bytes per launch, mean over the %d ea_gemm2_kernel dispatch classes of the separate "
+                                          "--pmc passes (profiles/r01_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE); per class "
+                                          "vs algorithmic bytes: DESIGN.md section 8b" % len(vals))
 
 
 def cpu_baseline(sds, args):
