@@ -142,7 +142,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
   static_assert(MT == 16 || MT == 32, "MFMA tile");
-  static_assert(!ILV || STAGES == 3, "interleaved issue needs the 3-deep ring (a full iteration of latency budget)");
+  static_assert(ILV == 0 || ILV == 3 || STAGES == 3, "interleaved issue / ping-pong need the 3-deep ring");
   static_assert(WTM % MT == 0 && WTN % MT == 0, "wave tile must be a whole number of MFMA tiles");
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
@@ -453,6 +453,132 @@ void ea_gemm2_kernel(EaGemmParams p) {
       if (kt + 1 < nk && p.debug != 11 && p.debug != 12) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
       if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
 #endif
+    }
+  } else if (ILV == 3) {
+    // ---- 3x3 convolution over an input HALO tile (stride 1, pad 1, no upsampling; opt-in kind 14).
+    // The im2col loop above stages the A tile nine times per 64-channel chunk -- once per tap, 16 KiB each for a 128-row
+    // tile -- although the nine tiles are shifted views of the same (TH + 2) x (W + 2) pixel neighbourhood.  Here that
+    // halo (W = 32: 6 x 34 pixels x 128 B = 25.5 KiB) is staged ONCE per chunk and the nine taps read their A
+    // fragments from it at a wave-uniform row offset ky * (W + 2) + kx; only the weight tile (BN x 64) still streams
+    // per K tile.  L2 -> LDS traffic per chunk: halo + 9 weight tiles = 206 KiB instead of 324 KiB at W = 32 (the PMC
+    // passes put the im2col form at 6x the algorithmic HBM-side bytes on the 32^2-level convolutions).
+    // K is walked chunk-major (chunk, tap) instead of tap-major: the same products, another fp32 summation order.
+    // Geometry (checked on the host, ea_gemm.hip halo_eligible): W a power of two, 16 <= W <= 64; a 128-row tile is
+    // TH = 128 / W whole image rows of one image (H * W % 128 == 0).  LDS: [2 weight stages][halo], <= 73 KiB, so two
+    // workgroups share a CU as in the im2col kernel.
+    // Synchronisation, first version: full DMA drains (vmcnt(0)) at every barrier -- the weight tile of K tile kt+1 is
+    // in flight during compute(kt), the next chunk's halo is issued after a barrier that follows the last tap's reads
+    // and is exposed once per nine K tiles (the co-resident workgroup covers it).
+    static_assert(ILV != 3 || (BM == 128 && NW == 4 && MT == 16 && STAGES == 2 && !LDR), "halo conv: 128-row 4-wave tiles");
+    constexpr int MAXHP = 9;                      // halo pieces per wave at W = 64 (264 pixels -> 33 1-KiB pieces)
+    const int Wd = p.Win;
+    int lw = 0;
+    while ((1 << lw) < Wd) ++lw;
+    const int HW2 = Wd + 2;
+    const int halo_px = ((BM >> lw) + 2) * HW2;
+    const int hpieces = (halo_px + 7) >> 3;
+    char* wring = smem;
+    char* halo = smem + 2 * BN * 128;
+    const int hwp = p.Hin * Wd;
+    const int bimg = ea_uniform(m0 / hwp);
+    const int y0 = (m0 - bimg * hwp) >> lw;
+    int hpix[MAXHP];                              // source pixel (element index / channels) of this lane's row of piece s; -1 = zero fill
+#pragma unroll
+    for (int s_ = 0; s_ < MAXHP; ++s_) {
+      const int hp = (s_ * NW + wave) * 8 + lrow;
+      const int hy = hp / HW2, hx = hp - hy * HW2;
+      const int iy = y0 - 1 + hy, ix = hx - 1;
+      const bool ok = hp < halo_px && iy >= 0 && iy < p.Hin && ix >= 0 && ix < Wd && m0 < p.M;
+      hpix[s_] = ok ? (bimg * p.Hin + iy) * Wd + ix : -1;
+    }
+    auto issue_halo = [&](int ci) {
+      const int c0 = ea_uniform(ci * EA_BK);
+      const bool second = c0 >= p.c1;
+      const ea_rsrc rs = second ? rs_a2 : rs_a1;
+      const unsigned cs = (unsigned)(second ? p.c2 : p.c1);
+      const unsigned soff = (unsigned)(second ? c0 - p.c1 : c0) * 2u;
+#pragma unroll
+      for (int s_ = 0; s_ < MAXHP; ++s_) {
+        const int k = s_ * NW + wave;
+        if (k < hpieces) {
+          const int hp = k * 8 + lrow;
+          const unsigned voff = hpix[s_] >= 0 ? ((unsigned)hpix[s_] * cs + (unsigned)((slot ^ ea_swz(hp)) * 8)) * 2u : EA_OOB;
+          ea_dma16(rs, voff, soff, halo + k * 1024);
+        }
+      }
+    };
+    auto issue_w = [&](int kt) {
+      const int ci = kt / 9, t = kt - ci * 9;
+      const unsigned soff = (unsigned)ea_uniform(t * ctot + ci * EA_BK) * 2u;
+      char* dst = wring + (kt & 1) * (BN * 128);
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j)
+        if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff, dst + (j * NW + wave) * 1024);
+    };
+    int p0[MI];                                   // halo row of this lane's output pixel for tap (0, 0), per row tile
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int q = wm * WTM + i * MT + frow;
+      p0[i] = (q >> lw) * HW2 + (q & (Wd - 1));
+    }
+    auto halo_compute = [&](int kt) {
+      const int ci = kt / 9, t = kt - ci * 9;
+      const int ky = t / 3, kx = t - ky * 3;
+      const int toff = ea_uniform(ky * HW2 + kx);
+      const char* sb = wring + (kt & 1) * (BN * 128);
+      f16x8 ha[2][MI], hb[2][NI];
+      auto ld = [&](int ks, int sl) {
+        const int ch = ks * 4 + fq;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int pp = p0[i] + toff;
+          ha[sl][i] = *reinterpret_cast<const f16x8*>(halo + pp * 128 + ((ch ^ ea_swz(pp)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int r = wn * WTN + j * MT + frow;
+          hb[sl][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        }
+      };
+      ld(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 0) ld(1, 1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(ha[ks][i], hb[ks][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+      }
+#ifndef EA_EMU
+      {   // same pinned double-buffering as compute_tile
+        constexpr int RD = MI + NI, MF = MI * NI;
+        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+        for (int r = 0; r < RD; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, (MF >= 2 * RD) ? 2 : 1, 0);
+        }
+        if (MF > ((MF >= 2 * RD) ? 2 : 1) * RD) __builtin_amdgcn_sched_group_barrier(0x008, MF - ((MF >= 2 * RD) ? 2 : 1) * RD, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
+      }
+#endif
+    };
+    const int nchunk = ctot / EA_BK;
+    const int nkh = (p.debug == 2) ? 0 : nchunk * 9;
+    if (nkh > 0) {
+      issue_halo(0);
+      issue_w(0);
+    }
+    for (int kt = 0; kt < nkh; ++kt) {
+      ea_wait_dma<0>();
+      ea_raw_barrier();                            // W(kt) (and a fresh halo) landed; everyone is past compute(kt - 1)
+      if (kt + 1 < nkh) issue_w(kt + 1);
+      halo_compute(kt);
+      if (kt % 9 == 8 && kt + 1 < nkh) {
+        ea_raw_barrier();                          // every wave has read the last tap: the halo buffer may be refilled
+        issue_halo(kt / 9 + 1);
+      }
     }
   } else if (ILV == 2) {
     // ---- ping-pong (8 waves, 3-deep ring).  The waves form two groups, G0 = waves [0, NW/2) and G1 = the rest; the
