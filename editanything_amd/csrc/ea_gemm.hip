@@ -101,6 +101,16 @@ static bool halo_eligible(const EaGemmParams& p) {
   return true;
 }
 
+// A-stationary persistent linear (ea_gemm2.h, ILV == 4): dense A, the whole K (<= 320) of a 128-row panel resident in
+// LDS, 160-wide column tiles walked by the workgroup itself, one of the two streamlined epilogues.
+static bool panel_eligible(const EaGemmParams& p) {
+  if (p.conv || p.batch != 1 || p.splits != 1) return false;
+  if ((p.K % EA_BK) || p.K > 320 || (p.N % 160) || p.N < 160) return false;
+  if (p.epi_fast != 1 && p.epi_fast != 2) return false;
+  if (p.epi_fast == 1 && p.epi.rowvec && (p.epi.rows_per_group % 128)) return false;
+  return true;
+}
+
 // Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
 //   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
 //   EA_GEMM2_VARIANT=k         0 auto; k = 1..8 forces instantiation k of launch_fast:
@@ -109,6 +119,8 @@ static bool halo_eligible(const EaGemmParams& p) {
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
 //        13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG (two wave groups alternate MFMA / load phases, ea_gemm2.h)
+//        15: A-stationary persistent linear (K <= 320, N % 160 == 0): one workgroup per 128 rows walks every column tile
+//            with the A panel resident in LDS; refused (EA_ERR_UNSUPPORTED) on anything else
 //        14: 128 x bn 3x3 convolution over an input HALO tile staged once per 64-channel chunk (eligible convolutions only:
 //            anything else is refused with EA_ERR_UNSUPPORTED so a sweep cannot silently measure another kernel)
 static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0;
@@ -162,13 +174,13 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 14) ? 128 : 256;   // 3..6, 8, 13: 256 rows
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 14 || g_variant == 15) ? 128 : 256;   // 3..6, 8, 13: 256 rows
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
     for (int s = 1; s <= smax; ++s) {
       if (g_force_splits > 0 && s != g_force_splits && allow_split) continue;
-      if (g_variant == 14 && s > 1) break;   // the halo convolution has no split-K form
+      if ((g_variant == 14 || g_variant == 15) && s > 1) break;   // the halo convolution / persistent linear have no split-K form
       if (s > 1 && nk / s < 4 && g_force_splits == 0) break;
       // 64-row tiles re-read every weight tile twice as often: with deep split-K (few M tiles, weight-streaming
       // bound) they lose to 128-row tiles in every measured case
@@ -238,6 +250,14 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
       p.epi_fast = 2;
   }
   if (t.kind == 14 && (!halo_eligible(p) || t.splits != 1 || t.bm != 128)) return EA_ERR_UNSUPPORTED;
+  if (t.kind == 15) {
+    if (t.splits != 1 || t.bn != 160 || !panel_eligible(p)) return EA_ERR_UNSUPPORTED;
+    auto kfn = ea_gemm2_kernel<128, 160, 4, 2, 2, 16, 4, 0>;
+    const int smem = (p.K / EA_BK) * (128 * 128) + 2 * 160 * 128 + 8 * 8 * 84 * 4;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, dim3((p.M + 127) / 128, 1, 1), dim3(512, 1, 1), smem, stream, p);
+    return ea_launch_status();
+  }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
   do {                                                                                \

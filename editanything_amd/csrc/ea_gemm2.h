@@ -142,7 +142,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
   static_assert(MT == 16 || MT == 32, "MFMA tile");
-  static_assert(ILV == 0 || ILV == 3 || STAGES == 3, "interleaved issue / ping-pong need the 3-deep ring");
+  static_assert(ILV == 0 || ILV == 3 || ILV == 4 || STAGES == 3, "interleaved issue / ping-pong need the 3-deep ring");
   static_assert(WTM % MT == 0 && WTN % MT == 0, "wave tile must be a whole number of MFMA tiles");
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
@@ -158,7 +158,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
   const int wm = wave / WN, wn = wave % WN;
 
   EA_STAMP(0);
-  const int tiles_n = (p.N + BN - 1) / BN;
+  // ILV == 4 (A-stationary persistent): one workgroup per ROW tile, it walks all the column tiles itself
+  const int tiles_n = (ILV == 4) ? 1 : (p.N + BN - 1) / BN;
   const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
   const int tile = ea_xcd_remap(blockIdx.x, ntile);
   // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
@@ -414,7 +415,156 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #undef EA_LOADF
 
   EA_STAMP(1);
-  if (STAGES == 2 && LDR) {
+  if (ILV == 4) {
+    // ---- A-stationary persistent linear (opt-in kind 15; dense A, K <= 320, N % BN == 0).
+    // The level-0 transformer linears ([32768 x {320, 960, 2560} x 320]) give every workgroup of the tiled kernel
+    // only five K tiles between a prologue (first-tile DMA latency) and an epilogue -- 8 rounds of ~13 us on the
+    // GEGLU launch -- and re-stage the same [128 x 320] A panel for every column tile.  Here one workgroup owns 128
+    // rows (M / 128 = 256 workgroups = one per CU at M = 32768), stages the A panel ONCE (80 KiB), and streams the
+    // weight tiles of ALL its column tiles through a 2-stage ring; the epilogue slabs have their own LDS, so the next
+    // column tile's weights land while the current tile is written out.  8 waves as 4 x 2 (wave tile 32 x 80).
+    // LDS: [A panel: K/64 x 16 KiB][weight ring: 2 x BN x 128 B][slabs: 8 waves x 8 rows x (80 + 4) floats].
+    // Synchronisation, first version: vmcnt(0) + barrier per K tile (weight tile g + 1 in flight during compute(g)).
+    static_assert(ILV != 4 || (BM == 128 && BN == 160 && WM == 4 && WN == 2 && MT == 16 && STAGES == 2 && !LDR),
+                  "A-stationary: 128 x 160 tiles, 8 waves 4 x 2");
+    constexpr int SLR = 8;                          // slab rows
+    constexpr int SLDP = WTN + 4;
+    const int nkp = p.K / EA_BK;                    // K tiles of the panel (<= 5)
+    const int NT = p.N / BN;
+    char* panel = smem;
+    char* wring = smem + nkp * (BM * 128);
+    float* wst = reinterpret_cast<float*>(wring + 2 * BN * 128) + wave * (SLR * SLDP);
+    const EaEpilogue& e = p.epi;
+    // A panel: piece j of K tile kt -> rows (j*NW + wave)*8 .. +7 (a_voff holds the dense per-lane offsets)
+    for (int kt = 0; kt < nkp; ++kt) {
+#pragma unroll
+      for (int j = 0; j < A_PW; ++j)
+        if (A_INSTR % NW == 0 || j * NW + wave < A_INSTR)
+          ea_dma16(rs_a1, a_voff[j], (unsigned)(kt * EA_BK) * 2u, panel + kt * (BM * 128) + (j * NW + wave) * 1024);
+    }
+    auto issue_wp = [&](int g) {
+      const int nt = ea_uniform(g / nkp), kt = ea_uniform(g - (g / nkp) * nkp);
+      const unsigned soff = ((unsigned)(nt * BN) * (unsigned)p.ldw + (unsigned)(kt * EA_BK)) * 2u;
+      char* dst = wring + (g & 1) * (BN * 128);
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j)
+        if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff, dst + (j * NW + wave) * 1024);
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] = 0.0f;
+    };
+    auto panel_compute = [&](int kt, int stage) {
+      const char* sa = panel + kt * (BM * 128);
+      const char* sb = wring + stage * (BN * 128);
+      f16x8 qa[2][MI], qb[2][NI];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ks * 4 + fq;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int r = wm * WTM + i * MT + frow;
+          qa[ks][i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int r = wn * WTN + j * MT + frow;
+          qb[ks][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(qa[ks][i], qb[ks][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+    };
+    // the two streamlined epilogues (p.epi_fast 1: bias / row vector / SiLU / GELU / scale / fp16 residual;
+    // 2: GEGLU with the 80-row packing), on 8-row slabs; same arithmetic as the tiled kernel's
+    auto tile_epilogue = [&](int nt) {
+      const int colbase = nt * BN + wn * WTN;
+      const bool geglu = p.epi_fast == 2;
+      const float* rvp = (!geglu && e.rowvec) ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
+      float cb[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int col = colbase + j * 16 + frow;
+        cb[j] = (e.bias ? e.bias[col] : 0.0f) + (rvp ? rvp[col] : 0.0f);
+      }
+      f16* outp = (f16*)e.out;
+      const f16* resp = geglu ? nullptr : e.residual;
+      const int out_w = geglu ? WTN / 2 : WTN, vpr = out_w / 8;
+      const int obase = geglu ? (colbase >> 1) : colbase;
+#pragma unroll
+      for (int slab = 0; slab < WTM / SLR; ++slab) {
+        const int ii = slab >> 1, half = slab & 1;        // 16-row MFMA tile and which 8 rows of it
+        if ((fq >> 1) == half) {
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const bool gate = geglu && (j * 16 + frow) >= 40;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[MT == 16 ? (ii < MI ? ii : 0) : 0][MT == 16 ? j : 0][r] + cb[j];
+              if (geglu) {
+                if (j >= 2) { const float gx = ea_gelu_erf(x); x = gate ? gx : x; }
+              } else {
+                if (e.act == EA_ACT_SILU) x = ea_silu(x);
+                else if (e.act == EA_ACT_GELU) x = ea_gelu_erf(x);
+                x *= e.scale;
+              }
+              wst[((fq & 1) * 4 + r) * SLDP + j * 16 + frow] = x;
+            }
+          }
+        }
+        ea_wave_lds_sync();
+        const int mrow0 = m0 + wm * WTM + slab * SLR;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int id = lane + 64 * v;
+          const int row = id / vpr, c = id - row * vpr;
+          const int m = mrow0 + row, n = obase + c * 8;
+          if (id < SLR * vpr && m < p.M) {
+            const float* sp = wst + row * SLDP + c * 8;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+            f16x8 h;
+            if (geglu) {
+              const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 40), g1 = *reinterpret_cast<const f32x4*>(sp + 44);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] * g0[q] * e.scale); h[4 + q] = (f16)(v1[q] * g1[q] * e.scale); }
+            } else if (resp) {
+              const f16x8 rr = ea_ld8(resp + (long long)m * e.ldr + n);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] + (float)rr[q]); h[4 + q] = (f16)(v1[q] + (float)rr[4 + q]); }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { h[q] = (f16)v0[q]; h[4 + q] = (f16)v1[q]; }
+            }
+            ea_st8(outp + (long long)m * e.ldc + n, h);
+          }
+        }
+        ea_wave_lds_sync();
+      }
+    };
+    const int G = (p.debug == 2) ? 0 : NT * nkp;
+    if (G > 0) issue_wp(0);
+    for (int g = 0; g < G; ++g) {
+      ea_wait_dma<0>();
+      ea_raw_barrier();
+      if (g + 1 < G) issue_wp(g + 1);
+      const int nt = g / nkp, kt = g - nt * nkp;
+      panel_compute(kt, g & 1);
+      if (kt == nkp - 1) {
+        tile_epilogue(nt);
+        zero_acc();
+      }
+    }
+    return;
+  } else if (STAGES == 2 && LDR) {
     // loader waves + 2-deep ring: the tile after the one being multiplied is in flight during exactly one compute
     // phase, so a single workgroup is DMA-latency bound -- this instantiation is built for TWO 8-wave workgroups per CU
     // (64-row tiles: <= 128 registers, 56 KiB of LDS), whose compute phases fill each other's waits.
@@ -756,7 +906,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int SLD = WTN + 4;                 // fp32 words per slab row (pad: conflict-free accumulator scatter)
   constexpr int NSLAB = WTM / SLAB;
   constexpr int ITERS = 6, SUB = 3;             // vectors per lane per slab (upper bound), gathered SUB at a time
-  static_assert(NW * SLAB * SLD * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+  static_assert(ILV == 4 || NW * SLAB * SLD * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
   static_assert(WTM % SLAB == 0, "slab rows");
   float* wstg = reinterpret_cast<float*>(smem) + wave * (SLAB * SLD);
   const bool raw = p.splits > 1;
@@ -821,7 +971,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     constexpr int SLDG = WTN + 4;
     constexpr int VPRG = 5;                                  // 16-byte output vectors per row (40 outputs)
     constexpr int NVG = (SLABG * VPRG + 63) / 64;            // 2
-    static_assert(NW * SLABG * SLDG * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    static_assert(ILV == 4 || NW * SLABG * SLDG * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
     float* wst = reinterpret_cast<float*>(smem) + wave * (SLABG * SLDG);
     const int colbase = n0 + wn * WTN;                       // packed weight row of this wave's first column
     const int obase = colbase >> 1;                          // first output column
@@ -872,7 +1022,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     constexpr int SLDF = WTN + 4;
     constexpr int VPR = WTN / 8;                            // 16-byte output vectors per row
     constexpr int NV = (SLABF * VPR + 63) / 64;             // vectors per lane per slab
-    static_assert(NW * SLABF * SLDF * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    static_assert(ILV == 4 || NW * SLABF * SLDF * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
     float* wst = reinterpret_cast<float*>(smem) + wave * (SLABF * SLDF);
     const int colbase = n0 + wn * WTN;
     const float* rvp = e.rowvec ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;

@@ -52,3 +52,40 @@ def test_conv_halo_variant(kb, B, H, W, c1, c2, cout, monkeypatch):
     out2 = kb.zeros((B * (H // 2) * (W // 2), cout), np.float16)
     e2 = epilogue(out2, bias=bias)
     assert kb.lib.ea_conv2d_f16(C.byref(src2), ptr(pack_conv_w(w)), cout, C.byref(e2), ptr(ws), ws_nbytes(ws), kb.stream) == -3
+
+
+@pytest.mark.parametrize("M,N,K,act,res,gb", [
+    (256, 320, 320, 0, True, 0),      # the level-0 attention output projection shape, two column tiles, residual
+    (200, 480, 128, 1, False, 0),     # ragged M, three column tiles, SiLU
+    (130, 960, 64, 2, True, 0),       # one K tile, six column tiles, GELU + residual
+    (256, 640, 320, 3, False, 80),    # GEGLU (80-row packing): four column tiles -> 320 outputs
+])
+def test_gemm_a_stationary_variant(kb, M, N, K, act, res, gb, monkeypatch):
+    """Kind 15 (A panel resident in LDS, the workgroup walks every column tile, epilogue slabs beside the weight ring)
+    == the reference expression; problems it does not cover are refused."""
+    monkeypatch.setenv("EA_GEMM2_VARIANT", "15")
+    A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
+    bias = f32(N)
+    No = N // 2 if act == 3 else N
+    R = f16(1, M, No) if res else None
+    out = kb.zeros((1, M, No), np.float16)
+    e = epilogue(out, bias=bias, act=act, residual=R, geglu_block=gb, scale=0.5)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ref = torch.einsum("bmk,bnk->bmn", t(A), t(W)) + t(bias)
+    if act == 1:
+        ref = F.silu(ref)
+    elif act == 2:
+        ref = F.gelu(ref)
+    elif act == 3:
+        r = ref.reshape(1, M, N // gb, 2, gb // 2)
+        ref = (r[..., 0, :] * F.gelu(r[..., 1, :])).reshape(1, M, No)
+    ref = ref * 0.5
+    if res:
+        ref = ref + t(R)
+    assert relerr(kb.down(out), ref.numpy()) < 2e-3
+    # K = 384 does not fit the resident panel: refused under the forced variant, not silently routed elsewhere
+    A2, W2 = f16(1, 128, 384), f16(1, 160, 384)
+    out2 = kb.zeros((1, 128, 160), np.float16)
+    e2 = epilogue(out2)
+    assert kb.lib.ea_gemm_f16(ptr(A2), 384, ptr(W2), 384, 128, 160, 384, 1, 0, 0, 0, 0, C.byref(e2), ptr(ws), ws_nbytes(ws), kb.stream) == -3
