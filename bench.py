@@ -90,6 +90,7 @@ def main():
     sam = models.ImageEncoderViT(models.SAM_CONFIGS[args.sam], sds["sam"], dev)
     inp = synthetic_inputs(args.batch, args.seed + 100 + rank, dev)
     init_image = inp["images_u8"].permute(0, 3, 1, 2).float() / 127.5 - 1.0
+    mask_b = inp["mask"].repeat(args.batch, 1, 1, 1)     # one mask per image ([B, 1, H, W]: check_inputs wants equal batch sizes)
 
     def one_step(seed):
         # SAM image encoding of the batch (ResizeLongestSide(1024) on device, then the ViT)
@@ -98,7 +99,7 @@ def main():
         x = (x - sam.mean) / sam.std
         emb = sam.forward(x) if args.no_graph else sam.forward_graph(x)
         gen = torch.Generator("cpu").manual_seed(seed)
-        out = pipe(prompt_embeds=inp["embeds"], negative_prompt_embeds=inp["neg"], image=init_image, mask_image=inp["mask"][0],
+        out = pipe(prompt_embeds=inp["embeds"], negative_prompt_embeds=inp["neg"], image=init_image, mask_image=mask_b,
                    controlnet_conditioning_image=inp["control"], height=512, width=512, num_inference_steps=args.ddim_steps,
                    guidance_scale=7.5, num_images_per_prompt=args.batch, generator=gen, output_type="np_device")
         return emb, out

@@ -95,17 +95,53 @@ class StableDiffusionControlNetInpaintPipeline:
             raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape.")
         n = len(self.controlnets)
         if not isinstance(self.controlnet, (list, tuple)):
-            if isinstance(cond_scale, (list, tuple)):
+            if not isinstance(cond_scale, float):
                 raise TypeError("For single controlnet: `controlnet_conditioning_scale` must be type `float`.")
         else:
-            if not isinstance(cond_images, (list, tuple)) or len(cond_images) != n:
-                raise ValueError("For multiple controlnets: `controlnet_conditioning_image` must be a list with one "
-                                 "entry per controlnet.")
-            if isinstance(cond_scale, (list, tuple)) and len(cond_scale) != n:
-                raise ValueError("For multiple controlnets: `controlnet_conditioning_scale` must have one entry per "
-                                 "controlnet.")
+            if not isinstance(cond_images, list):
+                raise TypeError("For multiple controlnets: `image` must be type `list`")
+            if len(cond_images) != n:
+                raise ValueError("For multiple controlnets: `image` must have the same length as the number of controlnets.")
+            if isinstance(cond_scale, list) and len(cond_scale) != n:
+                raise ValueError("For multiple controlnets: When `controlnet_conditioning_scale` is specified as `list`, it "
+                                 "must have the same length as the number of controlnets")
         if (image is None) != (mask_image is None):
             raise ValueError("`image` and `mask_image` must be given together (inpainting) or both omitted.")
+        from PIL import Image as _PIL
+        if isinstance(image, torch.Tensor) and not isinstance(mask_image, torch.Tensor):
+            raise TypeError("if `image` is a tensor, `mask_image` must also be a tensor")
+        if isinstance(image, _PIL.Image) and not isinstance(mask_image, _PIL.Image):
+            raise TypeError("if `image` is a PIL image, `mask_image` must also be a PIL image")
+        if isinstance(image, torch.Tensor):          # …inpaint.py:903-963
+            if image.ndim != 3 and image.ndim != 4:
+                raise ValueError("`image` must have 3 or 4 dimensions")
+            if mask_image.ndim not in (2, 3, 4):
+                raise ValueError("`mask_image` must have 2, 3, or 4 dimensions")
+            ib, ic, ih, iw = (1,) + tuple(image.shape) if image.ndim == 3 else tuple(image.shape)
+            if mask_image.ndim == 2:
+                mb, mc, mh, mw = (1, 1) + tuple(mask_image.shape)
+            elif mask_image.ndim == 3:
+                mb, mc, mh, mw = (mask_image.shape[0], 1) + tuple(mask_image.shape[1:])
+            else:
+                mb, mc, mh, mw = tuple(mask_image.shape)
+            if ic != 3:
+                raise ValueError("`image` must have 3 channels")
+            if mc != 1:
+                raise ValueError("`mask_image` must have 1 channel")
+            if ib != mb:
+                raise ValueError("`image` and `mask_image` mush have the same batch sizes")
+            if ih != mh or iw != mw:
+                raise ValueError("`image` and `mask_image` must have the same height and width dimensions")
+            # value ranges: checked for host tensors only -- on device tensors each min()/max() is a blocking round trip
+            # in front of the denoising loop (the reference pays it; a resident-input caller should not)
+            if not image.is_cuda and (image.min() < -1 or image.max() > 1):
+                raise ValueError("`image` should be in range [-1, 1]")
+            if not mask_image.is_cuda and (mask_image.min() < 0 or mask_image.max() > 1):
+                raise ValueError("`mask_image` should be in range [0, 1]")
+        unet_in = getattr(getattr(self, "unet", None), "cfg", {}).get("in_channels", 4)
+        if unet_in not in (4, 9):                    # :965-979: 4 latent channels, or 4 + 1 (mask) + 4 (masked image)
+            raise ValueError(f"The config of `pipeline.unet` expects {unet_in} but received non inpainting latent "
+                             f"channels: 4, mask channels: 1, and masked image channels: 4.")
 
     def _encode_text(self, prompts):
         """list[str] -> [B, L, ctx].  Two conventions: a plain callable `text_encoder(list[str])`, or the diffusers pair

@@ -1,0 +1,92 @@
+"""`check_inputs` error behaviour of the diffusers-style pipeline (utils/stable_diffusion_controlnet_inpaint.py:792-979):
+same exception types on the same conditions.  Host-only (the checks run before anything touches the device)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline as Pipe
+
+
+def make(n_controlnets=None, in_channels=4):
+    p = object.__new__(Pipe)
+    nets = [object()] * (n_controlnets or 1)
+    p.controlnet = nets if n_controlnets else nets[0]
+    p.controlnets = nets
+    p.unet = types.SimpleNamespace(cfg={"in_channels": in_channels})
+    return p
+
+
+PE = torch.zeros(1, 77, 8)
+IMG = Image.fromarray(np.zeros((64, 64, 3), np.uint8))
+MSK = Image.fromarray(np.zeros((64, 64), np.uint8))
+
+
+def call(p, **over):
+    kw = dict(prompt=None, image=IMG, mask_image=MSK, cond_images=IMG, height=64, width=64, callback_steps=1,
+              negative_prompt=None, prompt_embeds=PE, negative_prompt_embeds=PE, cond_scale=1.0)
+    kw.update(over)
+    return p.check_inputs(**kw)
+
+
+def test_valid_inputs_pass():
+    call(make())
+    call(make(2), cond_images=[IMG, IMG], cond_scale=[1.0, 0.5])
+    call(make(2), cond_images=[IMG, IMG], cond_scale=0.7)            # a scalar is broadcast over the nets
+    call(make(), image=None, mask_image=None)                        # generation pipeline: no inpaint inputs
+    t_img, t_msk = torch.zeros(2, 3, 64, 64), torch.ones(2, 1, 64, 64)
+    call(make(in_channels=9), image=t_img, mask_image=t_msk)
+
+
+@pytest.mark.parametrize("over,exc", [
+    (dict(height=60), ValueError),                                   # :806-809
+    (dict(callback_steps=0), ValueError),                            # :811-818
+    (dict(callback_steps=None), ValueError),
+    (dict(callback_steps=1.5), ValueError),
+    (dict(prompt="a cat"), ValueError),                              # both prompt and prompt_embeds :820-824
+    (dict(prompt_embeds=None, negative_prompt_embeds=None), ValueError),   # neither :825-828
+    (dict(prompt=3, prompt_embeds=None, negative_prompt_embeds=None), ValueError),   # wrong prompt type :829-834
+    (dict(negative_prompt="bad"), ValueError),                       # both negatives :836-840
+    (dict(negative_prompt_embeds=torch.zeros(1, 60, 8)), ValueError),   # shape mismatch :842-848
+    (dict(cond_scale=[1.0]), TypeError),                             # single net: scale must be float :875-879
+    (dict(cond_scale=1), TypeError),
+    (dict(image=torch.zeros(3, 64, 64)), TypeError),                 # tensor image with a PIL mask :891-894
+    (dict(mask_image=torch.zeros(64, 64)), TypeError),               # PIL image with a tensor mask :896-901
+    (dict(image=None), ValueError),
+])
+def test_single_controlnet_errors(over, exc):
+    with pytest.raises(exc):
+        call(make(), **over)
+
+
+@pytest.mark.parametrize("over,exc", [
+    (dict(cond_images=IMG), TypeError),                              # must be a list :857-859
+    (dict(cond_images=(IMG, IMG)), TypeError),
+    (dict(cond_images=[IMG]), ValueError),                           # wrong length :860-863
+    (dict(cond_images=[IMG, IMG], cond_scale=[1.0]), ValueError),    # scale list of the wrong length :880-887
+])
+def test_multi_controlnet_errors(over, exc):
+    with pytest.raises(exc):
+        call(make(2), **over)
+
+
+@pytest.mark.parametrize("image,mask,msg", [
+    (torch.zeros(64, 64), torch.zeros(64, 64), "3 or 4 dimensions"),
+    (torch.zeros(3, 64, 64), torch.zeros(1, 1, 1, 64, 64), "2, 3, or 4 dimensions"),
+    (torch.zeros(1, 64, 64), torch.zeros(64, 64), "3 channels"),
+    (torch.zeros(2, 3, 64, 64), torch.zeros(2, 2, 64, 64), "1 channel"),
+    (torch.zeros(2, 3, 64, 64), torch.zeros(3, 64, 64), "batch sizes"),
+    (torch.zeros(3, 64, 64), torch.zeros(32, 64), "height and width"),
+    (torch.full((3, 64, 64), 1.5), torch.zeros(64, 64), r"range \[-1, 1\]"),
+    (torch.zeros(3, 64, 64), torch.full((64, 64), 2.0), r"range \[0, 1\]"),
+])
+def test_tensor_image_and_mask_checks(image, mask, msg):
+    with pytest.raises(ValueError, match=msg):
+        call(make(), image=image, mask_image=mask)
+
+
+def test_unet_channel_check():
+    with pytest.raises(ValueError, match="expects 5"):
+        call(make(in_channels=5))
