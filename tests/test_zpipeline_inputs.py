@@ -90,3 +90,40 @@ def test_tensor_image_and_mask_checks(image, mask, msg):
 def test_unet_channel_check():
     with pytest.raises(ValueError, match="expects 5"):
         call(make(in_channels=5))
+
+
+def test_call_front_half_with_bench_shaped_inputs():
+    """bench.py's call (tensor image [4,3,512,512] in [-1,1], one mask per image, 4 images per prompt, CFG) through
+    everything `__call__` does on the host before the first device op -- validation, prompt / control / latent /
+    inpaint-input preparation -- with the device parts stubbed out."""
+    from editanything_amd.scheduler import DDIMScheduler
+
+    class Stop(Exception):
+        pass
+
+    seen = {}
+    p = make()
+    p.unet.plan = {"input": [[("conv_in", 4, 8)]] * 12}
+
+    def encode(img, noise):
+        seen["vae_in"], seen["vae_noise"] = tuple(img.shape), tuple(noise.shape)
+        return torch.zeros(img.shape[0], 4, 64, 64)
+
+    def prepare(embeds, hints, per_net, static=None):
+        seen["embeds"], seen["hints"], seen["scales"] = tuple(embeds.shape), [tuple(h.shape) for h in hints], per_net
+        raise Stop()
+
+    p.vae = types.SimpleNamespace(encode=encode, scale_factor=0.18215)
+    p.scheduler, p.text_encoder, p.tokenizer, p.device = DDIMScheduler(), None, None, torch.device("cpu")
+    p.denoiser = types.SimpleNamespace(prepare=prepare, only_mid_control=False)
+    p.use_graph, p._graphs, p.trace = True, {}, None
+    mask = torch.zeros(1, 1, 512, 512)
+    mask[:, :, 128:384, 128:384] = 1
+    with pytest.raises(Stop):
+        p(prompt_embeds=torch.zeros(1, 77, 1024), negative_prompt_embeds=torch.zeros(1, 77, 1024),
+          image=torch.rand(4, 3, 512, 512) * 2 - 1, mask_image=mask.repeat(4, 1, 1, 1),
+          controlnet_conditioning_image=torch.zeros(4, 3, 512, 512), height=512, width=512, num_inference_steps=20,
+          guidance_scale=7.5, num_images_per_prompt=4, generator=torch.Generator("cpu").manual_seed(0))
+    assert seen["vae_in"] == (4, 3, 512, 512) and seen["vae_noise"] == (4, 4, 64, 64)
+    assert seen["embeds"] == (8, 77, 1024) and seen["hints"] == [(8, 3, 512, 512)]          # [uncond || cond]
+    assert seen["scales"] == [[1.0] * 13]
