@@ -486,19 +486,37 @@ void ea_gemm2_kernel(EaGemmParams p) {
     };
     // the two streamlined epilogues (p.epi_fast 1: bias / row vector / SiLU / GELU / scale / fp16 residual;
     // 2: GEGLU with the 80-row packing), on 8-row slabs; same arithmetic as the tiled kernel's
-    auto tile_epilogue = [&](int nt) {
+    // Per-column terms and the residual rows of a column tile are fetched when its K loop STARTS (the loads ride under the
+    // five K tiles): fetched inside the epilogue they would cost a memory round trip per slab on every column tile.
+    const bool geglu = p.epi_fast == 2;
+    const float* rvp = (!geglu && e.rowvec) ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
+    const f16* resp = geglu ? nullptr : e.residual;
+    const int out_w = geglu ? WTN / 2 : WTN, vpr = out_w / 8;
+    constexpr int NSL = WTM / SLR;
+    float cb[NI];
+    f16x8 rq[NSL][2];
+    auto tile_prefetch = [&](int nt) {
       const int colbase = nt * BN + wn * WTN;
-      const bool geglu = p.epi_fast == 2;
-      const float* rvp = (!geglu && e.rowvec) ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
-      float cb[NI];
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int col = colbase + j * 16 + frow;
         cb[j] = (e.bias ? e.bias[col] : 0.0f) + (rvp ? rvp[col] : 0.0f);
       }
+      if (resp) {
+#pragma unroll
+        for (int slab = 0; slab < NSL; ++slab)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const int id = lane + 64 * v;
+            const int row = id / vpr, c = id - row * vpr;
+            const int m = m0 + wm * WTM + slab * SLR + row;
+            if (id < SLR * vpr && m < p.M) rq[slab][v] = ea_ld8(resp + (long long)m * e.ldr + colbase + c * 8);
+          }
+      }
+    };
+    auto tile_epilogue = [&](int nt) {
+      const int colbase = nt * BN + wn * WTN;
       f16* outp = (f16*)e.out;
-      const f16* resp = geglu ? nullptr : e.residual;
-      const int out_w = geglu ? WTN / 2 : WTN, vpr = out_w / 8;
       const int obase = geglu ? (colbase >> 1) : colbase;
 #pragma unroll
       for (int slab = 0; slab < WTM / SLR; ++slab) {
@@ -537,7 +555,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] * g0[q] * e.scale); h[4 + q] = (f16)(v1[q] * g1[q] * e.scale); }
             } else if (resp) {
-              const f16x8 rr = ea_ld8(resp + (long long)m * e.ldr + n);
+              const f16x8 rr = rq[slab][v];
 #pragma unroll
               for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] + (float)rr[q]); h[4 + q] = (f16)(v1[q] + (float)rr[4 + q]); }
             } else {
@@ -557,6 +575,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
       ea_raw_barrier();
       if (g + 1 < G) issue_wp(g + 1);
       const int nt = g / nkp, kt = g - nt * nkp;
+      if (kt == 0) tile_prefetch(nt);
       panel_compute(kt, g & 1);
       if (kt == nkp - 1) {
         tile_epilogue(nt);
