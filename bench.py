@@ -91,6 +91,9 @@ def main():
     inp = synthetic_inputs(args.batch, args.seed + 100 + rank, dev)
     init_image = inp["images_u8"].permute(0, 3, 1, 2).float() / 127.5 - 1.0
     mask_b = inp["mask"].repeat(args.batch, 1, 1, 1)     # one mask per image ([B, 1, H, W]: check_inputs wants equal batch sizes)
+    # one prompt row per image, num_images_per_prompt = 1: with a batch of control images the reference requires
+    # control batch == prompt batch (check_controlnet_conditioning_image, ...inpaint.py:782-790)
+    embeds_b, neg_b = inp["embeds"].repeat(args.batch, 1, 1), inp["neg"].repeat(args.batch, 1, 1)
 
     def one_step(seed):
         # SAM image encoding of the batch (ResizeLongestSide(1024) on device, then the ViT)
@@ -99,9 +102,9 @@ def main():
         x = (x - sam.mean) / sam.std
         emb = sam.forward(x) if args.no_graph else sam.forward_graph(x)
         gen = torch.Generator("cpu").manual_seed(seed)
-        out = pipe(prompt_embeds=inp["embeds"], negative_prompt_embeds=inp["neg"], image=init_image, mask_image=mask_b,
+        out = pipe(prompt_embeds=embeds_b, negative_prompt_embeds=neg_b, image=init_image, mask_image=mask_b,
                    controlnet_conditioning_image=inp["control"], height=512, width=512, num_inference_steps=args.ddim_steps,
-                   guidance_scale=7.5, num_images_per_prompt=args.batch, generator=gen, output_type="np_device")
+                   guidance_scale=7.5, num_images_per_prompt=1, generator=gen, output_type="np_device")
         return emb, out
 
     # output_type "np_device": keep the decoded batch on the device (the host copy of 4 images is not part of the path)

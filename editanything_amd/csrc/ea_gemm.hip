@@ -123,7 +123,7 @@ static bool panel_eligible(const EaGemmParams& p) {
 //            with the A panel resident in LDS; refused (EA_ERR_UNSUPPORTED) on anything else
 //        14: 128 x bn 3x3 convolution over an input HALO tile staged once per 64-channel chunk (eligible convolutions only:
 //            anything else is refused with EA_ERR_UNSUPPORTED so a sweep cannot silently measure another kernel)
-static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0;
+static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0, g_no_tr = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
   g_force_generic = (f && !strcmp(f, "generic")) ? 1 : 0;
@@ -133,6 +133,8 @@ static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B
   g_force_splits = (sp && *sp) ? atoi(sp) : 0;
   const char* bn = getenv("EA_GEMM2_BN");         // tuning sweeps only: 128 forces 128-wide column tiles
   g_force_bn = (bn && *bn) ? atoi(bn) : 0;
+  const char* tr = getenv("EA_GEMM2_TR");         // A/B only: 0 keeps the LDS-slab epilogue where the register-direct one applies
+  g_no_tr = (tr && *tr == '0') ? 1 : 0;
 }
 
 // Cost model (microseconds) that picks tile height (64 / 128 rows) and split-K factor.  Fitted to the forced
@@ -267,6 +269,22 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64 * (1 + LD_), 1, 1), smem, stream, p);    \
   } while (0)
 #define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
+  // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
+  const bool tr = p.epi_fast == 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (((uintptr_t)p.epi.bias) & 15) == 0 &&
+                  (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0));
+#define EA_LAUNCH_TR(BM_, BN_)                                                        \
+  do {                                                                                \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, 1>;                       \
+    const int smem = 2 * (BM_ + BN_) * 128;                                           \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                           \
+  } while (0)
+  if (tr) {
+    if (t.kind == 1) { if (t.bn == 160) EA_LAUNCH_TR(128, 160); else EA_LAUNCH_TR(128, 128); }
+    else { if (t.bn == 160) EA_LAUNCH_TR(64, 160); else EA_LAUNCH_TR(64, 128); }
+    return ea_launch_status();
+  }
+#undef EA_LAUNCH_TR
   switch (t.kind) {
     case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
     case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 0); break;

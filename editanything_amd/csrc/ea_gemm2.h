@@ -105,6 +105,36 @@ __device__ __forceinline__ void ea_wave_lds_sync() {
 }
 #endif
 
+// v_permlane16_swap_b32 a, b: the ODD 16-lane rows of `a` are exchanged with the EVEN rows of `b`
+// (a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]; probed on the MI355X,
+// tools/probe_misc.hip).  Used by the register-direct epilogue to turn two 4-column accumulator quads into 8
+// consecutive columns per lane (guide T21 applied to the 16x16 MFMA layout).
+#ifdef EA_EMU
+__device__ __forceinline__ void ea_swap16(float& a, float& b) {
+  char* s = ea_emu::wave_scratch();
+  const int l = ea_emu::lane_id();
+  memcpy(s + l * 64 + 32, &a, 4);
+  memcpy(s + l * 64 + 36, &b, 4);
+  ea_emu::wave_sync();
+  float na = a, nb = b;
+  if ((l >> 4) & 1) memcpy(&na, s + (l - 16) * 64 + 36, 4);
+  else memcpy(&nb, s + (l + 16) * 64 + 32, 4);
+  ea_emu::wave_sync();
+  a = na;
+  b = nb;
+}
+#else
+__device__ __forceinline__ void ea_swap16(float& a, float& b) {
+  // both results go through scalar `unsigned` temporaries: bit-casting the elements of the returned vector directly
+  // (`bit_cast<float>(r[1])`) makes hipcc (ROCm 7.2) treat r[1] as r[0] -- seen in the ISA and on the MI355X
+  const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  const auto r = __builtin_amdgcn_permlane16_swap(ua, ub, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+#endif
+
 // Phase timestamps for tools/phase_times.py (EA_GEMM2_DEBUG=3): wave 0 / lane 0 of every workgroup stores the
 // constant-rate wall clock (100 MHz) at a few program points into the (otherwise unused) split-K workspace.
 #ifdef EA_EMU
@@ -134,10 +164,18 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // max(issue, compute).  One barrier per K tile, 3-deep ring: at barrier kt the loaders have waited for tile kt
 // (counted vmcnt, tile kt + 1 still in flight), the compute waves have retired their reads of tile kt - 1, whose buffer
 // the loaders refill with tile kt + 2 right after.
-template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0>
+// TR = 1: TRANSPOSED accumulators + register-direct epilogue.  The MFMA operands are swapped (D^T = W A^T), so a lane
+// holds 4 CONSECUTIVE output columns of one output row per 16x16 tile (row = lane % 16, columns 4 * (lane / 16) ..+3)
+// instead of 4 consecutive rows of one column: after one v_permlane16_swap per register two tiles give every lane 8
+// consecutive columns, i.e. the finished fp16 row segment goes from registers to memory as a 16-byte store -- no LDS
+// slab, no scatter / gather passes, no waits between slabs.  Measured with tools/gemm_bench --debug 0,1,2 (round 2): the
+// LDS-slab epilogues cost 25 % of the contraction time of an evaluation (10-54 us per launch; the bare store stream of
+// the same bytes takes 5-15 us, tools/probe_misc).  Same products and the same fp32 summation order as TR = 0.
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
 __global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
 void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR);
+  static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && STAGES == 2), "register-direct epilogue: the 2-stage 16x16x32 tiles");
   static_assert(!LDR || !ILV, "loader waves replace the interleaved issue");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
@@ -372,7 +410,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[ks & 1][i], fb[ks & 1][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+          if (MT == 16 && TR) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fb[ks & 1][j], fa[ks & 1][i], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
+          else if (MT == 16) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(fa[ks & 1][i], fb[ks & 1][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
           else acc32[MT == 32 ? i : 0][MT == 32 ? j : 0] = ea_mfma_32x32x16(fa[ks & 1][i], fb[ks & 1][j], acc32[MT == 32 ? i : 0][MT == 32 ? j : 0]);
         }
         if (ILV == 1) {
@@ -919,6 +958,102 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
       for (int j = 0; j < NI; ++j) sum += (MT == 16) ? acc[MT == 16 ? i : 0][MT == 16 ? j : 0][0] : acc32[MT == 32 ? i : 0][MT == 32 ? j : 0][0];
     if (sum == 123456.789f) ((f16*)e.out)[0] = (f16)sum;
+    return;
+  }
+  if (TR) {
+    // ---- register-direct epilogue (p.epi_fast == 1 launches: fp16 out, optional fp16 residual, bias / per-sample row
+    // vector / SiLU / GELU / scalar scale, 16-byte aligned, no split-K; checked on the host).
+    // acc[i][j][r] = C[row i*16 + c16][col j*16 + 4*q4 + r].  Tiles are paired -- (j, j+1) along the columns, and when
+    // NI is odd the last column tile along the rows, (i, i+1) -- and each register pair goes through ea_swap16: the
+    // even-q4 lanes end up with columns 8*(q4/2) .. +7 of the pair's FIRST tile, the odd-q4 lanes with the same columns
+    // of its SECOND tile.  Per wave instruction: 16 rows x 64 contiguous bytes (column pairs).
+    static_assert(!TR || (NI % 2 == 0 || MI % 2 == 0), "an odd column-tile count needs an even row-tile count to pair up");
+    constexpr int JP = NI / 2;                    // column-tile pairs per row tile
+    constexpr int IP = (NI & 1) ? MI / 2 : 0;     // row-tile pairs of the odd last column tile
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int sel = q4 & 1, coff = 8 * (q4 >> 1);
+    const int colbase = n0 + wn * WTN, rowbase = m0 + wm * WTM;
+    const long long cb0 = (long long)batch * p.strideC, rb0 = (long long)batch * p.strideR;
+    f16* outp = (f16*)e.out + cb0;
+    const f16* resp = e.residual ? e.residual + rb0 : nullptr;
+    const float* rvp = e.rowvec ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
+    // where this lane's 8-column vectors go: column-pair vectors (ii, jp), then the odd tile's row-pair vectors (ip)
+    int voff[MI * JP + IP + 1], roff[MI * JP + IP + 1];
+#pragma unroll
+    for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+      for (int jp = 0; jp < JP; ++jp) {
+        const int m = rowbase + ii * 16 + c16, n = colbase + (2 * jp + sel) * 16 + coff;
+        const bool ok = m < p.M && n < e.N;
+        voff[ii * JP + jp] = ok ? m * e.ldc + n : -1;
+        roff[ii * JP + jp] = ok ? m * e.ldr + n : -1;
+      }
+#pragma unroll
+    for (int ip = 0; ip < IP; ++ip) {
+      const int m = rowbase + (2 * ip + sel) * 16 + c16, n = colbase + (NI - 1) * 16 + coff;
+      const bool ok = m < p.M && n < e.N;
+      voff[MI * JP + ip] = ok ? m * e.ldc + n : -1;
+      roff[MI * JP + ip] = ok ? m * e.ldr + n : -1;
+    }
+    // every global read of the epilogue is issued before the first use: residual vectors, then the per-column terms
+    f16x8 rq[MI * JP + IP + 1];
+    if (resp) {
+#pragma unroll
+      for (int v = 0; v < MI * JP + IP; ++v)
+        if (roff[v] >= 0) rq[v] = ea_ld8(resp + roff[v]);
+    }
+    f32x4 cb[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = colbase + j * 16 + 4 * q4;
+      cb[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (n < e.N) {
+        if (e.bias) cb[j] = *reinterpret_cast<const f32x4*>(e.bias + n);
+        if (rvp) cb[j] += *reinterpret_cast<const f32x4*>(rvp + n);
+      }
+    }
+    auto finish = [&](f32x4 x, int j) {
+      x += cb[j];
+      if (e.act == EA_ACT_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ea_silu(x[r]);
+      } else if (e.act == EA_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = ea_gelu_erf(x[r]);
+      }
+      return x * e.scale;
+    };
+    auto emit = [&](f32x4 a, f32x4 b, int v) {     // a, b: finished quads of the pair's first / second tile
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = a[r], y = b[r];
+        ea_swap16(x, y);
+        a[r] = x;
+        b[r] = y;
+      }
+      if (voff[v] < 0) return;
+      f16x8 h;
+      if (resp) {
+        const f16x8 rr = rq[v];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = (f16)(a[r] + (float)rr[r]); h[4 + r] = (f16)(b[r] + (float)rr[4 + r]); }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
+      }
+      ea_st8(outp + voff[v], h);
+    };
+#pragma unroll
+    for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+      for (int jp = 0; jp < JP; ++jp)
+        emit(finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp : 0], 2 * jp), finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp + 1 : 0], 2 * jp + 1),
+             ii * JP + jp);
+#pragma unroll
+    for (int ip = 0; ip < IP; ++ip)
+      emit(finish(acc[MT == 16 ? 2 * ip : 0][MT == 16 ? NI - 1 : 0], NI - 1), finish(acc[MT == 16 ? 2 * ip + 1 : 0][MT == 16 ? NI - 1 : 0], NI - 1),
+           MI * JP + ip);
+    EA_STAMP(4);
     return;
   }
   constexpr int SLAB = (WTN > 80) ? 16 : 32;   // rows per slab: keeps the per-lane gather depth at <= 6 vectors

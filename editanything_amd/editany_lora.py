@@ -302,9 +302,12 @@ class EditAnythingLoraModel:
             if self.batch_tile and num_samples > 1:
                 lat, vn = draw_call_noise(generator, num_samples, (1, 4, th // 8, tw // 8), self.device)
                 batch = np.stack(tiles)
+                # one prompt row per tile, num_images_per_prompt = 1: a batch of control images must match the prompt
+                # batch (check_controlnet_conditioning_image, ...inpaint.py:782-790)
+                bcommon = dict(common, prompt_embeds=tpe.repeat(num_samples, 1, 1), negative_prompt_embeds=tne.repeat(num_samples, 1, 1))
                 results_tile = list(self.tile_pipe(image=batch, controlnet_conditioning_image=batch,
-                                                   num_images_per_prompt=num_samples, latents=lat, vae_noise=vn,
-                                                   generator=generator, **common).images)
+                                                   num_images_per_prompt=1, latents=lat, vae_noise=vn,
+                                                   generator=generator, **bcommon).images)
             else:
                 for i in range(num_samples):
                     img_tile = Image.fromarray(tiles[i])

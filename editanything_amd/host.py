@@ -91,33 +91,43 @@ def resolve_seed(seed):
 
 
 def prepare_image(image):
-    """…inpaint.py:142-163: PIL / uint8 HWC / tensor -> float32 [B,3,H,W] in [-1, 1]."""
+    """…inpaint.py:142-163: tensor [3,H,W] / [B,3,H,W] (cast to float32), or PIL / uint8 HWC array / a list of either
+    -> float32 [B,3,H,W] in [-1, 1]."""
     if isinstance(image, torch.Tensor):
-        return image if image.ndim == 4 else image[None]
-    if isinstance(image, Image.Image):
-        image = np.asarray(image.convert("RGB"))
-    image = np.asarray(image)
-    if image.ndim == 3:
-        image = image[None]
-    return torch.from_numpy(image.transpose(0, 3, 1, 2).copy()).float() / 127.5 - 1.0
+        if image.ndim == 3:
+            image = image.unsqueeze(0)
+        return image.to(dtype=torch.float32)
+    if isinstance(image, (Image.Image, np.ndarray)):
+        image = [image]
+    if isinstance(image[0], Image.Image):
+        image = np.concatenate([np.array(i.convert("RGB"))[None, :] for i in image], axis=0)
+    else:
+        image = np.concatenate([np.asarray(i)[None, :] for i in image], axis=0)
+    return torch.from_numpy(image.transpose(0, 3, 1, 2).copy()).to(dtype=torch.float32) / 127.5 - 1.0
 
 
 def prepare_mask_image(mask):
-    """…inpaint.py:166-187: -> float32 [B,1,H,W] binarised at 0.5."""
+    """…inpaint.py:290-326 -> [B,1,H,W] binarised at 0.5.  Same cases as the reference: a 2-D tensor is one mask, a
+    3-D tensor is [1,H,W] (one mask) or [B,H,W] (a batch); PIL masks are converted to "L" and divided by 255, ndarray
+    masks are taken AS THEY ARE ([H,W] each, already in [0, 1]); a list is stacked along the batch axis.  The one
+    difference: the reference binarises a tensor argument in place, here the caller's tensor is left alone."""
     if isinstance(mask, torch.Tensor):
-        m = mask.float()
+        m = mask
         if m.ndim == 2:
-            m = m[None, None]
+            m = m.unsqueeze(0).unsqueeze(0)
+        elif m.ndim == 3 and m.shape[0] == 1:
+            m = m.unsqueeze(0)
         elif m.ndim == 3:
-            m = m[:, None] if m.shape[0] != 1 else m[None]
+            m = m.unsqueeze(1)
+        m = m.clone()
     else:
-        if isinstance(mask, Image.Image):
-            mask = np.asarray(mask.convert("L"))
-        m = np.asarray(mask).astype(np.float32) / 255.0
-        if m.ndim == 3:
-            m = m[..., 0]
-        m = torch.from_numpy(m)[None, None]
-    m = m.clone()
+        if isinstance(mask, (Image.Image, np.ndarray)):
+            mask = [mask]
+        if isinstance(mask[0], Image.Image):
+            m = np.concatenate([np.array(x.convert("L"))[None, None, :] for x in mask], axis=0).astype(np.float32) / 255.0
+        else:
+            m = np.concatenate([np.asarray(x)[None, None, :] for x in mask], axis=0).copy()
+        m = torch.from_numpy(m)
     m[m < 0.5] = 0
     m[m >= 0.5] = 1
     return m

@@ -72,7 +72,8 @@ def merge_lora(unet_state_dict, lora_state_dict, multiplier=1.0, layers_per_bloc
         for layer, elems in updates.items():
             delta = lora_delta(elems, multiplier)
             if "text" in layer:
-                te[layer.split(LORA_PREFIX_TEXT_ENCODER + "_")[-1]] = te.get(layer, 0) + delta
+                name = layer.split(LORA_PREFIX_TEXT_ENCODER + "_")[-1]
+                te[name] = te.get(name, 0) + delta      # several LoRA files touching one layer accumulate
                 continue
             key = ldm_key(layer.split(LORA_PREFIX_UNET + "_")[-1], layers_per_block) + ".weight"
             w = out[key]

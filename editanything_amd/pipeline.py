@@ -45,6 +45,7 @@ def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
 
 class StableDiffusionControlNetInpaintPipeline:
     vae_scale_factor = 8
+    _guess_mode_cond_only = False   # the generation pipeline runs the ControlNet on the conditional half only in guess mode
 
     def __init__(self, vae, unet, controlnet, scheduler=None, text_encoder=None, tokenizer=None, device="cuda",
                  use_graph=True):
@@ -176,21 +177,33 @@ class StableDiffusionControlNetInpaintPipeline:
             prompt_embeds = torch.cat([ne, prompt_embeds])
         return prompt_embeds
 
-    def _prepare_cond_image(self, img, width, height, batch, do_cfg):
-        """prepare_controlnet_conditioning_image (…inpaint.py:190-243).  Tensors pass through unscaled (the SAM id-map
-        control is fed as float 0..255, sam2image.py:158-177); PIL / uint8 arrays are scaled to [0, 1]."""
+    def _prepare_cond_image(self, img, width, height, batch, num_images_per_prompt, do_cfg):
+        """prepare_controlnet_conditioning_image (…inpaint.py:328-388).  Tensors (or a list of tensors, concatenated)
+        pass through unscaled -- the SAM id-map control is fed as float 0..255, sam2image.py:158-177; PIL images (or a
+        list of them) are LANCZOS-resized to (width, height) and scaled to [0, 1].  One image is repeated for the whole
+        batch, a batch of images `num_images_per_prompt` times each (repeat_interleave: [c0, c0, c1, c1], the order of
+        the prompt embeddings)."""
         if not isinstance(img, torch.Tensor):
-            arr = np.asarray(img.convert("RGB") if hasattr(img, "convert") else img)
-            if arr.ndim == 3:
-                arr = arr[None]
-            img = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+            if hasattr(img, "convert"):
+                img = [img]
+            if isinstance(img, np.ndarray):      # not a reference input kind: uint8 HWC / BHWC, treated like PIL
+                arr = img[None] if img.ndim == 3 else img
+                img = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+            elif hasattr(img[0], "convert"):
+                from PIL import Image as _PIL
+                arr = np.concatenate([np.array(i.resize((width, height), resample=_PIL.LANCZOS))[None, :] for i in img], axis=0)
+                img = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(0, 3, 1, 2)
+            else:
+                img = torch.cat([i if i.ndim == 4 else i[None] for i in img], dim=0)
         img = img.float()
         if img.ndim == 3:
             img = img[None]
         if img.shape[-2:] != (height, width):
             img = F.interpolate(img, size=(height, width), mode="bilinear", align_corners=False)
+        repeat_by = batch if img.shape[0] == 1 else num_images_per_prompt
+        img = img.repeat_interleave(repeat_by, dim=0)
         if img.shape[0] != batch:
-            img = img.repeat(batch // img.shape[0], 1, 1, 1)
+            raise ValueError(f"controlnet conditioning image batch {img.shape[0]} does not match the effective batch size {batch}")
         img = img.to(self.device)
         return torch.cat([img] * 2) if do_cfg else img
 
@@ -285,7 +298,7 @@ class StableDiffusionControlNetInpaintPipeline:
         self._mark("start")
         embeds = self._encode_prompt(prompt, num_images_per_prompt, do_cfg, negative_prompt, prompt_embeds,
                                      negative_prompt_embeds)
-        hints = [self._prepare_cond_image(ci, width, height, n_img, do_cfg) for ci in cond_images]
+        hints = [self._prepare_cond_image(ci, width, height, n_img, num_images_per_prompt, do_cfg) for ci in cond_images]
         n_out = len(self.unet.plan["input"]) + 1
         scales = controlnet_conditioning_scale
         if not isinstance(scales, (list, tuple)):
@@ -297,10 +310,16 @@ class StableDiffusionControlNetInpaintPipeline:
                 per_net.append([float(s) * r for r in ramp])
             else:
                 per_net.append([float(s)] * n_out)
+        nb_rows = 2 * n_img if do_cfg else n_img
         if controlnet_conditioning_scale_map is not None:
-            per_net[0] = self._scale_map_rows(controlnet_conditioning_scale_map, per_net[0], height, width,
-                                              2 * n_img if do_cfg else n_img)
-
+            # the reference multiplies EVERY net's scale by the map (utils/stable_diffusion_controlnet.py:490-495,
+            # …inpaint.py:1874-1880); ControlNetModel2 then resizes it per level (bilinear, align_corners=True, :785-802)
+            per_net = [self._scale_map_rows(controlnet_conditioning_scale_map, base, height, width, nb_rows)
+                       for base in per_net]
+        if guess_mode and do_cfg and self._guess_mode_cond_only:
+            # generation pipeline, utils/stable_diffusion_controlnet.py:579-600: the ControlNet sees the conditional half
+            # only and ZEROS are added to the unconditional half -> per-row scale 0 for the first n_img samples
+            per_net = [self._zero_uncond_rows(base, height, width, n_img) for base in per_net]
         sch = self.scheduler
         timesteps = sch.set_timesteps(num_inference_steps, eta=eta)
         nsteps = len(timesteps)
@@ -310,7 +329,7 @@ class StableDiffusionControlNetInpaintPipeline:
         extra = blend_mask = x_orig = None
         if image is not None:
             img = host.prepare_image(image).to(self.device)
-            msk = host.prepare_mask_image(mask_image).to(self.device)
+            msk = host.prepare_mask_image(mask_image).to(self.device, torch.float32)
             if img.shape[-2:] != (height, width):
                 img = F.interpolate(img, size=(height, width), mode="bilinear", align_corners=False)
                 msk = F.interpolate(msk, size=(height, width), mode="nearest")
@@ -460,13 +479,8 @@ class StableDiffusionControlNetInpaintPipeline:
         st["lat"].copy_(saved)
         return g
 
-    def _scale_map_rows(self, scale_map, base, height, width, nb):
-        """ControlNetModel2 spatial scale map (utils/stable_diffusion_controlnet.py:785-802): per output level a
-        bilinear resize of the [H, W] map -> one fp32 multiplier per output row (pixel)."""
-        sm = torch.as_tensor(scale_map, dtype=torch.float32, device=self.device)
-        sm = sm.reshape(1, 1, *sm.shape[-2:])
-        rows = []
-        res = [(height // 8) >> k for k in (0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3)][:len(base) - 1]
+    def _level_sizes(self, height, width):
+        """(h, w) of every ControlNet output: one per input block, plus the middle block."""
         sizes = []
         h8, w8 = height // 8, width // 8
         ds = 1
@@ -475,10 +489,29 @@ class StableDiffusionControlNetInpaintPipeline:
                 ds *= 2
             sizes.append((h8 // ds, w8 // ds))
         sizes.append(sizes[-1])
-        del res
-        for (hh, ww), b in zip(sizes, base):
-            m = F.interpolate(sm, size=(hh, ww), mode="bilinear", align_corners=False).reshape(-1) * b
+        return sizes
+
+    def _scale_map_rows(self, scale_map, base, height, width, nb):
+        """ControlNetModel2 spatial scale map (utils/stable_diffusion_controlnet.py:785-802): per output level a bilinear
+        (align_corners=True) resize of the [H, W] / [1, H, W] / [1, 1, H, W] map times the level's scalar scale -> one
+        fp32 multiplier per output row (pixel), the same for every sample."""
+        sm = torch.as_tensor(scale_map, dtype=torch.float32, device=self.device)
+        sm = sm.reshape(1, 1, *sm.shape[-2:])
+        rows = []
+        for (hh, ww), b in zip(self._level_sizes(height, width), base):
+            m = F.interpolate(sm, size=(hh, ww), mode="bilinear", align_corners=True).reshape(-1) * b
             rows.append(m.repeat(nb).contiguous())
+        return rows
+
+    def _zero_uncond_rows(self, base, height, width, n_img):
+        rows = []
+        for (hh, ww), b in zip(self._level_sizes(height, width), base):
+            if torch.is_tensor(b):
+                r = b.clone()
+            else:
+                r = torch.full((2 * n_img * hh * ww,), float(b), dtype=torch.float32, device=self.device)
+            r[:n_img * hh * ww] = 0
+            rows.append(r)
         return rows
 
 
@@ -494,6 +527,8 @@ class StableDiffusionControlNetInpaintMixingPipeline(StableDiffusionControlNetIn
 class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline):
     """Generation variant (sam2image.py:168-177 calls `pipe(prompt=..., image=control, ...)`): here `image` IS the
     ControlNet conditioning image, as in diffusers' StableDiffusionControlNetPipeline."""
+
+    _guess_mode_cond_only = True    # utils/stable_diffusion_controlnet.py:579-600
 
     def __call__(self, prompt=None, image=None, **kw):
         if "controlnet_conditioning_image" not in kw:

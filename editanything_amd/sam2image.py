@@ -101,8 +101,12 @@ class Demo:
                 kw = dict(prompt=[prompt + ', ' + a_prompt] * 1, negative_prompt=[n_prompt] * 1)
             # NOTE scale / strength / guess_mode / eta are accepted but NOT forwarded, exactly like the reference
             # (sam2image.py:168-177): guidance stays at the pipeline default 7.5.
+            # The reference passes num_samples prompts AND num_images_per_prompt=num_samples (sam2image.py:168-177), i.e. it
+            # denoises num_samples^2 images and keeps the first num_samples.  Those are the images of prompt 0 (all
+            # prompts and control images are identical) drawn from the first num_samples rows of the generator's x_T,
+            # which is exactly what ONE prompt x num_samples images produces: same outputs, 1/num_samples of the work.
             x_samples = pipe(num_images_per_prompt=num_samples, num_inference_steps=ddim_steps, generator=generator,
-                             height=H, width=W, controlnet_conditioning_image=control, **kw).images
+                             height=H, width=W, controlnet_conditioning_image=control[:1], **kw).images
             results = [x_samples[i] for i in range(num_samples)]
         return [full_segmask] + results, prompt
 

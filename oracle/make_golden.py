@@ -247,12 +247,123 @@ def gen_host():
     print("  show_anns: bit-exact on", len(anns), "masks")
 
 
+def pipe_nets():
+    """(state dict, cfg) pairs of the tiny networks the pipeline goldens run on (seeds fixed here AND in the tests)."""
+    un9_cfg = dict(arch.TINY_UNET, in_channels=9)
+    return dict(
+        cn=(synth.synth_state_dict_torch(arch.unet_param_shapes(arch.TINY_CONTROLNET, True), SEED), arch.TINY_CONTROLNET),
+        cn2=(synth.synth_state_dict_torch(arch.unet_param_shapes(arch.TINY_CONTROLNET, True), SEED + 7), arch.TINY_CONTROLNET),
+        unet=(synth.synth_state_dict_torch(arch.unet_param_shapes(arch.TINY_UNET), SEED + 1), arch.TINY_UNET),
+        unet9=(synth.synth_state_dict_torch(arch.unet_param_shapes(un9_cfg), SEED + 6), un9_cfg),
+        vae=(synth.synth_state_dict_torch(arch.vae_param_shapes(arch.TINY_VAE), SEED + 2), arch.TINY_VAE))
+
+
+def pipe_inputs():
+    d = np.load(os.path.join(GOLD, "ldm_tiny_ddim.npz"))
+    g = torch.Generator("cpu").manual_seed(5)
+    image = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, 128, 128)
+    mask[:, :, 24:104, 40:120] = 1.0
+    hint2 = torch.rand(1, 3, 128, 128, generator=g) * 2 - 1          # inpaint-condition style second hint
+    smap = torch.rand(1, 1, 128, 128, generator=g)                   # controlnet_conditioning_scale_map
+    f = lambda k: torch.from_numpy(d[k])
+    return dict(ctx=f("ctx"), un_ctx=f("un_ctx"), hint=f("hint"), image=image, mask=mask, hint2=hint2, smap=smap)
+
+
+PIPE_CASES = {   # name -> (unet key, controlnets, kwargs of the inpaint call)
+    "a_none": ("unet", ["cn"], dict(alignment_ratio=None)),
+    "a_075": ("unet", ["cn"], dict(alignment_ratio=0.75)),
+    "a_050_eta": ("unet", ["cn"], dict(alignment_ratio=0.5, eta=0.3)),
+    "nine": ("unet9", ["cn"], dict()),
+    "two_nets": ("unet", ["cn", "cn2"], dict(controlnet_conditioning_scale=[1.0, 0.6], alignment_ratio=None)),
+    "guess": ("unet", ["cn"], dict(guess_mode=True, controlnet_conditioning_scale=0.8)),
+    "nipp2": ("unet", ["cn"], dict(num_images_per_prompt=2, alignment_ratio=None)),
+}
+GEN_CASES = {
+    "plain": (["cn"], dict()),
+    "guess": (["cn"], dict(guess_mode=True)),
+    "smap_two": (["cn", "cn2"], dict(controlnet_conditioning_scale=[1.0, 0.5], smap=True)),
+    "smap_one": (["cn"], dict(controlnet_conditioning_scale=0.9, smap=True)),
+}
+
+
+def pipe_case_kwargs(name, inp):
+    """The call both the reference pipeline and the product receive for inpaint golden case `name`."""
+    ukey, cns, extra = PIPE_CASES[name]
+    kw = dict(prompt_embeds=inp["ctx"], negative_prompt_embeds=inp["un_ctx"], image=inp["image"].clone(),
+              mask_image=inp["mask"].clone(), num_inference_steps=4, guidance_scale=7.5, output_type="latent",
+              height=128, width=128)
+    kw["controlnet_conditioning_image"] = inp["hint"] if len(cns) == 1 else [inp["hint"], inp["hint2"].expand(2, -1, -1, -1).contiguous()]
+    kw.update(extra)
+    return ukey, cns, kw
+
+
+def gen_case_kwargs(name, inp):
+    cns, extra = GEN_CASES[name]
+    extra = dict(extra)
+    kw = dict(prompt_embeds=inp["ctx"], negative_prompt_embeds=inp["un_ctx"], num_inference_steps=4, guidance_scale=7.5,
+              output_type="latent", height=128, width=128)
+    kw["image"] = inp["hint"] if len(cns) == 1 else [inp["hint"], inp["hint2"].expand(2, -1, -1, -1).contiguous()]
+    if extra.pop("smap", False):
+        kw["controlnet_conditioning_scale_map"] = inp["smap"]
+    kw.update(extra)
+    return cns, kw
+
+
+def gen_pipeline():
+    """Inpaint / generation pipeline goldens: the reference's OWN `__call__` code (oracle/ref_pipeline.py) on the tiny
+    networks, 4 DDIM steps, CFG 7.5, seeded CPU generator; the restatement (oracle/pipeline_oracle.py) must agree."""
+    from oracle import pipeline_oracle, ref_pipeline
+    nets, inp = pipe_nets(), pipe_inputs()
+    out = {}
+    for name in PIPE_CASES:
+        ukey, cns, kw = pipe_case_kwargs(name, inp)
+        pipe = ref_pipeline.inpaint_pipeline([nets[c] for c in cns], nets[ukey], nets["vae"])
+        with torch.no_grad():
+            ref = pipe(generator=torch.Generator("cpu").manual_seed(11), **kw).images
+        ukey, cns, kw = pipe_case_kwargs(name, inp)
+        mine = pipeline_oracle.inpaint_call([nets[c] for c in cns], nets[ukey], nets["vae"],
+                                            generator=torch.Generator("cpu").manual_seed(11), **kw)
+        close(mine, ref, 1e-4, f"inpaint pipeline [{name}]")
+        out["inpaint_" + name] = ref.numpy()
+        out["vae_noise_" + name] = pipe.vae.noise_log[0].numpy()
+    # decoded image (output_type "np") of the first case
+    ukey, cns, kw = pipe_case_kwargs("a_none", inp)
+    kw["output_type"] = "np"
+    pipe = ref_pipeline.inpaint_pipeline([nets[c] for c in cns], nets[ukey], nets["vae"])
+    with torch.no_grad():
+        img = pipe(generator=torch.Generator("cpu").manual_seed(11), **kw).images
+    ukey, cns, kw = pipe_case_kwargs("a_none", inp)
+    kw["output_type"] = "np"
+    mine = pipeline_oracle.inpaint_call([nets[c] for c in cns], nets[ukey], nets["vae"],
+                                        generator=torch.Generator("cpu").manual_seed(11), **kw)
+    close(torch.from_numpy(mine), torch.from_numpy(img), 1e-4, "inpaint pipeline decoded image")
+    out["image_a_none"] = img
+    for name in GEN_CASES:
+        cns, kw = gen_case_kwargs(name, inp)
+        pipe = ref_pipeline.generation_pipeline([nets[c] for c in cns], nets["unet"], nets["vae"])
+        with torch.no_grad():
+            ref = pipe(generator=torch.Generator("cpu").manual_seed(12), **kw).images
+        cns, kw = gen_case_kwargs(name, inp)
+        mine = pipeline_oracle.generate_call([nets[c] for c in cns], nets["unet"], nets["vae"],
+                                             generator=torch.Generator("cpu").manual_seed(12), **kw)
+        close(mine, ref, 1e-4, f"generation pipeline [{name}]")
+        out["generate_" + name] = ref.numpy()
+    np.savez_compressed(os.path.join(GOLD, "pipe_tiny.npz"), image=inp["image"].numpy(), mask=inp["mask"].numpy(),
+                        hint2=inp["hint2"].numpy(), smap=inp["smap"].numpy(), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--pipeline" in sys.argv:        # only the pipeline goldens (the rest is unchanged since round 1)
+        ref_import.load()
+        gen_pipeline()
+        sys.exit(0)
     print("SAM ..."); gen_sam()          # before the import stubs (transformers probes for a real torchvision)
     print("SAM prompt encoder + mask decoder ..."); gen_sam_decoder()
     ns = ref_import.load()
     print("LDM (ControlNet/UNet/DDIM) ..."); gen_ldm(ns)
     print("VAE ..."); gen_vae(ns)
     print("host ..."); gen_host()
+    print("pipelines (reference __call__ executed from source) ..."); gen_pipeline()
     print("golden vectors written to", GOLD)

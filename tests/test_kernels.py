@@ -752,3 +752,67 @@ def test_groupnorm_sd21_shapes(kb, B, HW, c1, c2):
     xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
     ref = F.silu(F.group_norm(xin.permute(0, 2, 1), 32, t(gamma), t(beta), 1e-5))
     assert relerr(kb.down(out), ref.permute(0, 2, 1).numpy()) < 3e-3
+
+
+@pytest.mark.parametrize("M,N,K,act,res,rowvec", [
+    (256, 320, 128, 0, True, False),     # 128x160 tiles (2 column tiles), residual
+    (200, 160, 64, 1, False, False),     # ragged M, SiLU
+    (72, 160, 192, 2, True, False),      # 64-row tiles (M <= 64-row plan), GELU + residual
+    (130, 192, 128, 0, True, False),     # 128-wide column tiles, ragged M and N (N = 192 -> second tile half empty)
+    (256, 256, 64, 1, False, True),      # per-sample row vector (time embedding), 2 samples of 128 rows
+    (64, 128, 64, 0, False, False),      # one 64 x 128 tile
+])
+@pytest.mark.parametrize("variant", ["", "1"])     # the plan's own tile height (64 rows at these sizes) / forced 128-row tiles
+def test_register_direct_epilogue(kb, M, N, K, act, res, rowvec, variant, monkeypatch):
+    """ea_gemm2.h TR = 1 (transposed accumulators, v_permlane16_swap pairing, 16-byte stores straight from registers)
+    == the LDS-slab epilogue it replaces BIT FOR BIT (same products, same fp32 summation and epilogue order), and both
+    == torch.  EA_GEMM2_TR=0 keeps the slab epilogue for the A/B."""
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    rv = f32(M // 128, N) if rowvec else None
+    outs = []
+    if variant:
+        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+    for tr in ("1", "0"):
+        monkeypatch.setenv("EA_GEMM2_TR", tr)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias, act=act, scale=0.75, residual=R, rowvec=rv, rows_per_group=128 if rowvec else 1)
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1]), "register-direct epilogue differs from the slab epilogue"
+    ref = t(A) @ t(W).T + t(bias)
+    if rowvec:
+        ref = ref + t(rv).repeat_interleave(128, 0)
+    ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,act,res", [
+    (2, 16, 16, 64, 160, 1, True),       # 3x3, SiLU + residual, 128-row tiles
+    (4, 8, 8, 64, 320, 0, False),        # two column tiles, a 128-row tile spans two samples (row vector group = 64 rows)
+])
+def test_register_direct_epilogue_conv(kb, B, H, W, cin, cout, act, res, monkeypatch):
+    x = f16(B, H, W, cin)
+    w, bias = f16(cout, cin, 3, 3, scale=0.1), f32(cout)
+    rv = f32(B, cout)
+    R = f16(B * H * W, cout) if res else None
+    outs = []
+    for tr in ("1", "0"):
+        monkeypatch.setenv("EA_GEMM2_TR", tr)
+        src = conv_src(x, None, None, 3, 1, 1, 0, H, W)
+        out = kb.zeros((B * H * W, cout), np.float16)
+        e = epilogue(out, bias=bias, act=act, residual=R, rowvec=rv, rows_per_group=H * W)
+        ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(B * H * W, cout, 9 * cin, 1))
+        st = kb.lib.ea_conv2d_f16(C.byref(src), ptr(pack_conv_w(w)), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream)
+        assert st == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    ref = F.conv2d(t(x).permute(0, 3, 1, 2), t(w), t(bias), padding=1) + t(rv)[:, :, None, None]
+    ref = (F.silu(ref) if act == 1 else ref).permute(0, 2, 3, 1).reshape(-1, cout)
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 3e-3

@@ -46,7 +46,7 @@ class StubPipe:
         self.tokenizer, self.text_encoder = StubTokenizer(), StubEncoder()
 
     def __call__(self, **kw):
-        n = kw.get("num_images_per_prompt", 1)
+        n = kw.get("num_images_per_prompt", 1) * (kw["prompt_embeds"].shape[0] if kw.get("prompt_embeds") is not None else 1)
         h, w = kw["height"], kw["width"]
         shape = (n, 4, h // 8, w // 8)
         g = kw.get("generator")
@@ -216,7 +216,9 @@ def test_batched_tile_refinement_consumes_the_noise_stream_in_reference_order():
     out = bat.process(s, enable_tile=True, refine_alignment_ratio=0.9, refine_image_resolution=128, **PROCESS_ARGS)
     assert len(out[0]) == 3
     (call,) = tile_bat.calls
-    assert call["num_images_per_prompt"] == 3 and call["image"].shape == (3, 128, 128, 3)
+    # one prompt row per tile (a batch of control images must match the prompt batch, ...inpaint.py:782-790)
+    assert call["num_images_per_prompt"] == 1 and call["prompt_embeds"].shape[0] == 3
+    assert call["image"].shape == (3, 128, 128, 3)
     assert call["image"] is call["controlnet_conditioning_image"]
     assert call["latents"].shape == call["vae_noise"].shape == (3, 4, 16, 16)
     for i, c in enumerate(tile_seq.calls):
@@ -335,8 +337,9 @@ def test_gpu_tile_pipeline_batched_latents_equal_sequential():
                 num_images_per_prompt=1, generator=gen, **common).images for i in range(3)]
     gen = torch.Generator().manual_seed(77)
     lat, vn = el.draw_call_noise(gen, 3, (1, 4, 16, 16), "cuda")
-    bat = tile(image=imgs, controlnet_conditioning_image=imgs, num_images_per_prompt=3, latents=lat, vae_noise=vn,
-               generator=gen, **common).images
+    bcommon = dict(common, prompt_embeds=pe.repeat(3, 1, 1), negative_prompt_embeds=ne.repeat(3, 1, 1))
+    bat = tile(image=imgs, controlnet_conditioning_image=imgs, num_images_per_prompt=1, latents=lat, vae_noise=vn,
+               generator=gen, **bcommon).images
     ref = torch.cat(seq).float().cpu()
     got = bat.float().cpu()
     assert not torch.isnan(got).any()

@@ -93,7 +93,7 @@ def test_unet_channel_check():
 
 
 def test_call_front_half_with_bench_shaped_inputs():
-    """bench.py's call (tensor image [4,3,512,512] in [-1,1], one mask per image, 4 images per prompt, CFG) through
+    """bench.py's call (tensor image [4,3,512,512] in [-1,1], one mask / control image / prompt row per image, CFG) through
     everything `__call__` does on the host before the first device op -- validation, prompt / control / latent /
     inpaint-input preparation -- with the device parts stubbed out."""
     from editanything_amd.scheduler import DDIMScheduler
@@ -120,10 +120,10 @@ def test_call_front_half_with_bench_shaped_inputs():
     mask = torch.zeros(1, 1, 512, 512)
     mask[:, :, 128:384, 128:384] = 1
     with pytest.raises(Stop):
-        p(prompt_embeds=torch.zeros(1, 77, 1024), negative_prompt_embeds=torch.zeros(1, 77, 1024),
+        p(prompt_embeds=torch.zeros(4, 77, 1024), negative_prompt_embeds=torch.zeros(4, 77, 1024),
           image=torch.rand(4, 3, 512, 512) * 2 - 1, mask_image=mask.repeat(4, 1, 1, 1),
           controlnet_conditioning_image=torch.zeros(4, 3, 512, 512), height=512, width=512, num_inference_steps=20,
-          guidance_scale=7.5, num_images_per_prompt=4, generator=torch.Generator("cpu").manual_seed(0))
+          guidance_scale=7.5, num_images_per_prompt=1, generator=torch.Generator("cpu").manual_seed(0))
     assert seen["vae_in"] == (4, 3, 512, 512) and seen["vae_noise"] == (4, 4, 64, 64)
     assert seen["embeds"] == (8, 77, 1024) and seen["hints"] == [(8, 3, 512, 512)]          # [uncond || cond]
     assert seen["scales"] == [[1.0] * 13]

@@ -1,0 +1,32 @@
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import emu_util
+from emu_util import epilogue, ptr
+from editanything_amd import _lib
+be = emu_util.GpuBackend(_lib.lib()); emu_util.BACKEND = be
+rng = np.random.default_rng(0)
+M, N, K = 256, 320, 128
+A = rng.standard_normal((M, K)).astype(np.float16); W = (rng.standard_normal((N, K)) * 0.2).astype(np.float16)
+outs = {}
+for tr in ("1", "0"):
+    os.environ["EA_GEMM2_TR"] = tr
+    os.environ["EA_GEMM2_VARIANT"] = "1"
+    out = be.zeros((M, N), np.float16)
+    e = epilogue(out)
+    ws = be.zeros((64,), np.float32)
+    st = be.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), 256, be.stream)
+    outs[tr] = be.down(out).astype(np.float32)
+ref = A.astype(np.float32) @ W.astype(np.float32).T
+bad = np.abs(outs["1"] - outs["0"]) > 1e-2
+print("st", st, "bad frac", bad.mean())
+print("bad by col%80 (wave tile col):", [int(bad[:, c::80].any()) for c in range(80)])
+print("bad by row%64:", [int(bad[r::64].any()) for r in range(64)])
+# where does a wrong value actually come from?  search the reference tile for it
+r, c = np.argwhere(bad)[0]
+print("first bad", r, c, outs["1"][r, c], "expected", outs["0"][r, c])
+cand = np.argwhere(np.abs(ref - outs["1"][r, c]) < 2e-3 * max(1, abs(outs["1"][r, c])))
+print("value found in ref at", cand[:10].tolist())
+for (r, c) in np.argwhere(bad)[[5, 50, 500, 5000]]:
+    cand = np.argwhere(np.abs(ref - outs["1"][r, c]) < 2e-3 * max(1, abs(outs["1"][r, c])))
+    print((int(r), int(c)), "->", cand[:6].tolist())
