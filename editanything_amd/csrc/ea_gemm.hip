@@ -89,28 +89,6 @@ static bool fast_eligible(const EaGemmParams& p) {
   return true;
 }
 
-// 3x3 halo convolution (ea_gemm2.h, ILV == 3): stride 1, pad 1, same-size output, no upsampling, 64-channel chunks that
-// do not straddle the concat sources, W a power of two in [16, 64], 128-row tiles made of whole image rows of one image.
-static bool halo_eligible(const EaGemmParams& p) {
-  if (!p.conv || p.ksize != 3 || p.stride != 1 || p.ups || p.pad != 1 || p.a2_add) return false;
-  if (p.Hout != p.Hin || p.Wout != p.Win) return false;
-  const int W = p.Win;
-  if (W < 16 || W > 64 || (W & (W - 1))) return false;
-  if (((long long)p.Hin * W) % 128 || p.M % 128) return false;
-  if ((p.c1 % EA_BK) || (p.c2 % EA_BK) || p.batch != 1) return false;
-  return true;
-}
-
-// A-stationary persistent linear (ea_gemm2.h, ILV == 4): dense A, the whole K (<= 320) of a 128-row panel resident in
-// LDS, 160-wide column tiles walked by the workgroup itself, one of the two streamlined epilogues.
-static bool panel_eligible(const EaGemmParams& p) {
-  if (p.conv || p.batch != 1 || p.splits != 1) return false;
-  if ((p.K % EA_BK) || p.K > 320 || (p.N % 160) || p.N < 160) return false;
-  if (p.epi_fast != 1 && p.epi_fast != 2) return false;
-  if (p.epi_fast == 1 && p.epi.rowvec && (p.epi.rows_per_group % 128)) return false;
-  return true;
-}
-
 // Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
 //   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
 //   EA_GEMM2_VARIANT=k         0 auto; k = 1..8 forces instantiation k of launch_fast:
@@ -119,10 +97,6 @@ static bool panel_eligible(const EaGemmParams& p) {
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
 //        13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG (two wave groups alternate MFMA / load phases, ea_gemm2.h)
-//        15: A-stationary persistent linear (K <= 320, N % 160 == 0): one workgroup per 128 rows walks every column tile
-//            with the A panel resident in LDS; refused (EA_ERR_UNSUPPORTED) on anything else
-//        14: 128 x bn 3x3 convolution over an input HALO tile staged once per 64-channel chunk (eligible convolutions only:
-//            anything else is refused with EA_ERR_UNSUPPORTED so a sweep cannot silently measure another kernel)
 static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0, g_no_tr = 0;
 static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
   const char* f = getenv("EA_GEMM_FORCE");
@@ -176,13 +150,12 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 14 || g_variant == 15) ? 128 : 256;   // 3..6, 8, 13: 256 rows
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10) ? 128 : 256;   // 3..6, 8, 13: 256 rows
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
     for (int s = 1; s <= smax; ++s) {
       if (g_force_splits > 0 && s != g_force_splits && allow_split) continue;
-      if ((g_variant == 14 || g_variant == 15) && s > 1) break;   // the halo convolution / persistent linear have no split-K form
       if (s > 1 && nk / s < 4 && g_force_splits == 0) break;
       // 64-row tiles re-read every weight tile twice as often: with deep split-K (few M tiles, weight-streaming
       // bound) they lose to 128-row tiles in every measured case
@@ -251,15 +224,6 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
         (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 && p.debug != 9)
       p.epi_fast = 2;
   }
-  if (t.kind == 14 && (!halo_eligible(p) || t.splits != 1 || t.bm != 128)) return EA_ERR_UNSUPPORTED;
-  if (t.kind == 15) {
-    if (t.splits != 1 || t.bn != 160 || !panel_eligible(p)) return EA_ERR_UNSUPPORTED;
-    auto kfn = ea_gemm2_kernel<128, 160, 4, 2, 2, 16, 4, 0>;
-    const int smem = (p.K / EA_BK) * (128 * 128) + 2 * 160 * 128 + 8 * 8 * 84 * 4;
-    ea_allow_big_lds(kfn, smem);
-    EA_LAUNCH(kfn, dim3((p.M + 127) / 128, 1, 1), dim3(512, 1, 1), smem, stream, p);
-    return ea_launch_status();
-  }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
   do {                                                                                \
@@ -297,22 +261,6 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 9: if (t.bn == 160) EA_LAUNCH_G2(64, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(64, 128, 2, 2, 2, 16, 0); break;
     case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
     case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
-    case 14: {   // halo convolution: LDS = two weight stages + the halo, sized at run time
-      int lw = 0;
-      while ((1 << lw) < p.Win) ++lw;
-      const int hpieces = (((128 >> lw) + 2) * (p.Win + 2) + 7) / 8;
-      const int smem = 2 * t.bn * 128 + hpieces * 1024;
-      if (t.bn == 160) {
-        auto kfn = ea_gemm2_kernel<128, 160, 2, 2, 2, 16, 3, 0>;
-        ea_allow_big_lds(kfn, smem);
-        EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);
-      } else {
-        auto kfn = ea_gemm2_kernel<128, 128, 2, 2, 2, 16, 3, 0>;
-        ea_allow_big_lds(kfn, smem);
-        EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);
-      }
-      break;
-    }
     case 13: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 2); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 2); break;   // ping-pong
     case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
     default: return EA_ERR_UNSUPPORTED;

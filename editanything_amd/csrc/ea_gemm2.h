@@ -180,7 +180,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
   static_assert(MT == 16 || MT == 32, "MFMA tile");
-  static_assert(ILV == 0 || ILV == 3 || ILV == 4 || STAGES == 3, "interleaved issue / ping-pong need the 3-deep ring");
+  static_assert(ILV == 0 || STAGES == 3, "interleaved issue / ping-pong need the 3-deep ring");
   static_assert(WTM % MT == 0 && WTN % MT == 0, "wave tile must be a whole number of MFMA tiles");
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;          // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
@@ -196,8 +196,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   const int wm = wave / WN, wn = wave % WN;
 
   EA_STAMP(0);
-  // ILV == 4 (A-stationary persistent): one workgroup per ROW tile, it walks all the column tiles itself
-  const int tiles_n = (ILV == 4) ? 1 : (p.N + BN - 1) / BN;
+  const int tiles_n = (p.N + BN - 1) / BN;
   const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
   const int tile = ea_xcd_remap(blockIdx.x, ntile);
   // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
@@ -454,175 +453,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #undef EA_LOADF
 
   EA_STAMP(1);
-  if (ILV == 4) {
-    // ---- A-stationary persistent linear (opt-in kind 15; dense A, K <= 320, N % BN == 0).
-    // The level-0 transformer linears ([32768 x {320, 960, 2560} x 320]) give every workgroup of the tiled kernel
-    // only five K tiles between a prologue (first-tile DMA latency) and an epilogue -- 8 rounds of ~13 us on the
-    // GEGLU launch -- and re-stage the same [128 x 320] A panel for every column tile.  Here one workgroup owns 128
-    // rows (M / 128 = 256 workgroups = one per CU at M = 32768), stages the A panel ONCE (80 KiB), and streams the
-    // weight tiles of ALL its column tiles through a 2-stage ring; the epilogue slabs have their own LDS, so the next
-    // column tile's weights land while the current tile is written out.  8 waves as 4 x 2 (wave tile 32 x 80).
-    // LDS: [A panel: K/64 x 16 KiB][weight ring: 2 x BN x 128 B][slabs: 8 waves x 8 rows x (80 + 4) floats].
-    // Synchronisation, first version: vmcnt(0) + barrier per K tile (weight tile g + 1 in flight during compute(g)).
-    static_assert(ILV != 4 || (BM == 128 && BN == 160 && WM == 4 && WN == 2 && MT == 16 && STAGES == 2 && !LDR),
-                  "A-stationary: 128 x 160 tiles, 8 waves 4 x 2");
-    constexpr int SLR = 8;                          // slab rows
-    constexpr int SLDP = WTN + 4;
-    const int nkp = p.K / EA_BK;                    // K tiles of the panel (<= 5)
-    const int NT = p.N / BN;
-    char* panel = smem;
-    char* wring = smem + nkp * (BM * 128);
-    float* wst = reinterpret_cast<float*>(wring + 2 * BN * 128) + wave * (SLR * SLDP);
-    const EaEpilogue& e = p.epi;
-    // A panel: piece j of K tile kt -> rows (j*NW + wave)*8 .. +7 (a_voff holds the dense per-lane offsets)
-    for (int kt = 0; kt < nkp; ++kt) {
-#pragma unroll
-      for (int j = 0; j < A_PW; ++j)
-        if (A_INSTR % NW == 0 || j * NW + wave < A_INSTR)
-          ea_dma16(rs_a1, a_voff[j], (unsigned)(kt * EA_BK) * 2u, panel + kt * (BM * 128) + (j * NW + wave) * 1024);
-    }
-    auto issue_wp = [&](int g) {
-      const int nt = ea_uniform(g / nkp), kt = ea_uniform(g - (g / nkp) * nkp);
-      const unsigned soff = ((unsigned)(nt * BN) * (unsigned)p.ldw + (unsigned)(kt * EA_BK)) * 2u;
-      char* dst = wring + (g & 1) * (BN * 128);
-#pragma unroll
-      for (int j = 0; j < B_PW; ++j)
-        if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff, dst + (j * NW + wave) * 1024);
-    };
-    auto zero_acc = [&]() {
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] = 0.0f;
-    };
-    auto panel_compute = [&](int kt, int stage) {
-      const char* sa = panel + kt * (BM * 128);
-      const char* sb = wring + stage * (BN * 128);
-      f16x8 qa[2][MI], qb[2][NI];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int ch = ks * 4 + fq;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int r = wm * WTM + i * MT + frow;
-          qa[ks][i] = *reinterpret_cast<const f16x8*>(sa + r * 128 + ((ch ^ ea_swz(r)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int r = wn * WTN + j * MT + frow;
-          qb[ks][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(qa[ks][i], qb[ks][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
-    };
-    // the two streamlined epilogues (p.epi_fast 1: bias / row vector / SiLU / GELU / scale / fp16 residual;
-    // 2: GEGLU with the 80-row packing), on 8-row slabs; same arithmetic as the tiled kernel's
-    // Per-column terms and the residual rows of a column tile are fetched when its K loop STARTS (the loads ride under the
-    // five K tiles): fetched inside the epilogue they would cost a memory round trip per slab on every column tile.
-    const bool geglu = p.epi_fast == 2;
-    const float* rvp = (!geglu && e.rowvec) ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
-    const f16* resp = geglu ? nullptr : e.residual;
-    const int out_w = geglu ? WTN / 2 : WTN, vpr = out_w / 8;
-    constexpr int NSL = WTM / SLR;
-    float cb[NI];
-    f16x8 rq[NSL][2];
-    auto tile_prefetch = [&](int nt) {
-      const int colbase = nt * BN + wn * WTN;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int col = colbase + j * 16 + frow;
-        cb[j] = (e.bias ? e.bias[col] : 0.0f) + (rvp ? rvp[col] : 0.0f);
-      }
-      if (resp) {
-#pragma unroll
-        for (int slab = 0; slab < NSL; ++slab)
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            const int id = lane + 64 * v;
-            const int row = id / vpr, c = id - row * vpr;
-            const int m = m0 + wm * WTM + slab * SLR + row;
-            if (id < SLR * vpr && m < p.M) rq[slab][v] = ea_ld8(resp + (long long)m * e.ldr + colbase + c * 8);
-          }
-      }
-    };
-    auto tile_epilogue = [&](int nt) {
-      const int colbase = nt * BN + wn * WTN;
-      f16* outp = (f16*)e.out;
-      const int obase = geglu ? (colbase >> 1) : colbase;
-#pragma unroll
-      for (int slab = 0; slab < WTM / SLR; ++slab) {
-        const int ii = slab >> 1, half = slab & 1;        // 16-row MFMA tile and which 8 rows of it
-        if ((fq >> 1) == half) {
-#pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            const bool gate = geglu && (j * 16 + frow) >= 40;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float x = acc[MT == 16 ? (ii < MI ? ii : 0) : 0][MT == 16 ? j : 0][r] + cb[j];
-              if (geglu) {
-                if (j >= 2) { const float gx = ea_gelu_erf(x); x = gate ? gx : x; }
-              } else {
-                if (e.act == EA_ACT_SILU) x = ea_silu(x);
-                else if (e.act == EA_ACT_GELU) x = ea_gelu_erf(x);
-                x *= e.scale;
-              }
-              wst[((fq & 1) * 4 + r) * SLDP + j * 16 + frow] = x;
-            }
-          }
-        }
-        ea_wave_lds_sync();
-        const int mrow0 = m0 + wm * WTM + slab * SLR;
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-          const int id = lane + 64 * v;
-          const int row = id / vpr, c = id - row * vpr;
-          const int m = mrow0 + row, n = obase + c * 8;
-          if (id < SLR * vpr && m < p.M) {
-            const float* sp = wst + row * SLDP + c * 8;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
-            f16x8 h;
-            if (geglu) {
-              const f32x4 g0 = *reinterpret_cast<const f32x4*>(sp + 40), g1 = *reinterpret_cast<const f32x4*>(sp + 44);
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] * g0[q] * e.scale); h[4 + q] = (f16)(v1[q] * g1[q] * e.scale); }
-            } else if (resp) {
-              const f16x8 rr = rq[slab][v];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { h[q] = (f16)(v0[q] + (float)rr[q]); h[4 + q] = (f16)(v1[q] + (float)rr[4 + q]); }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { h[q] = (f16)v0[q]; h[4 + q] = (f16)v1[q]; }
-            }
-            ea_st8(outp + (long long)m * e.ldc + n, h);
-          }
-        }
-        ea_wave_lds_sync();
-      }
-    };
-    const int G = (p.debug == 2) ? 0 : NT * nkp;
-    if (G > 0) issue_wp(0);
-    for (int g = 0; g < G; ++g) {
-      ea_wait_dma<0>();
-      ea_raw_barrier();
-      if (g + 1 < G) issue_wp(g + 1);
-      const int nt = g / nkp, kt = g - nt * nkp;
-      if (kt == 0) tile_prefetch(nt);
-      panel_compute(kt, g & 1);
-      if (kt == nkp - 1) {
-        tile_epilogue(nt);
-        zero_acc();
-      }
-    }
-    return;
-  } else if (STAGES == 2 && LDR) {
+  if (STAGES == 2 && LDR) {
     // loader waves + 2-deep ring: the tile after the one being multiplied is in flight during exactly one compute
     // phase, so a single workgroup is DMA-latency bound -- this instantiation is built for TWO 8-wave workgroups per CU
     // (64-row tiles: <= 128 registers, 56 KiB of LDS), whose compute phases fill each other's waits.
@@ -661,132 +492,6 @@ void ea_gemm2_kernel(EaGemmParams p) {
       if (kt + 1 < nk && p.debug != 11 && p.debug != 12) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
       if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
 #endif
-    }
-  } else if (ILV == 3) {
-    // ---- 3x3 convolution over an input HALO tile (stride 1, pad 1, no upsampling; opt-in kind 14).
-    // The im2col loop above stages the A tile nine times per 64-channel chunk -- once per tap, 16 KiB each for a 128-row
-    // tile -- although the nine tiles are shifted views of the same (TH + 2) x (W + 2) pixel neighbourhood.  Here that
-    // halo (W = 32: 6 x 34 pixels x 128 B = 25.5 KiB) is staged ONCE per chunk and the nine taps read their A
-    // fragments from it at a wave-uniform row offset ky * (W + 2) + kx; only the weight tile (BN x 64) still streams
-    // per K tile.  L2 -> LDS traffic per chunk: halo + 9 weight tiles = 206 KiB instead of 324 KiB at W = 32 (the PMC
-    // passes put the im2col form at 6x the algorithmic HBM-side bytes on the 32^2-level convolutions).
-    // K is walked chunk-major (chunk, tap) instead of tap-major: the same products, another fp32 summation order.
-    // Geometry (checked on the host, ea_gemm.hip halo_eligible): W a power of two, 16 <= W <= 64; a 128-row tile is
-    // TH = 128 / W whole image rows of one image (H * W % 128 == 0).  LDS: [2 weight stages][halo], <= 73 KiB, so two
-    // workgroups share a CU as in the im2col kernel.
-    // Synchronisation, first version: full DMA drains (vmcnt(0)) at every barrier -- the weight tile of K tile kt+1 is
-    // in flight during compute(kt), the next chunk's halo is issued after a barrier that follows the last tap's reads
-    // and is exposed once per nine K tiles (the co-resident workgroup covers it).
-    static_assert(ILV != 3 || (BM == 128 && NW == 4 && MT == 16 && STAGES == 2 && !LDR), "halo conv: 128-row 4-wave tiles");
-    constexpr int MAXHP = 9;                      // halo pieces per wave at W = 64 (264 pixels -> 33 1-KiB pieces)
-    const int Wd = p.Win;
-    int lw = 0;
-    while ((1 << lw) < Wd) ++lw;
-    const int HW2 = Wd + 2;
-    const int halo_px = ((BM >> lw) + 2) * HW2;
-    const int hpieces = (halo_px + 7) >> 3;
-    char* wring = smem;
-    char* halo = smem + 2 * BN * 128;
-    const int hwp = p.Hin * Wd;
-    const int bimg = ea_uniform(m0 / hwp);
-    const int y0 = (m0 - bimg * hwp) >> lw;
-    int hpix[MAXHP];                              // source pixel (element index / channels) of this lane's row of piece s; -1 = zero fill
-#pragma unroll
-    for (int s_ = 0; s_ < MAXHP; ++s_) {
-      const int hp = (s_ * NW + wave) * 8 + lrow;
-      const int hy = hp / HW2, hx = hp - hy * HW2;
-      const int iy = y0 - 1 + hy, ix = hx - 1;
-      const bool ok = hp < halo_px && iy >= 0 && iy < p.Hin && ix >= 0 && ix < Wd && m0 < p.M;
-      hpix[s_] = ok ? (bimg * p.Hin + iy) * Wd + ix : -1;
-    }
-    auto issue_halo = [&](int ci) {
-      const int c0 = ea_uniform(ci * EA_BK);
-      const bool second = c0 >= p.c1;
-      const ea_rsrc rs = second ? rs_a2 : rs_a1;
-      const unsigned cs = (unsigned)(second ? p.c2 : p.c1);
-      const unsigned soff = (unsigned)(second ? c0 - p.c1 : c0) * 2u;
-#pragma unroll
-      for (int s_ = 0; s_ < MAXHP; ++s_) {
-        const int k = s_ * NW + wave;
-        if (k < hpieces) {
-          const int hp = k * 8 + lrow;
-          const unsigned voff = hpix[s_] >= 0 ? ((unsigned)hpix[s_] * cs + (unsigned)((slot ^ ea_swz(hp)) * 8)) * 2u : EA_OOB;
-          ea_dma16(rs, voff, soff, halo + k * 1024);
-        }
-      }
-    };
-    auto issue_w = [&](int kt) {
-      const int ci = kt / 9, t = kt - ci * 9;
-      const unsigned soff = (unsigned)ea_uniform(t * ctot + ci * EA_BK) * 2u;
-      char* dst = wring + (kt & 1) * (BN * 128);
-#pragma unroll
-      for (int j = 0; j < B_PW; ++j)
-        if (B_INSTR % NW == 0 || j * NW + wave < B_INSTR) ea_dma16(rs_w, b_voff[j], soff, dst + (j * NW + wave) * 1024);
-    };
-    int p0[MI];                                   // halo row of this lane's output pixel for tap (0, 0), per row tile
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int q = wm * WTM + i * MT + frow;
-      p0[i] = (q >> lw) * HW2 + (q & (Wd - 1));
-    }
-    auto halo_compute = [&](int kt) {
-      const int ci = kt / 9, t = kt - ci * 9;
-      const int ky = t / 3, kx = t - ky * 3;
-      const int toff = ea_uniform(ky * HW2 + kx);
-      const char* sb = wring + (kt & 1) * (BN * 128);
-      f16x8 ha[2][MI], hb[2][NI];
-      auto ld = [&](int ks, int sl) {
-        const int ch = ks * 4 + fq;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const int pp = p0[i] + toff;
-          ha[sl][i] = *reinterpret_cast<const f16x8*>(halo + pp * 128 + ((ch ^ ea_swz(pp)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const int r = wn * WTN + j * MT + frow;
-          hb[sl][j] = *reinterpret_cast<const f16x8*>(sb + r * 128 + ((ch ^ ea_swz(r)) << 4));
-        }
-      };
-      ld(0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        if (ks == 0) ld(1, 1);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[MT == 16 ? i : 0][MT == 16 ? j : 0] = ea_mfma_16x16x32(ha[ks][i], hb[ks][j], acc[MT == 16 ? i : 0][MT == 16 ? j : 0]);
-      }
-#ifndef EA_EMU
-      {   // same pinned double-buffering as compute_tile
-        constexpr int RD = MI + NI, MF = MI * NI;
-        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
-#pragma unroll
-        for (int r = 0; r < RD; ++r) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, (MF >= 2 * RD) ? 2 : 1, 0);
-        }
-        if (MF > ((MF >= 2 * RD) ? 2 : 1) * RD) __builtin_amdgcn_sched_group_barrier(0x008, MF - ((MF >= 2 * RD) ? 2 : 1) * RD, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, MF, 0);
-      }
-#endif
-    };
-    const int nchunk = ctot / EA_BK;
-    const int nkh = (p.debug == 2) ? 0 : nchunk * 9;
-    if (nkh > 0) {
-      issue_halo(0);
-      issue_w(0);
-    }
-    for (int kt = 0; kt < nkh; ++kt) {
-      ea_wait_dma<0>();
-      ea_raw_barrier();                            // W(kt) (and a fresh halo) landed; everyone is past compute(kt - 1)
-      if (kt + 1 < nkh) issue_w(kt + 1);
-      halo_compute(kt);
-      if (kt % 9 == 8 && kt + 1 < nkh) {
-        ea_raw_barrier();                          // every wave has read the last tap: the halo buffer may be refilled
-        issue_halo(kt / 9 + 1);
-      }
     }
   } else if (ILV == 2) {
     // ---- ping-pong (8 waves, 3-deep ring).  The waves form two groups, G0 = waves [0, NW/2) and G1 = the rest; the
@@ -1060,7 +765,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int SLD = WTN + 4;                 // fp32 words per slab row (pad: conflict-free accumulator scatter)
   constexpr int NSLAB = WTM / SLAB;
   constexpr int ITERS = 6, SUB = 3;             // vectors per lane per slab (upper bound), gathered SUB at a time
-  static_assert(ILV == 4 || NW * SLAB * SLD * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+  static_assert(NW * SLAB * SLD * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
   static_assert(WTM % SLAB == 0, "slab rows");
   float* wstg = reinterpret_cast<float*>(smem) + wave * (SLAB * SLD);
   const bool raw = p.splits > 1;
@@ -1125,7 +830,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     constexpr int SLDG = WTN + 4;
     constexpr int VPRG = 5;                                  // 16-byte output vectors per row (40 outputs)
     constexpr int NVG = (SLABG * VPRG + 63) / 64;            // 2
-    static_assert(ILV == 4 || NW * SLABG * SLDG * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    static_assert(NW * SLABG * SLDG * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
     float* wst = reinterpret_cast<float*>(smem) + wave * (SLABG * SLDG);
     const int colbase = n0 + wn * WTN;                       // packed weight row of this wave's first column
     const int obase = colbase >> 1;                          // first output column
@@ -1176,7 +881,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     constexpr int SLDF = WTN + 4;
     constexpr int VPR = WTN / 8;                            // 16-byte output vectors per row
     constexpr int NV = (SLABF * VPR + 63) / 64;             // vectors per lane per slab
-    static_assert(ILV == 4 || NW * SLABF * SLDF * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
+    static_assert(NW * SLABF * SLDF * 4 <= STAGES * STAGE_BYTES, "epilogue slabs must fit in the stage ring");
     float* wst = reinterpret_cast<float*>(smem) + wave * (SLABF * SLDF);
     const int colbase = n0 + wn * WTN;
     const float* rvp = e.rowvec ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;

@@ -97,6 +97,8 @@ def prepare_image(image):
         if image.ndim == 3:
             image = image.unsqueeze(0)
         return image.to(dtype=torch.float32)
+    if isinstance(image, np.ndarray) and image.ndim == 4:      # [B,H,W,3]: a batch in one array (the batched tile
+        image = list(image)                                     # refinement passes one; the reference takes HWC only)
     if isinstance(image, (Image.Image, np.ndarray)):
         image = [image]
     if isinstance(image[0], Image.Image):
