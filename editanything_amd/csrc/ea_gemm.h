@@ -42,8 +42,14 @@ struct EaEpilogue {
   void* out;              // fp16 or fp32 [M][ldc]
   int ldc;
   int out_f32;
-  int geglu_block;        // GEGLU packing granule (64 or 160)
+  int geglu_block;        // GEGLU packing granule (64, 80 or 32)
   int M, N;               // logical output extent (N = N_gemm/2 for GEGLU)
+  // LayerNorm folded into the contraction (register-direct epilogue only; see include/editanything_hip.h)
+  const float* ln_stats;  // [ln_parts][M][2] partial (sum, sum of squares) of A's rows; NULL = no fold
+  int ln_parts;
+  const float* ln_colsum; // [N_gemm] row sums of the gamma-folded fp16 weight
+  float ln_eps;
+  float* row_stats_out;   // [parts][M][2] partial (sum, sum of squares) of the OUTPUT rows, one part per wave-column block
 };
 
 struct EaGemmParams {
@@ -433,4 +439,28 @@ __global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
     }
     ea_epilogue_store8(p.epi, batch * p.strideC, batch * p.strideR, m, n, v, true);
   }
+}
+
+// Row statistics of a finished fp16 [M][ld] output, in the layout the register-direct epilogue writes
+// ([parts][M][2] partial (sum, sum of squares)): the fallback producer for launches whose epilogue cannot emit them
+// (split-K, generic kernel).  One wave per row; everything lands in part 0, the other parts are zeroed.
+__global__ __launch_bounds__(256) void ea_row_stats_kernel(const f16* x, int ld, float* stats, int M, int C, int parts) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s1 = 0.0f, s2 = 0.0f;
+  const f16* xr = x + (long long)row * ld;
+  for (int c = lane * 8; c < C; c += 64 * 8) {
+    if (c + 8 <= C) {
+      const f16x8 v = ea_ld8(xr + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s1 += f; s2 += f * f; }
+    } else {
+      for (int j = 0; c + j < C; ++j) { const float f = (float)xr[c + j]; s1 += f; s2 += f * f; }
+    }
+  }
+  s1 = ea_wave_sum(s1);
+  s2 = ea_wave_sum(s2);
+  if (lane == 0) *reinterpret_cast<f32x2*>(stats + (long long)row * 2) = f32x2{s1, s2};
+  else if (lane < parts) *reinterpret_cast<f32x2*>(stats + ((long long)lane * M + row) * 2) = f32x2{0.0f, 0.0f};
 }

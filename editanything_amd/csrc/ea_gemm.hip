@@ -52,10 +52,18 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
   e.ldc = epi->ldc;
   e.out_f32 = epi->out_f32;
   e.geglu_block = epi->geglu_block > 0 ? epi->geglu_block : 64;
+  e.ln_stats = epi->ln_stats;
+  e.ln_parts = epi->ln_parts;
+  e.ln_colsum = epi->ln_colsum;
+  e.ln_eps = epi->ln_eps;
+  e.row_stats_out = epi->row_stats_out;
+  if (e.ln_stats && (!e.ln_colsum || e.ln_parts <= 0)) return EA_ERR_BAD_ARG;
+  if ((((uintptr_t)e.ln_stats) & 7) || (((uintptr_t)e.ln_colsum) & 15) || (((uintptr_t)e.row_stats_out) & 7)) return EA_ERR_BAD_ARG;
   e.M = M;
   e.N = (epi->act == EA_ACT_GEGLU) ? N / 2 : N;
   if (epi->act < 0 || epi->act > EA_ACT_GEGLU) return EA_ERR_BAD_ARG;
-  if (epi->act == EA_ACT_GEGLU && e.geglu_block != 64 && e.geglu_block != 80) return EA_ERR_UNSUPPORTED;
+  if (epi->act == EA_ACT_GEGLU && e.geglu_block != 64 && e.geglu_block != 80 && e.geglu_block != 32) return EA_ERR_UNSUPPORTED;
+  if (epi->act == EA_ACT_GEGLU && e.row_stats_out) return EA_ERR_UNSUPPORTED;
   if (epi->act == EA_ACT_GEGLU && (N % e.geglu_block) != 0) return EA_ERR_BAD_SHAPE;
   if (epi->act == EA_ACT_GEGLU && epi->bias_per_row) return EA_ERR_UNSUPPORTED;
   if (e.ldc < e.N) return EA_ERR_BAD_SHAPE;
@@ -74,7 +82,8 @@ struct Plan2 {
 
 static bool fast_eligible(const EaGemmParams& p) {
   if (p.K % EA_BK) return false;
-  if (p.N < 64 || p.M < 32) return false;
+  // (GEGLU weights packed for the register-direct epilogue must run here whatever M is: the packing is fixed at load time)
+  if (p.N < 64 || (p.M < 32 && !(p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block == 32))) return false;
   // LDS-DMA goes through 2 GiB buffer descriptors with 32-bit per-lane byte offsets
   const long long lim = 0x7fffffffLL - 4096;
   if ((long long)p.N * p.ldw * 2 > lim) return false;
@@ -85,9 +94,13 @@ static bool fast_eligible(const EaGemmParams& p) {
   } else {
     if ((long long)p.M * p.lda * 2 > lim) return false;
   }
-  if (p.epi.act == EA_ACT_GEGLU) return p.epi.geglu_block == 80 && (p.N % 160) == 0;
+  if (p.epi.act == EA_ACT_GEGLU)
+    return (p.epi.geglu_block == 80 && (p.N % 160) == 0) || (p.epi.geglu_block == 32 && (p.N % 128) == 0);
   return true;
 }
+
+// wave-column blocks (= row-statistics parts) of an N-wide output: 80 columns with 160-wide tiles, else 64
+static int row_stat_parts(int N) { return (N % 160 == 0) ? N / 80 : (N + 63) / 64; }
 
 // Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
 //   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
@@ -145,6 +158,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   Plan2 t;
   t.bn = (N % 160 == 0) ? 160 : 128;
   if (g_force_bn == 128 && !geglu) t.bn = 128;   // tuning sweeps only (EA_GEMM2_BN)
+  if (geglu == 32) t.bn = 128;                    // [16 value | 16 gate] packing: 64-column wave tiles
   const int nk = K / EA_BK;
   double best = 1e30;
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
@@ -189,8 +203,18 @@ static int launch_reduce(EaGemmParams& p, void* stream) {
   return ea_launch_status();
 }
 
+// fallback producer of the output row statistics (launches whose epilogue could not write them)
+static int launch_row_stats(EaGemmParams& p, void* stream) {
+  const EaEpilogue& e = p.epi;
+  if (!e.row_stats_out) return EA_OK;
+  if (e.out_f32 || p.batch != 1) return EA_ERR_UNSUPPORTED;
+  auto kfn = ea_row_stats_kernel;
+  EA_LAUNCH(kfn, dim3((p.M + 3) / 4), dim3(256), 0, stream, (const f16*)e.out, e.ldc, e.row_stats_out, p.M, e.N, row_stat_parts(e.N));
+  return ea_launch_status();
+}
+
 static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
-  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU);
+  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
@@ -223,6 +247,14 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
         !e.residual32 && !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 &&
         (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 && p.debug != 9)
       p.epi_fast = 2;
+    // register-direct GEGLU epilogue: 32-row packing on 128-wide tiles
+    if (e.act == EA_ACT_GEGLU && e.geglu_block == 32) {
+      if (!(t.bn == 128 && t.splits == 1 && (t.kind == 1 || t.kind == 9) && !e.out_f32 && !e.residual && !e.residual32 &&
+            !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 && (((uintptr_t)e.out) & 15) == 0 &&
+            (((uintptr_t)e.bias) & 15) == 0 && (p.strideC & 7) == 0 && span < 0x7fffffffLL && p.batch == 1))
+        return EA_ERR_UNSUPPORTED;
+      p.epi_fast = 3;
+    }
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
@@ -234,8 +266,13 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   } while (0)
 #define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
-  const bool tr = p.epi_fast == 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (((uintptr_t)p.epi.bias) & 15) == 0 &&
-                  (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0));
+  // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
+  const bool tr_raw = t.splits > 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (p.N & 3) == 0 && p.debug != 9;
+  const bool tr = tr_raw || p.epi_fast == 3 ||
+                  (p.epi_fast == 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (((uintptr_t)p.epi.bias) & 15) == 0 &&
+                   (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
+  // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
+  if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
 #define EA_LAUNCH_TR(BM_, BN_)                                                        \
   do {                                                                                \
     auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, 1>;                       \
@@ -246,7 +283,12 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   if (tr) {
     if (t.kind == 1) { if (t.bn == 160) EA_LAUNCH_TR(128, 160); else EA_LAUNCH_TR(128, 128); }
     else { if (t.bn == 160) EA_LAUNCH_TR(64, 160); else EA_LAUNCH_TR(64, 128); }
-    return ea_launch_status();
+    int st_tr = ea_launch_status();
+    if (st_tr == EA_OK && t.splits > 1) {
+      st_tr = launch_reduce(p, stream);
+      if (st_tr == EA_OK) st_tr = launch_row_stats(p, stream);
+    }
+    return st_tr;                  // (unsplit launches: row statistics, if asked for, were written by the epilogue)
   }
 #undef EA_LAUNCH_TR
   switch (t.kind) {
@@ -270,6 +312,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   int st = ea_launch_status();
   if (st != EA_OK) return st;
   if (t.splits > 1) st = launch_reduce(p, stream);
+  if (st == EA_OK) st = launch_row_stats(p, stream);
   return st;
 }
 
@@ -277,6 +320,7 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   read_env();
   if (!g_force_generic && fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
   if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
+  if (p.epi.ln_stats) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
   TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);
   p.splits = t.splits;
@@ -305,10 +349,21 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   int st = ea_launch_status();
   if (st != EA_OK) return st;
   if (t.splits > 1) st = launch_reduce(p, stream);
+  if (st == EA_OK) st = launch_row_stats(p, stream);
   return st;
 }
 
 }  // namespace
+
+extern "C" int ea_row_stats_parts(int N) { return N > 0 ? row_stat_parts(N) : 0; }
+
+// 1 when a LayerNorm-folded launch of this shape runs through the register-direct epilogue (fp16 output, 16-byte
+// aligned operands assumed): the 2-stage LDS-DMA tiles with no split-K.  act: EA_ACT_* (GEGLU = the 32-row packing).
+extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
+  if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+  Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
+  return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
+}
 
 extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return 0;

@@ -452,6 +452,50 @@ void ea_gemm2_kernel(EaGemmParams p) {
   };
 #undef EA_LOADF
 
+  // LayerNorm fold (register-direct epilogue): mean / rstd of this lane's MI output rows from the producer's row
+  // partials.  Runs right AFTER the first tile's DMA is issued (below), every load in flight before the first add, so
+  // the round trip rides under that tile's latency.  (Measured: inside the epilogue the dependent 8-byte loads cost each
+  // workgroup ln_parts x ~0.5 us; in front of the first DMA issue still 3-4 us per workgroup round.)
+  float ln_mu[MI], ln_rs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) { ln_mu[i] = 0.0f; ln_rs[i] = 1.0f; }
+  auto ln_prologue = [&]() {
+    if (!(TR && p.epi.ln_stats)) return;
+    const int c16p = lane & 15;
+    constexpr int CH = 8;                     // parts per chunk: CH * MI 8-byte loads in flight
+    float s1[MI], s2[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { s1[i] = 0.0f; s2[i] = 0.0f; }
+    for (int pp0 = 0; pp0 < p.epi.ln_parts; pp0 += CH) {
+      f32x2 t2[CH][MI];
+      // UNCONDITIONAL loads (indices clamped, the surplus masked arithmetically): a per-load `if` makes hipcc branch
+      // around every load and wait for it on its own (guide section 5, trap (c)) -- 32 dependent round trips, 5 us per
+      // workgroup, measured
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          int m = m0 + wm * WTM + i * 16 + c16p;
+          m = m < p.M ? m : p.M - 1;
+          int pp = pp0 + u;
+          pp = pp < p.epi.ln_parts ? pp : p.epi.ln_parts - 1;
+          t2[u][i] = *reinterpret_cast<const f32x2*>(p.epi.ln_stats + ((long long)pp * p.M + m) * 2);
+        }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const float keep = (pp0 + u < p.epi.ln_parts) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { s1[i] += keep * t2[u][i][0]; s2[i] += keep * t2[u][i][1]; }
+      }
+    }
+    const float inv = 1.0f / (float)p.K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const float mu = s1[i] * inv;
+      ln_mu[i] = mu;
+      ln_rs[i] = 1.0f / sqrtf(fmaxf(s2[i] * inv - mu * mu, 0.0f) + p.epi.ln_eps);
+    }
+  };
   EA_STAMP(1);
   if (STAGES == 2 && LDR) {
     // loader waves + 2-deep ring: the tile after the one being multiplied is in flight during exactly one compute
@@ -469,6 +513,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     }
   } else if (STAGES == 2) {
     if (nk > 0) issue_tile(0);
+    ln_prologue();
 #ifndef EA_EMU
     // Two co-resident workgroups that start together run their DMA-issue and MFMA phases in lockstep (both contend
     // for the texture path, then both for the matrix pipe).  Workgroups b and b + 256 normally share a CU (dispatch
@@ -667,19 +712,116 @@ void ea_gemm2_kernel(EaGemmParams p) {
   }
   if (TR) {
     // ---- register-direct epilogue (p.epi_fast == 1 launches: fp16 out, optional fp16 residual, bias / per-sample row
-    // vector / SiLU / GELU / scalar scale, 16-byte aligned, no split-K; checked on the host).
+    // vector / SiLU / GELU / scalar scale, 16-byte aligned, no split-K; p.epi_fast == 3: GEGLU with 32-row packing;
+    // checked on the host).
     // acc[i][j][r] = C[row i*16 + c16][col j*16 + 4*q4 + r].  Tiles are paired -- (j, j+1) along the columns, and when
     // NI is odd the last column tile along the rows, (i, i+1) -- and each register pair goes through ea_swap16: the
     // even-q4 lanes end up with columns 8*(q4/2) .. +7 of the pair's FIRST tile, the odd-q4 lanes with the same columns
     // of its SECOND tile.  Per wave instruction: 16 rows x 64 contiguous bytes (column pairs).
+    // Optional, both in fp32 on the values about to be rounded to fp16:
+    //  * LayerNorm FOLD (e.ln_stats): the A operand is the UN-normalised activation and W carries gamma, so
+    //    LN(x) W^T + b = rstd_m * (acc - mean_m * colsum_n) + (W beta + b)_n with mean / rstd from the row partials the
+    //    producing launch left behind (attention.py:271-275: norm -> to_q / GEGLU proj) -- no LayerNorm pass at all;
+    //  * ROW STATISTICS out (e.row_stats_out): per output row the (sum, sum of squares) over this wave's WTN columns,
+    //    part = (column of the wave tile) / WTN -- what the next launch's LayerNorm fold consumes.
     static_assert(!TR || (NI % 2 == 0 || MI % 2 == 0), "an odd column-tile count needs an even row-tile count to pair up");
-    constexpr int JP = NI / 2;                    // column-tile pairs per row tile
-    constexpr int IP = (NI & 1) ? MI / 2 : 0;     // row-tile pairs of the odd last column tile
     const int c16 = lane & 15, q4 = lane >> 4;
+    if (p.splits > 1) {
+      // split-K slice: the raw fp32 accumulators go to the [slice][M][N] partials straight from the registers -- a lane's
+      // quad is 4 consecutive columns of one row = one 16-byte store (64 contiguous bytes per row per wave instruction);
+      // ea_splitk_reduce_kernel sums the slices and applies the epilogue.  (The LDS-slab form of this dump cost the
+      // 75 split launches of an evaluation 5-8 us each.)
+      float* part = p.partial + (long long)bz * p.M * p.N;
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii) {
+        const int m = m0 + wm * WTM + ii * 16 + c16;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = n0 + wn * WTN + j * 16 + 4 * q4;
+          if (m < p.M && n < p.N) *reinterpret_cast<f32x4*>(part + (long long)m * p.N + n) = acc[MT == 16 ? ii : 0][MT == 16 ? j : 0];
+        }
+      }
+      EA_STAMP(4);
+      return;
+    }
     const int sel = q4 & 1, coff = 8 * (q4 >> 1);
     const int colbase = n0 + wn * WTN, rowbase = m0 + wm * WTM;
     const long long cb0 = (long long)batch * p.strideC, rb0 = (long long)batch * p.strideR;
     f16* outp = (f16*)e.out + cb0;
+    f32x4 cb[NI], cs[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = colbase + j * 16 + 4 * q4;
+      cb[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      cs[j] = cb[j];
+      if (n < p.N) {
+        if (e.bias) cb[j] = *reinterpret_cast<const f32x4*>(e.bias + n);
+        if (e.ln_stats) cs[j] = *reinterpret_cast<const f32x4*>(e.ln_colsum + n);
+      }
+    }
+    auto ln_fold = [&](f32x4 x, int i, int j) {
+      if (e.ln_stats) x = (x - ln_mu[i] * cs[j]) * ln_rs[i];
+      return x;
+    };
+    // row-statistics accumulators (per row tile of this lane)
+    float st1[MI], st2[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { st1[i] = 0.0f; st2[i] = 0.0f; }
+    auto stats_flush = [&]() {
+      if (!e.row_stats_out) return;
+      const int part = colbase / WTN;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float a1 = st1[i], a2 = st2[i];
+        a1 += ea_shfl_xor(a1, 16); a2 += ea_shfl_xor(a2, 16);
+        a1 += ea_shfl_xor(a1, 32); a2 += ea_shfl_xor(a2, 32);
+        const int m = rowbase + i * 16 + c16;
+        if (q4 == 0 && m < p.M && colbase < e.N)
+          *reinterpret_cast<f32x2*>(e.row_stats_out + ((long long)part * p.M + m) * 2) = f32x2{a1, a2};
+      }
+    };
+    if (p.epi_fast == 3) {
+      // ---- GEGLU, weight rows packed [16 value | 16 gate] per 32: column tile 2t holds the values, 2t+1 the gates of
+      // outputs t*16 .. +15 in the SAME lanes and registers (attention.py:54-56: x, gate = proj(x).chunk(2); x * gelu(gate)).
+      // Output tiles pair up along the columns like above: NI / 2 output tiles, (NI / 4) 16-byte vectors per row tile.
+      // (only launched on the 128-wide tiles, NI = 4; the NI = 5 instantiations compile this branch but never take it)
+      constexpr int OP = NI / 4;                 // output-tile pairs per row tile (NI = 4: one)
+      const int obase = colbase >> 1;
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+        for (int op = 0; op < OP; ++op) {
+          f32x4 o2[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int jv = 4 * op + 2 * h2, jg = jv + 1;
+            const f32x4 v = ln_fold(acc[MT == 16 ? ii : 0][MT == 16 ? (jv < NI ? jv : 0) : 0], ii, jv < NI ? jv : 0) + cb[jv < NI ? jv : 0];
+            f32x4 g = ln_fold(acc[MT == 16 ? ii : 0][MT == 16 ? (jg < NI ? jg : 0) : 0], ii, jg < NI ? jg : 0) + cb[jg < NI ? jg : 0];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = ea_gelu_erf(g[r]);
+            o2[h2] = v * g * e.scale;
+          }
+          f32x4 a = o2[0], b = o2[1];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = a[r], y = b[r];
+            ea_swap16(x, y);
+            a[r] = x;
+            b[r] = y;
+          }
+          const int m = rowbase + ii * 16 + c16, n = obase + (2 * op + sel) * 16 + coff;
+          if (m < p.M && n < e.N) {
+            f16x8 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
+            ea_st8(outp + (long long)m * e.ldc + n, h);
+          }
+        }
+      EA_STAMP(4);
+      return;
+    }
+    constexpr int JP = NI / 2;                    // column-tile pairs per row tile
+    constexpr int IP = (NI & 1) ? MI / 2 : 0;     // row-tile pairs of the odd last column tile
     const f16* resp = e.residual ? e.residual + rb0 : nullptr;
     const float* rvp = e.rowvec ? e.rowvec + (long long)(m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
     // where this lane's 8-column vectors go: column-pair vectors (ii, jp), then the odd tile's row-pair vectors (ip)
@@ -707,18 +849,15 @@ void ea_gemm2_kernel(EaGemmParams p) {
       for (int v = 0; v < MI * JP + IP; ++v)
         if (roff[v] >= 0) rq[v] = ea_ld8(resp + roff[v]);
     }
-    f32x4 cb[NI];
+    if (rvp) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = colbase + j * 16 + 4 * q4;
-      cb[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (n < e.N) {
-        if (e.bias) cb[j] = *reinterpret_cast<const f32x4*>(e.bias + n);
-        if (rvp) cb[j] += *reinterpret_cast<const f32x4*>(rvp + n);
+      for (int j = 0; j < NI; ++j) {
+        const int n = colbase + j * 16 + 4 * q4;
+        if (n < e.N) cb[j] += *reinterpret_cast<const f32x4*>(rvp + n);
       }
     }
-    auto finish = [&](f32x4 x, int j) {
-      x += cb[j];
+    auto finish = [&](f32x4 x, int i, int j) {
+      x = ln_fold(x, i, j) + cb[j];
       if (e.act == EA_ACT_SILU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = ea_silu(x[r]);
@@ -728,7 +867,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
       }
       return x * e.scale;
     };
-    auto emit = [&](f32x4 a, f32x4 b, int v) {     // a, b: finished quads of the pair's first / second tile
+    // a, b: finished quads of the pair's first / second tile; i0 / i1: row tile of the result in even- / odd-q4 lanes
+    auto emit = [&](f32x4 a, f32x4 b, int v, int i0, int i1) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float x = a[r], y = b[r];
@@ -736,28 +876,39 @@ void ea_gemm2_kernel(EaGemmParams p) {
         a[r] = x;
         b[r] = y;
       }
-      if (voff[v] < 0) return;
-      f16x8 h;
-      if (resp) {
+      const bool on = voff[v] >= 0;
+      if (on && resp) {
         const f16x8 rr = rq[v];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = (f16)(a[r] + (float)rr[r]); h[4 + r] = (f16)(b[r] + (float)rr[4 + r]); }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
+        for (int r = 0; r < 4; ++r) { a[r] += (float)rr[r]; b[r] += (float)rr[4 + r]; }
       }
+      if (e.row_stats_out) {
+        float t1 = 0.0f, t2 = 0.0f;
+        if (on) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { t1 += a[r] + b[r]; t2 += a[r] * a[r] + b[r] * b[r]; }
+        }
+        if (i0 == i1) { st1[i0] += t1; st2[i0] += t2; }
+        else { st1[i0] += sel ? 0.0f : t1; st2[i0] += sel ? 0.0f : t2; st1[i1] += sel ? t1 : 0.0f; st2[i1] += sel ? t2 : 0.0f; }
+      }
+      if (!on) return;
+      f16x8 h;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
       ea_st8(outp + voff[v], h);
     };
 #pragma unroll
     for (int ii = 0; ii < MI; ++ii)
 #pragma unroll
       for (int jp = 0; jp < JP; ++jp)
-        emit(finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp : 0], 2 * jp), finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp + 1 : 0], 2 * jp + 1),
-             ii * JP + jp);
+        emit(finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp : 0], ii, 2 * jp), finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp + 1 : 0], ii, 2 * jp + 1),
+             ii * JP + jp, ii, ii);
 #pragma unroll
     for (int ip = 0; ip < IP; ++ip)
-      emit(finish(acc[MT == 16 ? 2 * ip : 0][MT == 16 ? NI - 1 : 0], NI - 1), finish(acc[MT == 16 ? 2 * ip + 1 : 0][MT == 16 ? NI - 1 : 0], NI - 1),
-           MI * JP + ip);
+      emit(finish(acc[MT == 16 ? 2 * ip : 0][MT == 16 ? NI - 1 : 0], 2 * ip, NI - 1),
+           finish(acc[MT == 16 ? (2 * ip + 1 < MI ? 2 * ip + 1 : 0) : 0][MT == 16 ? NI - 1 : 0], 2 * ip + 1 < MI ? 2 * ip + 1 : 0, NI - 1), MI * JP + ip, 2 * ip,
+           2 * ip + 1 < MI ? 2 * ip + 1 : 0);
+    stats_flush();
     EA_STAMP(4);
     return;
   }

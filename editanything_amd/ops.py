@@ -6,6 +6,7 @@ libeditanything_hip.so on `torch.cuda.current_stream()`.  Activations are NHWC f
 There is no eager/CPU fallback: tensors must live on the MI355X.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -108,9 +109,32 @@ def _epilogue(out, n_out, bias=None, act=ACT_NONE, scale=1.0, residual=None, row
     return e
 
 
+def geglu_block(n_gemm, k):
+    """Packing granule of the EA_ACT_GEGLU weight rows (include/editanything_hip.h): 32 -- [16 value | 16 gate], the
+    register-direct epilogue on 128-wide tiles -- whenever the LDS-DMA kernel applies (every SD2.1 / SD1.5 width), else
+    the generic kernel's 64."""
+    return 32 if (n_gemm % 128 == 0 and k % 64 == 0) else 64
+
+
+LN_FOLD = os.environ.get("EA_LN_FOLD", "1") != "0"      # A/B switch (tools/): 0 keeps the LayerNorm launches
+
+
+def ln_fold_ok(M, N, K):
+    """Can a LayerNorm-folded GEMM of this shape run (register-direct epilogue, no split-K)?"""
+    return LN_FOLD and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
+
+
+def row_stats_buffer(M, N, device):
+    """[parts][M][2] fp32 row partials a GEMM with N outputs writes (`row_stats=`) for the next launch's fold."""
+    return torch.empty((_lib().ea_row_stats_parts(int(N)), M, 2), dtype=torch.float32, device=device)
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
-         rows_per_group=1, row_scale=None, bias_per_row=False):
-    """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor."""
+         rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
+    """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor.
+    row_stats: a `row_stats_buffer` to fill with the output rows' (sum, sum of squares) partials.
+    ln_fold = (stats, colsum, eps): LayerNorm over a's rows folded into the contraction -- `w` carries gamma, `bias`
+    carries W beta + b, `stats` are the partials the launch that produced `a` wrote."""
     _check_dev(a, w)
     K = a.shape[-1]
     M = a.numel() // K
@@ -121,7 +145,12 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
     ws = workspace(a.device)
     e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
     if act == ACT_GEGLU:
-        e.geglu_block = 80 if (N % 160 == 0 and K % 64 == 0) else 64       # must match unet.pack_geglu
+        e.geglu_block = geglu_block(N, K)       # must match unet.pack_geglu
+    if row_stats is not None:
+        e.row_stats_out = _p(row_stats)
+    if ln_fold is not None:
+        stats, colsum, eps = ln_fold
+        e.ln_stats, e.ln_parts, e.ln_colsum, e.ln_eps = _p(stats), stats.shape[0], _p(colsum), float(eps)
     ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
     _prof_end(ev, 2.0 * M * N * K, f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}")
@@ -270,7 +299,7 @@ def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None,
     ws = workspace(x.device)
     e = _epilogue(out, n_out, bias, act, 1.0, residual)
     if act == ACT_GEGLU:
-        e.geglu_block = 80 if (N % 160 == 0 and K % 64 == 0) else 64
+        e.geglu_block = geglu_block(N, K)
     st = _lib().ea_ln_gemm_f16(_p(x), int(x.dtype == torch.float32), _p(gamma), _p(beta), eps, _p(ln_out), _p(w),
                                w.stride(0), M, N, K, C.byref(e), _p(ws), ws.numel(), _stream())
     L.check(st, "ea_ln_gemm_f16")

@@ -44,20 +44,24 @@ def pack_conv(w, device):
     return _f16(w.reshape(cout, k * k * cin8), device)
 
 
-def geglu_block(n_gemm, k):
-    """Packing granule of the EA_ACT_GEGLU weight rows: 80 (one wave's columns of the 160-wide-tile LDS-DMA kernel)
-    when that kernel applies (every SD2.1/SD1.5 width), else the generic kernel's 64."""
-    return 80 if (n_gemm % 160 == 0 and k % 64 == 0) else 64
-
-
 def pack_geglu(w, b):
     """ff.net.0.proj [8C, C]: rows [0,4C) are values, [4C,8C) gates -> interleave as [G/2 value | G/2 gate] per G
-    rows so the GEMM epilogue finds value and gate of one output in the same workgroup tile (EA_ACT_GEGLU)."""
+    rows (G = ops.geglu_block) so the GEMM epilogue finds value and gate of one output in the same lane (EA_ACT_GEGLU)."""
     half = w.shape[0] // 2
-    g2 = geglu_block(w.shape[0], w.shape[1]) // 2
+    g2 = ops.geglu_block(w.shape[0], w.shape[1]) // 2
     wv, wg = w[:half].reshape(half // g2, g2, -1), w[half:].reshape(half // g2, g2, -1)
     bv, bg = b[:half].reshape(half // g2, g2), b[half:].reshape(half // g2, g2)
     return torch.cat([wv, wg], 1).reshape(2 * half, -1), torch.cat([bv, bg], 1).reshape(2 * half)
+
+
+def fold_layernorm(w, b, gamma, beta, device):
+    """LayerNorm -> Linear folded for `ops.gemm(ln_fold=...)`: (fp16 W * gamma, fp32 row sums of THAT fp16 weight -- the
+    epilogue subtracts mean * colsum from an accumulator built with the rounded weight --, fp32 W beta + b)."""
+    w32, g32, b32 = w.float(), gamma.float(), beta.float()
+    wf = (w32 * g32[None, :]).to(torch.float16)
+    colsum = wf.float().sum(1)
+    bias = w32 @ b32 + (b.float() if b is not None else 0.0)
+    return wf.to(device).contiguous(), colsum.to(device).contiguous(), bias.to(device).contiguous()
 
 
 class _Res:
@@ -96,8 +100,10 @@ class _Attn:
         self.pin_w = _f16(sd[p + "proj_in.weight"].reshape(inner, ch), device)
         self.pin_b = _f32(sd[p + "proj_in.bias"], device)
         t = p + "transformer_blocks.0."
-        self.ln = [(_f32(sd[t + f"norm{i}.weight"], device), _f32(sd[t + f"norm{i}.bias"], device)) for i in (1, 2, 3)]
-        self.wqkv = _f16(torch.cat([sd[t + "attn1.to_q.weight"], sd[t + "attn1.to_k.weight"], sd[t + "attn1.to_v.weight"]], 0), device)
+        ln = [(sd[t + f"norm{i}.weight"], sd[t + f"norm{i}.bias"]) for i in (1, 2, 3)]
+        self.ln = [(_f32(g, device), _f32(b, device)) for g, b in ln]
+        wqkv = torch.cat([sd[t + "attn1.to_q.weight"], sd[t + "attn1.to_k.weight"], sd[t + "attn1.to_v.weight"]], 0)
+        self.wqkv = _f16(wqkv, device)
         self.wo1, self.bo1 = _f16(sd[t + "attn1.to_out.0.weight"], device), _f32(sd[t + "attn1.to_out.0.bias"], device)
         self.wq2 = _f16(sd[t + "attn2.to_q.weight"], device)
         self.wkv2 = _f16(torch.cat([sd[t + "attn2.to_k.weight"], sd[t + "attn2.to_v.weight"]], 0), device)
@@ -107,6 +113,11 @@ class _Attn:
         self.wff2, self.bff2 = _f16(sd[t + "ff.net.2.weight"], device), _f32(sd[t + "ff.net.2.bias"], device)
         self.pout_w = _f16(sd[p + "proj_out.weight"].reshape(ch, inner), device)
         self.pout_b = _f32(sd[p + "proj_out.bias"], device)
+        # LayerNorm folded into the three projections that follow a norm (attention.py:271-275): used wherever the
+        # launch qualifies (ops.ln_fold_ok: the large-M levels); the plain weights above serve the other levels
+        self.fold = [fold_layernorm(wqkv, None, ln[0][0], ln[0][1], device),
+                     fold_layernorm(sd[t + "attn2.to_q.weight"], None, ln[1][0], ln[1][1], device),
+                     fold_layernorm(gw, gb, ln[2][0], ln[2][1], device)]
 
     def project_context(self, ctx16):
         """Text K/V are step-invariant: [B, L, ctx] -> [B, L, 2*inner] once per call."""
@@ -115,16 +126,28 @@ class _Attn:
     def forward(self, x, kv):
         B, H, W, Cc = x.shape
         inner = self.inner
+        M = B * H * W
         xt = x.view(B, H * W, Cc)
         xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False)
-        h = ops.gemm(xn, self.pin_w, self.pin_b)
-        qkv = ops.ln_gemm(h, self.ln[0][0], self.ln[0][1], self.wqkv)
+        # a norm -> Linear pair runs as ONE launch when it can: the producer of h leaves the row partials behind
+        # (row_stats), the consumer's epilogue applies the LayerNorm algebraically (ops.gemm ln_fold)
+        fold = [ops.PROFILE is None and ops.ln_fold_ok(M, wf.shape[0], inner) for wf, _, _ in self.fold]
+        st = [ops.row_stats_buffer(M, inner, x.device) if f else None for f in fold]
+
+        def normed(h, i, w, b=None, act=ops.ACT_NONE):
+            if fold[i]:
+                wf, colsum, bias = self.fold[i]
+                return ops.gemm(h, wf, bias, act=act, ln_fold=(st[i], colsum, 1e-5))
+            return ops.ln_gemm(h, self.ln[i][0], self.ln[i][1], w, b, act=act)
+
+        h = ops.gemm(xn, self.pin_w, self.pin_b, row_stats=st[0])
+        qkv = normed(h, 0, self.wqkv)
         a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
-        h = ops.gemm(a, self.wo1, self.bo1, residual=h)
-        q = ops.ln_gemm(h, self.ln[1][0], self.ln[1][1], self.wq2)
+        h = ops.gemm(a, self.wo1, self.bo1, residual=h, row_stats=st[1])
+        q = normed(h, 1, self.wq2)
         a = ops.attention(q, kv[..., :inner], kv[..., inner:], self.heads, self.d)
-        h = ops.gemm(a, self.wo2, self.bo2, residual=h)
-        f = ops.ln_gemm(h, self.ln[2][0], self.ln[2][1], self.wff1, self.bff1, act=ops.ACT_GEGLU)
+        h = ops.gemm(a, self.wo2, self.bo2, residual=h, row_stats=st[2])
+        f = normed(h, 2, self.wff1, self.bff1, act=ops.ACT_GEGLU)
         h = ops.gemm(f, self.wff2, self.bff2, residual=h)
         return ops.gemm(h, self.pout_w, self.pout_b, residual=xt).view(B, H, W, Cc)
 

@@ -72,7 +72,20 @@ typedef struct ea_epilogue {
   void* out;              /* fp16 (out_f32=0) or fp32 [M][ldc] */
   int32_t ldc;
   int32_t out_f32;
-  int32_t geglu_block;    /* EA_ACT_GEGLU packing granule G: 64 (0 means 64) or 80 (needs N % 160 == 0, K % 64 == 0) */
+  int32_t geglu_block;    /* EA_ACT_GEGLU packing granule G: 64 (0 means 64), 80 (needs N % 160 == 0, K % 64 == 0) or
+                           * 32 (N % 128 == 0, K % 64 == 0: the register-direct epilogue, plain fp16 output only) */
+  /* LayerNorm folded into the contraction (BasicTransformerBlock norm -> Linear, attention.py:271-275).  A is the
+   * UN-normalised activation, W's rows carry gamma, bias carries W beta + b, and
+   *     out = epilogue(rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n])
+   * with mean / rstd from the row partials `ln_stats` the producing launch wrote (`row_stats_out`).  Only launches
+   * for which ea_gemm_ln_fold_ok() returns 1 accept it (EA_ERR_UNSUPPORTED otherwise).  All NULL / 0 = off. */
+  const float* ln_stats;  /* [ln_parts][M][2]: partial (sum, sum of squares) over the K columns of A's row m */
+  int32_t ln_parts;
+  const float* ln_colsum; /* [N]: sum over k of the gamma-folded fp16 weight row n */
+  float ln_eps;
+  /* Row statistics of THIS launch's fp16 output, for the next launch's fold: [ea_row_stats_parts(N)][M][2].  Written by
+   * the epilogue where it can, by one extra small launch otherwise (split-K, generic kernel).  NULL = off. */
+  float* row_stats_out;
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and
@@ -95,6 +108,11 @@ int ea_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);
 
 /* Bytes of fp32 workspace ea_gemm_f16 / ea_conv2d_f16 need for this problem (split-K). */
 size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch);
+
+/* LayerNorm fold support (see ea_epilogue): parts a producer with N output columns writes; whether a consumer launch
+ * of this shape can apply the fold. */
+int ea_row_stats_parts(int N);
+int ea_gemm_ln_fold_ok(int M, int N, int K);
 
 /* C[b] = epilogue(A[b] (MxK, lda) * W[b]^T (NxK, ldw)), b < batch. */
 int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,

@@ -77,7 +77,8 @@ def _is_f32(a):
 
 
 def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual32=None, ldr=None, rowvec=None,
-             rows_per_group=1, row_scale=None, bias_per_row=0, geglu_block=0):
+             rows_per_group=1, row_scale=None, bias_per_row=0, geglu_block=0, ln_stats=None, ln_parts=0, ln_colsum=None,
+             ln_eps=1e-5, row_stats_out=None):
     e = L.Epilogue()
     e.bias = ptr(bias)
     e.bias_per_row = bias_per_row
@@ -95,6 +96,11 @@ def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual
     e.ldc = n if ldc is None else ldc
     e.out_f32 = int(_is_f32(out))
     e.geglu_block = geglu_block
+    e.ln_stats = ptr(ln_stats)
+    e.ln_parts = ln_parts
+    e.ln_colsum = ptr(ln_colsum)
+    e.ln_eps = ln_eps
+    e.row_stats_out = ptr(row_stats_out)
     return e
 
 

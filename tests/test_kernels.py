@@ -816,3 +816,118 @@ def test_register_direct_epilogue_conv(kb, B, H, W, cin, cout, act, res, monkeyp
     if res:
         ref = ref + t(R)
     assert relerr(outs[0], ref.numpy()) < 3e-3
+
+
+def _row_stats_ref(y, parts, width):
+    """[parts][M][2] partial (sum, sum of squares) over column blocks of `width`."""
+    M, N = y.shape
+    out = np.zeros((parts, M, 2), np.float64)
+    for pblk in range(parts):
+        blk = y[:, pblk * width:(pblk + 1) * width].astype(np.float64)
+        out[pblk, :, 0], out[pblk, :, 1] = blk.sum(1), (blk * blk).sum(1)
+    return out
+
+
+@pytest.mark.parametrize("M,N,K,res,variant", [
+    (256, 320, 128, True, ""),        # 64-row tiles, 80-column wave blocks -> 4 parts
+    (200, 320, 64, False, "1"),       # 128-row tiles, ragged M
+    (130, 192, 128, True, "1"),       # 128-wide column tiles: 64-column wave blocks -> 3 parts, last tile half empty
+    (128, 160, 2048, True, ""),       # split-K: the epilogue cannot write them -> the fallback launch (all in part 0)
+])
+def test_row_statistics_output(kb, M, N, K, res, variant, monkeypatch):
+    """`row_stats_out`: per output row the partial (sum, sum of squares) of the finished values, one part per wave-column
+    block, written by the register-direct epilogue (or the fallback kernel); summed over the parts they are the
+    LayerNorm statistics of the row."""
+    if variant:
+        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    parts = kb.lib.ea_row_stats_parts(N)
+    assert parts == (N // 80 if N % 160 == 0 else (N + 63) // 64)
+    stats = kb.zeros((parts, M, 2), np.float32)
+    out = kb.zeros((M, N), np.float16)
+    e = epilogue(out, bias=bias, residual=R, row_stats_out=stats)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    y = kb.down(out).astype(np.float32)
+    got = kb.down(stats).astype(np.float64)
+    tot = _row_stats_ref(y, 1, N)[0]
+    # totals: fp32 sums of the un-rounded values vs the rounded output -> relative 2^-11 of the row's magnitude
+    assert np.abs(got.sum(0)[:, 0] - tot[:, 0]).max() <= 2e-3 * np.abs(y).sum(1).max()
+    assert np.abs(got.sum(0)[:, 1] - tot[:, 1]).max() <= 2e-3 * tot[:, 1].max()
+    if K < 2048:    # written by the epilogue: every part is its own column block
+        ref = _row_stats_ref(y, parts, 80 if N % 160 == 0 else 64)
+        assert np.abs(got[..., 1] - ref[..., 1]).max() <= 2e-3 * ref[..., 1].max()
+
+
+@pytest.mark.parametrize("M,N,K,act,gb,variant", [
+    (256, 960, 320, 0, 0, ""),        # LN1 -> fused q/k/v projection (no bias), level-0 width
+    (200, 320, 320, 0, 0, "1"),       # LN2 -> to_q, 128-row tiles, ragged M
+    (128, 1280, 320, 3, 32, ""),      # LN3 -> GEGLU projection, 32-row packing (register-direct GEGLU epilogue)
+    (256, 512, 128, 3, 32, "1"),      # GEGLU, 128-row tiles, K = 128
+    (192, 256, 64, 2, 0, ""),         # GELU after the fold, 128-wide tiles
+])
+def test_layernorm_fold(kb, M, N, K, act, gb, variant, monkeypatch):
+    """LayerNorm folded into the contraction: A = the un-normalised rows, W = gamma-folded weight, bias = W beta + b,
+    row partials from a producing launch's `row_stats_out` -> == Linear(LayerNorm(x)) (attention.py:271-275, 54-56)."""
+    if variant:
+        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+    assert kb.lib.ea_gemm_ln_fold_ok(M, N, K) == 1
+    # producer: x = A0 W0^T + residual, K columns, with row statistics
+    A0, W0, R0 = f16(M, 64), f16(K, 64, scale=0.3), f16(M, K, scale=2.0) + np.float16(0.5)
+    parts = kb.lib.ea_row_stats_parts(K)
+    stats = kb.zeros((parts, M, 2), np.float32)
+    x = kb.zeros((M, K), np.float16)
+    e0 = epilogue(x, residual=R0, row_stats_out=stats)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A0), 64, ptr(W0), 64, M, K, 64, 1, 0, 0, 0, 0, C.byref(e0), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    xh = kb.down(x).copy()
+    # consumer
+    gamma, beta = (1.0 + 0.2 * RNG.standard_normal(K)).astype(np.float32), (0.1 * RNG.standard_normal(K)).astype(np.float32)
+    W = (RNG.standard_normal((N, K)) * 0.2).astype(np.float32)
+    b = f32(N)
+    Wf = (W * gamma[None, :]).astype(np.float16)
+    colsum = Wf.astype(np.float32).sum(1)
+    bf = (W @ beta + b).astype(np.float32)
+    No = N // 2 if act == 3 else N
+    out = kb.zeros((M, No), np.float16)
+    e = epilogue(out, bias=bf, act=act, geglu_block=gb, ln_stats=stats, ln_parts=parts, ln_colsum=colsum, ln_eps=1e-5)
+    assert kb.lib.ea_gemm_f16(ptr(x) if not isinstance(x, np.ndarray) else ptr(xh), K, ptr(Wf), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ln = F.layer_norm(t(xh), (K,), t(gamma), t(beta), 1e-5)
+    ref = ln @ t(W).T + t(b)
+    if act == 2:
+        ref = F.gelu(ref)
+    elif act == 3:
+        r = ref.reshape(M, N // 32, 2, 16)
+        ref = (r[:, :, 0] * F.gelu(r[:, :, 1])).reshape(M, No)
+    assert relerr(kb.down(out), ref.numpy()) < 4e-3
+
+
+def test_layernorm_fold_refused_where_it_cannot_run(kb):
+    """Split-K launches have no fold: ea_gemm_ln_fold_ok says so and the launch is refused, never silently wrong."""
+    M, N, K = 64, 160, 2048
+    assert kb.lib.ea_gemm_ln_fold_ok(M, N, K) == 0
+    A, W = f16(M, K), f16(N, K)
+    stats, colsum = kb.zeros((1, M, 2), np.float32), kb.zeros((N,), np.float32)
+    out = kb.zeros((M, N), np.float16)
+    e = epilogue(out, ln_stats=stats, ln_parts=1, ln_colsum=colsum)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == -3
+
+
+@pytest.mark.parametrize("M,N,K,variant", [(200, 256, 128, ""), (128, 640, 64, "1"), (64, 128, 192, "")])
+def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
+    """GEGLU with [16 value | 16 gate] weight-row packing through the register-direct epilogue (128-wide tiles)."""
+    if variant:
+        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    out = kb.zeros((M, N // 2), np.float16)
+    e = epilogue(out, bias=bias, act=3, scale=0.5, geglu_block=32)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ref = t(A) @ t(W).T + t(bias)
+    r = ref.reshape(M, N // 32, 2, 16)
+    ref = (r[:, :, 0] * F.gelu(r[:, :, 1])).reshape(M, N // 2) * 0.5
+    assert relerr(kb.down(out), ref.numpy()) < 3e-3

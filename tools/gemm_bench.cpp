@@ -131,7 +131,7 @@ int main(int argc, char** argv) {
   }
   std::string cases_sel = "all", out_path;
   std::vector<std::string> variants = {"auto"}, debugs = {"0"}, splits_opt = {"0"};
-  int iters = 20, rounds = 3, check = 0;
+  int iters = 20, rounds = 3, check = 0, geglu = 80;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--cases" && i + 1 < argc) cases_sel = argv[++i];
@@ -141,6 +141,7 @@ int main(int argc, char** argv) {
     else if (a == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
     else if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (a == "--check") check = 1;
+    else if (a == "--geglu" && i + 1 < argc) geglu = atoi(argv[++i]);   // EA_ACT_GEGLU weight-row packing: 80 | 32
     else if (a == "--bn" && i + 1 < argc) setenv("EA_GEMM2_BN", argv[++i], 1);
     else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
   }
@@ -192,7 +193,7 @@ int main(int argc, char** argv) {
     auto make_epi = [&](void* o) {
       ea_epilogue e{};
       e.bias = (const float*)bias; e.act = c.act; e.scale = 1.0f; e.rows_per_group = 1;
-      e.residual = res; e.ldr = Nout; e.out = o; e.ldc = Nout; e.geglu_block = c.act == EA_ACT_GEGLU ? 80 : 0;
+      e.residual = res; e.ldr = Nout; e.out = o; e.ldc = Nout; e.geglu_block = c.act == EA_ACT_GEGLU ? geglu : 0;
       return e;
     };
     auto launch = [&](Lib& l, void* o) {
