@@ -273,16 +273,22 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
                    (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
   // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
   if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
-#define EA_LAUNCH_TR(BM_, BN_)                                                        \
+#define EA_LAUNCH_TR(BM_, BN_, TR_)                                                   \
   do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, 1>;                       \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, TR_>;                     \
     const int smem = 2 * (BM_ + BN_) * 128;                                           \
     ea_allow_big_lds(kfn, smem);                                                      \
     EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                           \
   } while (0)
   if (tr) {
-    if (t.kind == 1) { if (t.bn == 160) EA_LAUNCH_TR(128, 160); else EA_LAUNCH_TR(128, 128); }
-    else { if (t.bn == 160) EA_LAUNCH_TR(64, 160); else EA_LAUNCH_TR(64, 128); }
+    const bool lnx = p.epi.ln_stats || (p.epi.row_stats_out && t.splits == 1);   // fold / statistics compiled in
+    if (t.kind == 1) {
+      if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
+      else { if (lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
+    } else {
+      if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(64, 160, 2); else EA_LAUNCH_TR(64, 160, 1); }
+      else { if (lnx) EA_LAUNCH_TR(64, 128, 2); else EA_LAUNCH_TR(64, 128, 1); }
+    }
     int st_tr = ea_launch_status();
     if (st_tr == EA_OK && t.splits > 1) {
       st_tr = launch_reduce(p, stream);

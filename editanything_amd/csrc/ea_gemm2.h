@@ -164,7 +164,8 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // max(issue, compute).  One barrier per K tile, 3-deep ring: at barrier kt the loaders have waited for tile kt
 // (counted vmcnt, tile kt + 1 still in flight), the compute waves have retired their reads of tile kt - 1, whose buffer
 // the loaders refill with tile kt + 2 right after.
-// TR = 1: TRANSPOSED accumulators + register-direct epilogue.  The MFMA operands are swapped (D^T = W A^T), so a lane
+// TR = 1 / 2: TRANSPOSED accumulators + register-direct epilogue (2 = with the LayerNorm fold and the row-statistics
+// output compiled in; the plain launches run the instantiation without them).  The MFMA operands are swapped (D^T = W A^T), so a lane
 // holds 4 CONSECUTIVE output columns of one output row per 16x16 tile (row = lane % 16, columns 4 * (lane / 16) ..+3)
 // instead of 4 consecutive rows of one column: after one v_permlane16_swap per register two tiles give every lane 8
 // consecutive columns, i.e. the finished fp16 row segment goes from registers to memory as a 16-byte store -- no LDS
@@ -460,7 +461,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
   for (int i = 0; i < MI; ++i) { ln_mu[i] = 0.0f; ln_rs[i] = 1.0f; }
   auto ln_prologue = [&]() {
-    if (!(TR && p.epi.ln_stats)) return;
+    if (!(TR == 2 && p.epi.ln_stats)) return;
     const int c16p = lane & 15;
     constexpr int CH = 8;                     // parts per chunk: CH * MI 8-byte loads in flight
     float s1[MI], s2[MI];
@@ -756,11 +757,11 @@ void ea_gemm2_kernel(EaGemmParams p) {
       cs[j] = cb[j];
       if (n < p.N) {
         if (e.bias) cb[j] = *reinterpret_cast<const f32x4*>(e.bias + n);
-        if (e.ln_stats) cs[j] = *reinterpret_cast<const f32x4*>(e.ln_colsum + n);
+        if (TR == 2 && e.ln_stats) cs[j] = *reinterpret_cast<const f32x4*>(e.ln_colsum + n);
       }
     }
     auto ln_fold = [&](f32x4 x, int i, int j) {
-      if (e.ln_stats) x = (x - ln_mu[i] * cs[j]) * ln_rs[i];
+      if (TR == 2 && e.ln_stats) x = (x - ln_mu[i] * cs[j]) * ln_rs[i];
       return x;
     };
     // row-statistics accumulators (per row tile of this lane)
@@ -768,7 +769,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) { st1[i] = 0.0f; st2[i] = 0.0f; }
     auto stats_flush = [&]() {
-      if (!e.row_stats_out) return;
+      if (!(TR == 2 && e.row_stats_out)) return;
       const int part = colbase / WTN;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -882,7 +883,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { a[r] += (float)rr[r]; b[r] += (float)rr[4 + r]; }
       }
-      if (e.row_stats_out) {
+      if (TR == 2 && e.row_stats_out) {
         float t1 = 0.0f, t2 = 0.0f;
         if (on) {
 #pragma unroll
