@@ -33,6 +33,12 @@ class Epilogue(C.Structure):
     ]
 
 
+class Tuning(C.Structure):
+    """Mirror of ``struct ea_tuning`` (tools / tests only)."""
+    _fields_ = [("force_generic", C.c_int32), ("variant", C.c_int32), ("splits", C.c_int32), ("bn", C.c_int32),
+                ("no_register_direct", C.c_int32), ("debug", C.c_int32)]
+
+
 class ConvSrc(C.Structure):
     """Mirror of ``struct ea_conv_src``."""
     _fields_ = [
@@ -47,6 +53,7 @@ class ConvSrc(C.Structure):
 SIGNATURES = {
     "ea_version": (_i, []),
     "ea_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
+    "ea_set_tuning": (_i, [C.POINTER(Tuning)]),
     "ea_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_row_stats_parts": (_i, [_i]),
     "ea_gemm_ln_fold_ok": (_i, [_i, _i, _i]),
@@ -113,3 +120,23 @@ def lib():
         import torch  # noqa: F401
         _lib = bind(LIB_PATH)
     return _lib
+
+
+def set_tuning(library=None, **fields):
+    """Tools / tests: set the calling thread's contraction tuning (`ea_set_tuning`); no fields = reset."""
+    library = library or lib()
+    if not fields:
+        return library.ea_set_tuning(None)
+    t = Tuning()
+    for k, v in fields.items():
+        setattr(t, k, int(v))
+    return library.ea_set_tuning(C.byref(t))
+
+
+def apply_env_tuning(library=None):
+    """Tools only: translate the historical EA_GEMM* environment switches into one explicit ea_set_tuning() call."""
+    import os
+    g = os.environ.get
+    return set_tuning(library, force_generic=int(g("EA_GEMM_FORCE", "") == "generic"), variant=int(g("EA_GEMM2_VARIANT", "0") or 0),
+                      splits=int(g("EA_GEMM2_SPLITS", "0") or 0), bn=int(g("EA_GEMM2_BN", "0") or 0),
+                      no_register_direct=int(g("EA_GEMM2_TR", "1") == "0"), debug=int(g("EA_GEMM2_DEBUG", "0") or 0))

@@ -102,27 +102,25 @@ static bool fast_eligible(const EaGemmParams& p) {
 // wave-column blocks (= row-statistics parts) of an N-wide output: 80 columns with 160-wide tiles, else 64
 static int row_stat_parts(int N) { return (N % 160 == 0) ? N / 80 : (N + 63) / 64; }
 
-// Tuning / A-B knobs for tools/bench_ops.py and the tests (unset in production):
-//   EA_GEMM_FORCE=generic      route everything to ea_gemm.h
-//   EA_GEMM2_VARIANT=k         0 auto; k = 1..8 forces instantiation k of launch_fast:
+// Tuning / A-B knobs (include/editanything_hip.h `ea_tuning`): set explicitly through ea_set_tuning() by tools and tests,
+// per host thread, all zero in production.  Nothing on the launch path reads the environment.
+//   force_generic   route everything to ea_gemm.h
+//   variant         0 auto; k forces instantiation k of launch_fast:
 //        1: 128 x bn, 4 waves 2x2 (wave tile 64x80), 2-stage, 16x16x32     2: same, 3-stage counted vmcnt
 //        3: 256 x bn, 8 waves 4x2 (64x80), 3-stage                        4: 256 x bn, 4 waves 2x2 (128x80), 3-stage
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
-//        13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG (two wave groups alternate MFMA / load phases, ea_gemm2.h)
-static int g_force_generic = 0, g_variant = 0, g_force_splits = 0, g_force_bn = 0, g_no_tr = 0;
-static void read_env() {   // getenv per call: ~100 ns, and lets one process A/B the variants
-  const char* f = getenv("EA_GEMM_FORCE");
-  g_force_generic = (f && !strcmp(f, "generic")) ? 1 : 0;
-  const char* v = getenv("EA_GEMM2_VARIANT");
-  g_variant = (v && *v) ? atoi(v) : 0;
-  const char* sp = getenv("EA_GEMM2_SPLITS");   // tuning sweeps only: force the split-K factor
-  g_force_splits = (sp && *sp) ? atoi(sp) : 0;
-  const char* bn = getenv("EA_GEMM2_BN");         // tuning sweeps only: 128 forces 128-wide column tiles
-  g_force_bn = (bn && *bn) ? atoi(bn) : 0;
-  const char* tr = getenv("EA_GEMM2_TR");         // A/B only: 0 keeps the LDS-slab epilogue where the register-direct one applies
-  g_no_tr = (tr && *tr == '0') ? 1 : 0;
-}
+//        9: 64 x bn, 2-stage   10 / 11 / 12: loader-wave forms   13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG
+//   splits / bn     tuning sweeps: force the split-K factor / 128-wide column tiles
+//   no_register_direct   keep the LDS-slab epilogue where the register-direct one applies (A/B)
+//   debug           K-loop / epilogue ablations (ea_gemm2.h p.debug)
+static thread_local ea_tuning g_tune = {0, 0, 0, 0, 0, 0};
+#define g_force_generic (g_tune.force_generic)
+#define g_variant (g_tune.variant)
+#define g_force_splits (g_tune.splits)
+#define g_force_bn (g_tune.bn)
+#define g_no_tr (g_tune.no_register_direct)
+static void read_env() {}
 
 // Cost model (microseconds) that picks tile height (64 / 128 rows) and split-K factor.  Fitted to the forced
 // (variant, splits) sweep of tools/sweep_splits.py on MI355X (profiles/r01_sweep_splits.json):
@@ -218,10 +216,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
-  {
-    const char* dbg = getenv("EA_GEMM2_DEBUG");
-    p.debug = (dbg && *dbg) ? atoi(dbg) : 0;
-  }
+  p.debug = g_tune.debug;
   if (t.splits > 1) {
     const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
     if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
@@ -360,6 +355,12 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 }
 
 }  // namespace
+
+extern "C" int ea_set_tuning(const ea_tuning* t) {
+  if (t) g_tune = *t;
+  else g_tune = ea_tuning{0, 0, 0, 0, 0, 0};
+  return EA_OK;
+}
 
 extern "C" int ea_row_stats_parts(int N) { return N > 0 ? row_stat_parts(N) : 0; }
 

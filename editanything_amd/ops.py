@@ -45,15 +45,22 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_aux = 0        # workspace tag of the stream ops are currently being issued on (0 = the main stream)
+import threading
+
+_tls = threading.local()     # per host thread: the workspace tag of the stream ops are currently being issued on
+
+
+def _aux_tag():
+    return getattr(_tls, "aux", 0)      # 0 = the main stream
 
 
 def workspace(device):
-    """Persistent fp32 scratch per device (split-K partials, GroupNorm partial sums): one for the main stream and one
-    for a concurrent side stream (`aux_workspace`).  Allocated once, before any HIP-graph capture; ops on one stream
-    use theirs serially."""
+    """Persistent fp32 scratch per (device, host thread, stream tag) -- split-K partials, GroupNorm partial sums: one
+    for the main stream and one per concurrent side stream (`aux_workspace`).  Allocated once, before any HIP-graph
+    capture; ops on one stream use theirs serially.  Keyed by the host thread too, so two threads driving one GPU never
+    share scratch."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, _aux)
+    key = (idx, threading.get_ident(), _aux_tag())
     if key not in _ws:
         _ws[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
     return _ws[key]
@@ -67,12 +74,10 @@ class aux_workspace:
         self.tag = tag
 
     def __enter__(self):
-        global _aux
-        self._prev, _aux = _aux, self.tag
+        self._prev, _tls.aux = _aux_tag(), self.tag
 
     def __exit__(self, *exc):
-        global _aux
-        _aux = self._prev
+        _tls.aux = self._prev
 
 
 def _p(t):

@@ -102,6 +102,19 @@ typedef struct ea_conv_src {
   int32_t Hout, Wout;
 } ea_conv_src;
 
+/* Tuning / A-B knobs of the contraction entry points, for tools and tests only (production leaves them zero).  The
+ * setting belongs to the CALLING HOST THREAD (thread-local) -- no process-global mutable state, nothing is read from the
+ * environment on the launch path.  NULL resets.  Fields: editanything_amd/csrc/ea_gemm.hip. */
+typedef struct ea_tuning {
+  int32_t force_generic;       /* 1: the register-staged generic kernel for everything */
+  int32_t variant;             /* 0 auto, k: force instantiation k of the LDS-DMA kernel */
+  int32_t splits;              /* 0 plan's own, s: force the split-K factor */
+  int32_t bn;                  /* 0 plan's own, 128: force 128-wide column tiles */
+  int32_t no_register_direct;  /* 1: LDS-slab epilogue where the register-direct one would run */
+  int32_t debug;               /* K-loop / epilogue ablation selector */
+} ea_tuning;
+int ea_set_tuning(const ea_tuning* t);
+
 /* library / device info */
 int ea_version(void);
 int ea_device_info(int* cu_count, int* lds_bytes, char* arch, int arch_len);

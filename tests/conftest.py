@@ -35,5 +35,6 @@ def kb(request):
         be = emu_util.GpuBackend(_lib.lib())
     emu_util.BACKEND = be
     yield be
+    be.lib.ea_set_tuning(None)      # tests that pin an instantiation (test_kernels.tune) never leak it
     be.keep.clear()
     emu_util.BACKEND = None

@@ -20,6 +20,12 @@ import torch.nn.functional as F
 from emu_util import conv_src, epilogue, ptr, relerr
 
 
+def tune(kb, **fields):
+    """Contraction tuning of this thread through the explicit C-ABI setter (reset by the `kb` fixture's teardown)."""
+    from editanything_amd import _lib
+    assert _lib.set_tuning(kb.lib, **fields) == 0
+
+
 def workspace(kb, nbytes):
     return kb.zeros((max(int(nbytes), 16) // 4 + 4,), np.float32)
 
@@ -117,7 +123,7 @@ def test_gemm_fast_path(kb, M, N, K, batch, act, res, f32out, gb):
 def test_gemm_geglu_streamlined_epilogue_variants(kb, variant, monkeypatch):
     """The streamlined GEGLU epilogue (no residual, 80-row packing) in every instantiation that carries it, with a
     scalar scale and ragged M; kinds 5 (32x32x16 MFMA) takes the general path and must agree too."""
-    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    tune(kb, variant=int(variant))
     M, N, K, gb = 150, 480, 128, 80
     A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
     bias = f32(N)
@@ -138,7 +144,7 @@ def test_gemm_geglu_streamlined_epilogue_variants(kb, variant, monkeypatch):
 def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
     """Every instantiation of launch_fast (EA_GEMM2_VARIANT 2..8: 3-stage counted-vmcnt rings, 256-row tiles,
     128x80 and 64x160 wave tiles, 32x32x16 MFMA) against the same reference."""
-    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    tune(kb, variant=int(variant))
     A, W = f16(1, M, K), f16(1, N, K, scale=0.2)
     bias = f32(N)
     No = N // 2 if act == 3 else N
@@ -160,7 +166,7 @@ def test_gemm_fast_path_variants(kb, variant, M, N, K, act, gb, monkeypatch):
 
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_conv_fast_path_variants(kb, variant, monkeypatch):
-    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    tune(kb, variant=int(variant))
     B, H, W_, c1, c2, cout = 2, 12, 12, 64, 64, 160
     x1, x2 = f16(B, H, W_, c1), f16(B, H, W_, c2)
     w, bias = f16(cout, c1 + c2, 3, 3, scale=0.1), f32(cout)
@@ -178,7 +184,7 @@ def test_conv_fast_path_variants(kb, variant, monkeypatch):
 def test_gemm_fast_epilogue_options(kb, variant, monkeypatch):
     """Every epilogue operand of the LDS-DMA kernel's vector path: time-embedding row vector, per-row scale map,
     scalar scale, fp32 residual, fp32 out; then bias-per-row; then a ragged N (N % 8 != 0 -> scalar-capable path)."""
-    monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    tune(kb, variant=int(variant))
     M, N, K, hw = 96, 160, 64, 32
     A, W = f16(M, K), f16(N, K, scale=0.2)
     rowvec, rs, bias, R32 = f32(M // hw, N), f32(M), f32(N), f32(M, N)
@@ -263,17 +269,15 @@ def test_gemm_rowvec_rowscale_bias_per_row(kb):
 def test_gemm_streamlined_epilogue(kb, variant, act, res, monkeypatch):
     """The common-launch epilogue of ea_gemm2 (bias + per-sample row vector + activation applied in the accumulator
     layout, scalar scale, fp16 residual; ragged M edge; the last column tile partly outside N) against the same formula,
-    and against the general epilogue of the same kernel (EA_GEMM2_DEBUG=9 disables the streamlined one)."""
-    if variant:
-        monkeypatch.setenv("EA_GEMM2_VARIANT", str(variant))
+    and against the general epilogue of the same kernel (tuning debug = 9 disables the streamlined one)."""
     M, N, K, hw = 3 * 256 - 40, 200, 128, 256
     A, W = f16(M, K), f16(N, K, scale=0.1)
     bias, rowvec = f32(N), f32(3, N)
     R = f16(M, N) if res else None
     ws = workspace(kb, 0)
     outs = []
-    for dbg in ("0", "9"):
-        monkeypatch.setenv("EA_GEMM2_DEBUG", dbg)
+    for dbg in (0, 9):
+        tune(kb, variant=int(variant), debug=dbg)
         out = kb.zeros((M, N), np.float16)
         e = epilogue(out, bias=bias, act=act, rowvec=rowvec, rows_per_group=hw, scale=0.75, residual=R)
         assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
@@ -766,16 +770,14 @@ def test_groupnorm_sd21_shapes(kb, B, HW, c1, c2):
 def test_register_direct_epilogue(kb, M, N, K, act, res, rowvec, variant, monkeypatch):
     """ea_gemm2.h TR = 1 (transposed accumulators, v_permlane16_swap pairing, 16-byte stores straight from registers)
     == the LDS-slab epilogue it replaces BIT FOR BIT (same products, same fp32 summation and epilogue order), and both
-    == torch.  EA_GEMM2_TR=0 keeps the slab epilogue for the A/B."""
+    == torch.  Tuning `no_register_direct` keeps the slab epilogue for the A/B."""
     A, W = f16(M, K), f16(N, K, scale=0.2)
     bias = f32(N)
     R = f16(M, N) if res else None
     rv = f32(M // 128, N) if rowvec else None
     outs = []
-    if variant:
-        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
-    for tr in ("1", "0"):
-        monkeypatch.setenv("EA_GEMM2_TR", tr)
+    for tr in (1, 0):
+        tune(kb, variant=int(variant or 0), no_register_direct=1 - tr)
         out = kb.zeros((M, N), np.float16)
         e = epilogue(out, bias=bias, act=act, scale=0.75, residual=R, rowvec=rv, rows_per_group=128 if rowvec else 1)
         ws = workspace(kb, 0)
@@ -801,8 +803,8 @@ def test_register_direct_epilogue_conv(kb, B, H, W, cin, cout, act, res, monkeyp
     rv = f32(B, cout)
     R = f16(B * H * W, cout) if res else None
     outs = []
-    for tr in ("1", "0"):
-        monkeypatch.setenv("EA_GEMM2_TR", tr)
+    for tr in (1, 0):
+        tune(kb, no_register_direct=1 - tr)
         src = conv_src(x, None, None, 3, 1, 1, 0, H, W)
         out = kb.zeros((B * H * W, cout), np.float16)
         e = epilogue(out, bias=bias, act=act, residual=R, rowvec=rv, rows_per_group=H * W)
@@ -839,7 +841,7 @@ def test_row_statistics_output(kb, M, N, K, res, variant, monkeypatch):
     block, written by the register-direct epilogue (or the fallback kernel); summed over the parts they are the
     LayerNorm statistics of the row."""
     if variant:
-        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+        tune(kb, variant=int(variant))
     A, W = f16(M, K), f16(N, K, scale=0.2)
     bias = f32(N)
     R = f16(M, N) if res else None
@@ -872,7 +874,7 @@ def test_layernorm_fold(kb, M, N, K, act, gb, variant, monkeypatch):
     """LayerNorm folded into the contraction: A = the un-normalised rows, W = gamma-folded weight, bias = W beta + b,
     row partials from a producing launch's `row_stats_out` -> == Linear(LayerNorm(x)) (attention.py:271-275, 54-56)."""
     if variant:
-        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+        tune(kb, variant=int(variant))
     assert kb.lib.ea_gemm_ln_fold_ok(M, N, K) == 1
     # producer: x = A0 W0^T + residual, K columns, with row statistics
     A0, W0, R0 = f16(M, 64), f16(K, 64, scale=0.3), f16(M, K, scale=2.0) + np.float16(0.5)
@@ -920,7 +922,7 @@ def test_layernorm_fold_refused_where_it_cannot_run(kb):
 def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
     """GEGLU with [16 value | 16 gate] weight-row packing through the register-direct epilogue (128-wide tiles)."""
     if variant:
-        monkeypatch.setenv("EA_GEMM2_VARIANT", variant)
+        tune(kb, variant=int(variant))
     A, W = f16(M, K), f16(N, K, scale=0.2)
     bias = f32(N)
     out = kb.zeros((M, N // 2), np.float16)

@@ -6,12 +6,14 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_ops as bo  # noqa: E402
+from editanything_amd import _lib as L  # noqa: E402
 
 if __name__ == "__main__":
     B = 8
     for var in os.environ.get("EA_ABLATE_VARIANTS", "1,3,4,5,6").split(","):
         for dbg in ("0", "1", "2"):
             os.environ["EA_GEMM2_DEBUG"] = dbg
+            L.apply_env_tuning()
             bo.set_variant(var)
             bo.VARIANT = f"v{var}/dbg{dbg}"
             bo.bench_conv(B, 64, 320, 0, 320)
@@ -25,6 +27,7 @@ if __name__ == "__main__":
             bo.bench_gemm(B * 256, 1280, 1280)
             bo.bench_gemm(B * 256, 1280, 5120)
     os.environ.pop("EA_GEMM2_DEBUG", None)
+    L.apply_env_tuning()
     if len(sys.argv) > 1:
         with open(sys.argv[1], "w") as f:
             json.dump(bo.results, f, indent=1)

@@ -5,10 +5,12 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_ops as bo  # noqa: E402
+from editanything_amd import _lib as L  # noqa: E402
 
 bo.timeit.__defaults__ = (20, 3)
 for dbg in (sys.argv[1:] or ["0", "1", "10", "11", "12"]):
     os.environ["EA_GEMM2_DEBUG"] = dbg
+    L.apply_env_tuning()
     bo.set_variant("1")
     bo.VARIANT = "dbg" + dbg
     bo.bench_conv(8, 64, 320, 320, 320)

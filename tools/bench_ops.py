@@ -83,7 +83,7 @@ def bench_gemm(M, N, K, act=0):
     bias = torch.randn(N, device=dev)
     No = N // 2 if act == 3 else N
     out = torch.empty(M, No, device=dev, dtype=torch.half)
-    gb = 80 if (act == 3 and N % 160 == 0 and K % 64 == 0 and os.environ.get("EA_GEMM_FORCE") != "generic") else 0
+    gb = 32 if (act == 3 and N % 128 == 0 and K % 64 == 0 and os.environ.get("EA_GEMM_FORCE") != "generic") else 0
     e = epi(out, No, bias, act, geglu_block=gb)
     fn = lambda: lib.ea_gemm_f16(A.data_ptr(), K, W.data_ptr(), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), WS.data_ptr(),
                                  WS.numel(), S())
@@ -171,6 +171,7 @@ def set_variant(v):
         os.environ["EA_GEMM_FORCE"] = "generic"
     elif v not in ("auto", ""):
         os.environ["EA_GEMM2_VARIANT"] = v
+    L.apply_env_tuning()
 
 
 def gemm_suite():

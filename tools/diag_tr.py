@@ -12,6 +12,7 @@ outs = {}
 for tr in ("1", "0"):
     os.environ["EA_GEMM2_TR"] = tr
     os.environ["EA_GEMM2_VARIANT"] = "1"
+    _lib.apply_env_tuning()
     out = be.zeros((M, N), np.float16)
     e = epilogue(out)
     ws = be.zeros((64,), np.float32)

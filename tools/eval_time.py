@@ -11,6 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from editanything_amd import arch, synth  # noqa: E402
 from editanything_amd.unet import ControlledDenoiser, ControlledUnetModel, ControlNet  # noqa: E402
 
+from editanything_amd import _lib  # noqa: E402
+_lib.apply_env_tuning()      # EA_GEMM2_* A/B switches -> one explicit ea_set_tuning() call
 dev = "cuda"
 t0 = time.time()
 un = ControlledUnetModel(arch.SD21_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_UNET), 12), dev)

@@ -36,12 +36,31 @@
 typedef int (*gemm_fn)(const void*, int, const void*, int, int, int, int, int, long long, long long, long long, long long,
                        const ea_epilogue*, void*, size_t, void*);
 typedef int (*conv_fn)(const ea_conv_src*, const void*, int, const ea_epilogue*, void*, size_t, void*);
+typedef int (*tune_fn)(const ea_tuning*);
 
 struct Lib {
   std::string path;
   gemm_fn gemm;
   conv_fn conv;
+  tune_fn tune;   // ea_set_tuning (libraries built before it existed read the EA_GEMM* environment instead: both are set)
 };
+// one configuration = (variant, debug knob, split factor) + the process-wide A/B switches of this run
+static int g_no_tr = 0, g_bn = 0;
+static void apply_tuning(std::vector<Lib>& libs, const std::string& variant, const std::string& debug, const std::string& splits, bool generic = false) {
+  if (generic) setenv("EA_GEMM_FORCE", "generic", 1); else unsetenv("EA_GEMM_FORCE");
+  if (variant == "auto" || variant.empty()) unsetenv("EA_GEMM2_VARIANT"); else setenv("EA_GEMM2_VARIANT", variant.c_str(), 1);
+  if (debug == "0" || debug.empty()) unsetenv("EA_GEMM2_DEBUG"); else setenv("EA_GEMM2_DEBUG", debug.c_str(), 1);
+  if (splits == "0" || splits.empty()) unsetenv("EA_GEMM2_SPLITS"); else setenv("EA_GEMM2_SPLITS", splits.c_str(), 1);
+  ea_tuning t{};
+  t.force_generic = generic ? 1 : 0;
+  t.variant = (variant == "auto" || variant.empty()) ? 0 : atoi(variant.c_str());
+  t.debug = atoi(debug.c_str());
+  t.splits = atoi(splits.c_str());
+  t.bn = g_bn;
+  t.no_register_direct = g_no_tr;
+  for (auto& l : libs)
+    if (l.tune) l.tune(&t);
+}
 
 struct Case {
   std::string name;
@@ -142,14 +161,15 @@ int main(int argc, char** argv) {
     else if (a == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (a == "--check") check = 1;
     else if (a == "--geglu" && i + 1 < argc) geglu = atoi(argv[++i]);   // EA_ACT_GEGLU weight-row packing: 80 | 32
-    else if (a == "--bn" && i + 1 < argc) setenv("EA_GEMM2_BN", argv[++i], 1);
+    else if (a == "--bn" && i + 1 < argc) { g_bn = atoi(argv[++i]); setenv("EA_GEMM2_BN", argv[i], 1); }
+    else if (a == "--slab-epilogue") { g_no_tr = 1; setenv("EA_GEMM2_TR", "0", 1); }   // A/B: no register-direct epilogue
     else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
   }
   std::vector<Lib> libs;
   for (auto& p : split(argv[1], ',')) {
     void* h = dlopen(p.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen %s: %s\n", p.c_str(), dlerror()); return 2; }
-    Lib l{p, (gemm_fn)dlsym(h, "ea_gemm_f16"), (conv_fn)dlsym(h, "ea_conv2d_f16")};
+    Lib l{p, (gemm_fn)dlsym(h, "ea_gemm_f16"), (conv_fn)dlsym(h, "ea_conv2d_f16"), (tune_fn)dlsym(h, "ea_set_tuning")};
     if (!l.gemm || !l.conv) { fprintf(stderr, "%s: missing ea_gemm_f16 / ea_conv2d_f16\n", p.c_str()); return 2; }
     libs.push_back(l);
   }
@@ -203,18 +223,15 @@ int main(int argc, char** argv) {
     };
     std::vector<_Float16> h_ref, h_test;
     if (check) {
-      setenv("EA_GEMM_FORCE", "generic", 1);
-      unsetenv("EA_GEMM2_VARIANT");
-      unsetenv("EA_GEMM2_DEBUG");
+      apply_tuning(libs, "auto", "0", "0", true);
       int st = launch(libs[0], o_ref);
       HIP_CHECK(hipStreamSynchronize(stream));
-      unsetenv("EA_GEMM_FORCE");
       if (st != 0) {   // e.g. GEGLU with 80-row packing exists only in the fast kernel: reference = its GENERAL epilogue
-        setenv("EA_GEMM2_DEBUG", "9", 1);
+        apply_tuning(libs, "auto", "9", "0");
         st = launch(libs[0], o_ref);
         HIP_CHECK(hipStreamSynchronize(stream));
-        unsetenv("EA_GEMM2_DEBUG");
       }
+      apply_tuning(libs, "auto", "0", "0");
       if (st != 0) { fprintf(stderr, "%s: reference launch failed (%d)\n", c.name.c_str(), st); check = 0; }
       h_ref.resize((size_t)M * Nout);
       h_test.resize((size_t)M * Nout);
@@ -231,9 +248,7 @@ int main(int argc, char** argv) {
             cfgs.push_back(Cfg{(int)li, v, d, sp, nullptr, {}, 0.0, 0, 0});
           }
     for (auto& cf : cfgs) {
-      if (cf.variant == "auto") unsetenv("EA_GEMM2_VARIANT"); else setenv("EA_GEMM2_VARIANT", cf.variant.c_str(), 1);
-      if (cf.debug == "0") unsetenv("EA_GEMM2_DEBUG"); else setenv("EA_GEMM2_DEBUG", cf.debug.c_str(), 1);
-      if (cf.splits == "0") unsetenv("EA_GEMM2_SPLITS"); else setenv("EA_GEMM2_SPLITS", cf.splits.c_str(), 1);
+      apply_tuning(libs, cf.variant, cf.debug, cf.splits);
       cf.st = launch(libs[cf.lib], o_test);   // warm-up (module load, LDS attribute)
       HIP_CHECK(hipStreamSynchronize(stream));
       if (cf.st != 0) continue;
@@ -244,9 +259,7 @@ int main(int argc, char** argv) {
       HIP_CHECK(hipGraphInstantiate(&cf.exec, graph, nullptr, nullptr, 0));
       HIP_CHECK(hipGraphDestroy(graph));
     }
-    unsetenv("EA_GEMM2_VARIANT");
-    unsetenv("EA_GEMM2_DEBUG");
-    unsetenv("EA_GEMM2_SPLITS");
+    apply_tuning(libs, "auto", "0", "0");
     for (int r = 0; r < rounds; ++r) {
       for (auto& cf : cfgs) {
         if (!cf.exec) continue;

@@ -8,16 +8,19 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_ops as bo  # noqa: E402
+from editanything_amd import _lib as L  # noqa: E402
 
 
 def run(name, launch, nblocks):
     os.environ["EA_GEMM2_DEBUG"] = "3"
+    L.apply_env_tuning()
     bo.WS.zero_()
     for _ in range(3):
         assert launch() == 0
     torch.cuda.synchronize()
     st = bo.WS[:nblocks * 64].view(torch.int64).view(nblocks, 8).cpu().double()
     os.environ.pop("EA_GEMM2_DEBUG")
+    L.apply_env_tuning()
     t0 = st[:, 0].min()
     rel = (st[:, :5] - t0) / 100.0          # us since the first workgroup started
     d = (st[:, 1:5] - st[:, 0:4]) / 100.0

@@ -6,6 +6,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_ops as bo  # noqa: E402
+from editanything_amd import _lib as L  # noqa: E402
 
 SHAPES = [("conv", (8, 8, 1280, 0, 1280)), ("conv", (8, 16, 1280, 0, 1280)), ("conv", (8, 32, 640, 0, 640)),
           ("conv", (8, 16, 1280, 1280, 1280)), ("conv", (8, 8, 1280, 1280, 1280)), ("conv", (8, 64, 320, 0, 320)),
@@ -18,6 +19,7 @@ if __name__ == "__main__":
     for variant in ("1", "9", "3"):
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             os.environ["EA_GEMM2_SPLITS"] = str(sp)
+            L.apply_env_tuning()
             for kind, a in SHAPES:
                 K = 9 * (a[2] + a[3]) if kind == "conv" else a[2]
                 if sp > 1 and (K // 64) // sp < 2:
