@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--sam", default="vit_h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
+                         "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -63,11 +66,71 @@ def synthetic_inputs(batch, seed, device):
                 mask=torch.from_numpy(mask).to(device), embeds=embeds.to(device), neg=neg.to(device))
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run on 127.0.0.1) instead of silently measuring one GPU.  Fails loudly when fewer than N GPUs
+    are visible."""
+    import socket
+    import subprocess
+    n_vis = torch.cuda.device_count()
+    if n_vis < args.gpus and not args.dry_run:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_vis} GPU(s) visible on this node")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args):
+    """The N-rank control flow of main() with the GPU work replaced by a sleep: exercised by tests/test_dist.py under
+    gloo (world size 2), because multi-GPU nodes are the driver's, not ours, to launch."""
+    from editanything_amd import dist as eadist, synth
+    rank, world, _ = eadist.init_from_env(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
+    shapes = {"w%d" % i: (64, 16 + i) for i in range(5)}
+    sd = synth.synth_state_dict_torch(shapes, args.seed) if rank == 0 else {k: torch.empty(v) for k, v in shapes.items()}
+    sd = eadist.broadcast_state_dict(sd, 0)
+    checksum = float(sum(v.double().sum() for v in sd.values()))
+    units = eadist.shard_indices(args.batch * world, rank, world)          # weak scaling: `batch` images per rank
+
+    def one_step():
+        time.sleep(0.01 * (rank + 1))                                      # ranks finish at different times
+
+    for _ in range(args.warmup):
+        one_step()
+    eadist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    eadist.barrier()
+    elapsed = eadist.max_over_ranks(time.perf_counter() - t0)
+    sums = eadist.gather_host_objects((rank, checksum, units))
+    if rank == 0:
+        assert all(abs(c - checksum) < 1e-9 for _, c, _ in sums), "weights differ across ranks after the broadcast"
+        print(json.dumps({"metric": "512^2 images/s end-to-end (SAM encode + 20-step ControlNet-SD inpaint)",
+                          "value": round(args.batch * args.steps * world / elapsed, 3), "unit": "images/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "dry-run (no GPU work)",
+                          "config": {"workload": "control-flow dry run", "global_batch": args.batch * world,
+                                     "units_per_rank": [u for _, _, u in sums]}}), flush=True)
+    eadist.barrier()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
+    if args.dry_run:
+        return dry_run(args)
     from editanything_amd import arch, dist as eadist, models, ops, synth
     rank, world, local = eadist.init_from_env()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ops.workspace(dev)
@@ -144,7 +207,10 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"SAM {args.sam} encode + SD2.1 ControlNet inpaint, bs={args.batch}/GPU, 512^2, "
-                               f"{args.ddim_steps} DDIM steps, CFG 7.5 (network batch {2 * args.batch}), fp16, random-init weights",
+                               f"{args.ddim_steps} DDIM steps, CFG 7.5 (network batch {2 * args.batch}), fp16, random-init weights; "
+                               "inputs resident in HBM, control = synthetic SAM id map (SURVEY 8d: the mask decoder / AMG is not "
+                               "part of the metric, the SAM embedding is computed and dropped), decoded images stay on the "
+                               "device (no D2H copy / PIL conversion in the timed region)",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
@@ -198,54 +264,90 @@ def roofline_leg(one_step, pipe, args):
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_summary.json:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE ...` runs of tools/pmc_cases.py, per-dispatch averages).
-    Counters cannot be read inside this process, so this is the mean over the PMC population (six dominant launch
-    shapes of one evaluation), NOT over this run's launches: bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB), FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950.  null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    """HBM-side bytes per launch of the dominant kernel, from the PMC passes of THIS round's shipped kernels
+    (profiles/r02_pmc_traffic_tap_major.json: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` in separate
+    passes over tools/gemm_bench, tools/gpu_pmc2.sh; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes on gfx950).  Counters cannot be read inside this process, so the figure is the
+    TIME-WEIGHTED mean over the launch classes of one evaluation (weight = launches per evaluation x microseconds per
+    launch, profiles/r02_epilogue_register_direct.jsonl); the per-class table with the algorithmic bytes is in DESIGN.md
+    section 8c.  null when the files are absent."""
     try:
-        with open(path) as f:
-            ks = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_tap_major.json")) as f:
+            cases = json.load(f)["cases"]
+        with open(os.path.join(ROOT, "profiles", "r01_eval_breakdown_v3.json")) as f:
+            calls = {r["op"]: r["calls"] for r in json.load(f)[0]["rows"]}
+        us = {}
+        with open(os.path.join(ROOT, "profiles", "r02_epilogue_register_direct.jsonl")) as f:
+            for line in f:
+                r = json.loads(line)
+                if r.get("debug") == "0" and "us" in r:
+                    us[r["case"]] = r["us"]
+    except (OSError, ValueError, KeyError, IndexError):
         return None, "no PMC summary under profiles/"
-    vals = [(2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0 for k, v in ks.items()
-            if "ea_gemm2_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v]
-    if not vals:
-        return None, "no ea_gemm2_kernel dispatches in the PMC summary"
-    return round(sum(vals) / len(vals)), ("bytes per launch, mean over the %d ea_gemm2_kernel dispatch classes of the separate "
-                                          "--pmc passes (profiles/r01_pmc_summary.json: 2*FETCH_SIZE + WRITE_SIZE); per class "
-                                          "vs algorithmic bytes: DESIGN.md section 8b" % len(vals))
+    num = den = 0.0
+    n = 0
+    for name, c in cases.items():
+        w = calls.get(name, 0) * us.get(name, 0.0)
+        if w > 0 and "hbm_bytes" in c:
+            num += w * c["hbm_bytes"]
+            den += w
+            n += 1
+    if den == 0:
+        return None, "no weighted classes"
+    return round(num / den), ("bytes per launch of ea_gemm2_kernel, time-weighted mean over %d launch classes of one evaluation "
+                             "(separate --pmc passes on the shipped kernels, profiles/r02_pmc_traffic_tap_major.json; "
+                             "2*FETCH_SIZE + WRITE_SIZE, L2 fabric side: every XCD's L2 fetches the weights once, so "
+                             "weight-heavy classes sit at 2-3x the algorithmic bytes by construction; per class: DESIGN.md 8c)" % n)
 
 
 def cpu_baseline(sds, args):
-    """The oracle (CPU restatement pinned to the reference) on this box's host cores, bounded sample:
-    1 ControlNet+UNet evaluation (batch 1) + 1 VAE decode + 1 VAE encode + 1 SAM encoder pass, extrapolated to
-    images/s for the same 20-step CFG workload.  A reported baseline, not the optimisation target."""
+    """The oracle (CPU restatement pinned to the reference) on this box's host cores, bounded sample: ControlNet + UNet
+    evaluations at batch 1 (1 warm-up + 2 timed, best), one VAE decode and one VAE encode (after a small warm-up call),
+    4 of the SAM encoder's 32 blocks (extrapolated), extrapolated to images/s for the same 20-step CFG workload.  The
+    thread count is picked by a one-second probe (a 128-thread pool on this host is slower than 32 threads for these
+    sizes).  `kind` is "port": /root/reference is not on the GPU box; the oracle is the restatement the goldens pin.
+    A reported baseline, not the optimisation target."""
     from editanything_amd import arch, models
     from oracle import ldm_oracle, sam_oracle
-    cores = torch.get_num_threads()
     rng = np.random.default_rng(0)
     f = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32))
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best
     with torch.no_grad():
+        # thread-count probe on one representative conv (64x64, 320 -> 320 channels)
+        xp, wp = f(1, 320, 64, 64), f(320, 320, 3, 3)
+        ncpu = os.cpu_count() or 8
+        cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu})
+        probe = {}
+        for c in cands:
+            torch.set_num_threads(c)
+            probe[c] = timed(lambda: torch.nn.functional.conv2d(xp, wp, padding=1), 1, 3)
+        cores = min(probe, key=probe.get)
+        torch.set_num_threads(cores)
         x, ctx, hint, ts = f(1, 4, 64, 64), f(1, 77, 1024), f(1, 3, 512, 512).abs() * 50, torch.tensor([501])
-        t0 = time.perf_counter()
-        ldm_oracle.apply_model(sds["unet"], arch.SD21_UNET, sds["cn"], arch.SD21_CONTROLNET, x, ts, ctx, hint)
-        t_eval = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        ldm_oracle.vae_decode(sds["vae"], arch.VAE_KL_F8, f(1, 4, 64, 64))
-        t_dec = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        ldm_oracle.vae_encode_moments(sds["vae"], arch.VAE_KL_F8, f(1, 3, 512, 512))
-        t_enc = time.perf_counter() - t0
+        t_eval = timed(lambda: ldm_oracle.apply_model(sds["unet"], arch.SD21_UNET, sds["cn"], arch.SD21_CONTROLNET, x, ts, ctx, hint), 1, 2)
+        ldm_oracle.vae_decode(sds["vae"], arch.VAE_KL_F8, f(1, 4, 8, 8))          # warm the thread pool / allocator
+        t_dec = timed(lambda: ldm_oracle.vae_decode(sds["vae"], arch.VAE_KL_F8, f(1, 4, 64, 64)), 0, 1)
+        t_enc = timed(lambda: ldm_oracle.vae_encode_moments(sds["vae"], arch.VAE_KL_F8, f(1, 3, 512, 512)), 0, 1)
         cfg = models.SAM_CONFIGS[args.sam]
-        t0 = time.perf_counter()
-        sam_oracle.image_encoder(sds["sam"], cfg, f(1, 3, 1024, 1024))
-        t_sam = time.perf_counter() - t0
+        nblk = min(4, cfg["depth"])
+        cfg4 = dict(cfg, depth=nblk, global_attn_indexes=tuple(i for i in (nblk - 1,) if (cfg["depth"] - 1) in cfg["global_attn_indexes"]))
+        t_sam4 = timed(lambda: sam_oracle.image_encoder(sds["sam"], cfg4, f(1, 3, 1024, 1024)), 0, 1)
+        t_sam = t_sam4 * cfg["depth"] / nblk
     per_image = 2 * args.ddim_steps * t_eval + t_dec + t_enc + t_sam
     return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fp32: 1 ControlNet+UNet eval b=1 ({t_eval:.2f}s) + VAE decode ({t_dec:.2f}s) + VAE encode "
-                      f"({t_enc:.2f}s) + SAM {args.sam} encoder ({t_sam:.2f}s); extrapolated to 2x{args.ddim_steps} evals/image"}
+            "sample": f"oracle fp32 on {cores} threads (probe over {cands}): ControlNet+UNet eval b=1, 1 warm-up + best of 2 ({t_eval:.2f}s) "
+                      f"+ VAE decode ({t_dec:.2f}s) + VAE encode ({t_enc:.2f}s) + SAM {args.sam} encoder, {nblk} of {cfg['depth']} blocks "
+                      f"timed ({t_sam4:.2f}s -> {t_sam:.2f}s); extrapolated to 2x{args.ddim_steps} evals/image; "
+                      "'port' = the CPU restatement pinned to the reference (the reference tree is not on the GPU box)"}
 
 
 if __name__ == "__main__":

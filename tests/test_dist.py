@@ -101,3 +101,43 @@ def test_single_process_paths_are_noops():
     assert eadist.gather_host_objects([1, 2]) == [[1, 2]]
     assert eadist.max_over_ranks(3.5) == 3.5
     eadist.barrier()
+
+
+def _bench(*argv, timeout=300):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), capture_output=True, text=True, timeout=timeout, env=env)
+    return p.returncode, p.stdout, p.stderr
+
+
+def test_bench_spawns_its_own_ranks_and_times_the_slowest():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run on
+    127.0.0.1) and prints ONE line from rank 0 whose time is the MAX over the ranks (dry run: rank r sleeps 10 (r + 1) ms
+    per step, so the step time is rank 1's)."""
+    import json
+    rc, out, err = _bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert rc == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 19.0, d                       # the slower rank (20 ms per step) sets the clock
+    assert d["config"]["units_per_rank"] == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    assert abs(d["value"] - 8 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01    # whole-job aggregate
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """No silent 1-GPU measurement under a `--gpus N` label: without N visible GPUs the run fails loudly, and a
+    WORLD_SIZE that disagrees with --gpus is an error too."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        rc, out, err = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert rc != 0 and "GPU(s) visible" in (out + err)
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stdout + p.stderr)
