@@ -279,6 +279,10 @@ PIPE_CASES = {   # name -> (unet key, controlnets, kwargs of the inpaint call)
     "guess": ("unet", ["cn"], dict(guess_mode=True, controlnet_conditioning_scale=0.8)),
     "nipp2": ("unet", ["cn"], dict(num_images_per_prompt=2, alignment_ratio=None)),
 }
+MIX_CASES = {   # StableDiffusionControlNetInpaintMixingPipeline: name -> (controlnets, kwargs)
+    "mix_a05": (["cn"], dict(alpha_weight=0.5, alignment_ratio=0.5)),
+    "mix_a02_smap": (["cn", "cn2"], dict(alpha_weight=0.2, alignment_ratio=0.75, controlnet_conditioning_scale=[1.0, 0.7], smap=True)),
+}
 GEN_CASES = {
     "plain": (["cn"], dict()),
     "guess": (["cn"], dict(guess_mode=True)),
@@ -296,6 +300,18 @@ def pipe_case_kwargs(name, inp):
     kw["controlnet_conditioning_image"] = inp["hint"] if len(cns) == 1 else [inp["hint"], inp["hint2"].expand(2, -1, -1, -1).contiguous()]
     kw.update(extra)
     return ukey, cns, kw
+
+
+def mix_case_kwargs(name, inp):
+    cns, extra = MIX_CASES[name]
+    extra = dict(extra)
+    kw = dict(prompt_embeds=inp["ctx"], negative_prompt_embeds=inp["un_ctx"], image=inp["image"].clone(), mask_image=inp["mask"].clone(),
+              num_inference_steps=4, guidance_scale=7.5, output_type="latent", height=128, width=128)
+    kw["controlnet_conditioning_image"] = inp["hint"] if len(cns) == 1 else [inp["hint"], inp["hint2"].expand(2, -1, -1, -1).contiguous()]
+    if extra.pop("smap", False):
+        kw["controlnet_conditioning_scale_map"] = inp["smap"]
+    kw.update(extra)
+    return cns, kw
 
 
 def gen_case_kwargs(name, inp):
@@ -339,6 +355,15 @@ def gen_pipeline():
                                         generator=torch.Generator("cpu").manual_seed(11), **kw)
     close(torch.from_numpy(mine), torch.from_numpy(img), 1e-4, "inpaint pipeline decoded image")
     out["image_a_none"] = img
+    for name in MIX_CASES:       # blend noise on the GLOBAL generator (torch.randn_like in the reference): generator = the default one
+        cns, kw = mix_case_kwargs(name, inp)
+        pipe = ref_pipeline.inpaint_pipeline([nets[c] for c in cns], nets["unet"], nets["vae"], mixing=True)
+        with torch.no_grad():
+            ref = pipe(generator=torch.manual_seed(13), **kw).images
+        cns, kw = mix_case_kwargs(name, inp)
+        mine = pipeline_oracle.inpaint_call([nets[c] for c in cns], nets["unet"], nets["vae"], generator=torch.manual_seed(13), **kw)
+        close(mine, ref, 1e-4, f"mixing pipeline [{name}]")
+        out["mixing_" + name] = ref.numpy()
     for name in GEN_CASES:
         cns, kw = gen_case_kwargs(name, inp)
         pipe = ref_pipeline.generation_pipeline([nets[c] for c in cns], nets["unet"], nets["vae"])

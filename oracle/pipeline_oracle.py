@@ -184,9 +184,17 @@ def decode_latents(vae, latents):
 def inpaint_call(cns, unet, vae, *, prompt_embeds, negative_prompt_embeds=None, image, mask_image,
                  controlnet_conditioning_image, height, width, num_inference_steps=50, guidance_scale=7.5,
                  num_images_per_prompt=1, eta=0.0, generator=None, latents=None, output_type="latent",
-                 controlnet_conditioning_scale=1.0, alignment_ratio=None, guess_mode=False, callback=None):
-    """StableDiffusionControlNetInpaintPipeline.__call__, …inpaint.py:1288-1703 (no ref_image branch).
+                 controlnet_conditioning_scale=1.0, alignment_ratio=None, guess_mode=False, callback=None,
+                 alpha_weight=None, controlnet_conditioning_scale_map=None):
+    """StableDiffusionControlNetInpaintPipeline.__call__, …inpaint.py:1288-1703 (no ref_image branch); with
+    `alpha_weight` set: StableDiffusionControlNetInpaintMixingPipeline.__call__, …inpaint.py:1707-2088 -- the scale map
+    (:1874-1880), the kept region started from the re-noised original (:1968-1975), after every step but the last the
+    generated region pulled towards the re-noised original by alpha and the kept region re-noised or left alone
+    (:2039-2051), no final fill.  Its blend noise is torch.randn_like on the GLOBAL generator: pass
+    generator=torch.manual_seed(seed) (the default generator, as the reference's callers do) and the draws interleave
+    exactly as in the reference.
     cns: list of (state_dict, cfg); unet / vae: (state_dict, cfg)."""
+    mixing = alpha_weight is not None
     batch_size = prompt_embeds.shape[0]
     do_cfg = guidance_scale > 1.0
     n_img = batch_size * num_images_per_prompt
@@ -194,6 +202,9 @@ def inpaint_call(cns, unet, vae, *, prompt_embeds, negative_prompt_embeds=None, 
     scales = controlnet_conditioning_scale
     if multi and isinstance(scales, float):
         scales = [scales] * len(cns)                                               # :1318-1324
+    if mixing and controlnet_conditioning_scale_map is not None:                     # :1874-1880
+        scales = [sc * controlnet_conditioning_scale_map for sc in scales] if isinstance(scales, list) \
+            else scales * controlnet_conditioning_scale_map
     pe = encode_prompt_embeds(prompt_embeds, negative_prompt_embeds, num_images_per_prompt, do_cfg)
     image = prepare_image(image)                                                    # :1349
     mask_image = prepare_mask_image(mask_image)                                     # :1351
@@ -215,6 +226,8 @@ def inpaint_call(cns, unet, vae, *, prompt_embeds, negative_prompt_embeds=None, 
         init_lat = rep(vae_encode_sample(vae, image, generator, n_img))
         _, _, w, h = mask_image.shape
         keep = 1 - F.interpolate(mask_image, (w // 8, h // 8), mode="nearest")
+        if mixing:                                                                  # :1973-1975
+            latents = keep * sch.add_noise(init_lat, torch.randn(init_lat.shape), sch.timesteps[0]) + (1 - keep) * latents
     ts = sch.timesteps
     for i, t in enumerate(ts):                                                      # :1540-1664
         x2 = torch.cat([latents] * 2) if do_cfg else latents
@@ -228,10 +241,16 @@ def inpaint_call(cns, unet, vae, *, prompt_embeds, negative_prompt_embeds=None, 
         latents = sch.step(eps, t, latents, eta, generator)
         if callback is not None:
             callback(i, t, latents)
+        if mixing:
+            if in_ch == 4 and i < len(ts) - 1:                                      # :2039-2051
+                proper = sch.add_noise(init_lat, torch.randn(init_lat.shape), ts[i + 1])
+                mixed = ((1 - alpha_weight) * latents + alpha_weight * proper) * (1 - keep)
+                latents = (proper if i < len(ts) * alignment_ratio else latents) * keep + mixed
+            continue
         if in_ch == 4 and alignment_ratio is not None and i < len(ts) * alignment_ratio:
             proper = sch.add_noise(init_lat, noise, ts[i + 1])                      # :1650-1656
             latents = proper * keep + latents * (1 - keep)
-    if in_ch == 4 and (alignment_ratio == 1.0 or alignment_ratio is None):          # :1658-1664
+    if not mixing and in_ch == 4 and (alignment_ratio == 1.0 or alignment_ratio is None):   # :1658-1664
         latents = init_lat * keep + latents * (1 - keep)
     if output_type == "latent":
         return latents

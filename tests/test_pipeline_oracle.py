@@ -63,6 +63,15 @@ def test_generation_restatement_vs_reference_golden(nets, inp, gold, name):
     assert relmax(out, gold["generate_" + name]) < 1e-4
 
 
+@pytest.mark.parametrize("name", list(mg.MIX_CASES))
+def test_mixing_restatement_vs_reference_golden(nets, inp, gold, name):
+    """StableDiffusionControlNetInpaintMixingPipeline (…inpaint.py:1707-2088): alpha-weight blend, scale map on every
+    net; blend noise drawn from the global generator in the reference's order."""
+    cns, kw = mg.mix_case_kwargs(name, inp)
+    out = po.inpaint_call([nets[c] for c in cns], nets["unet"], nets["vae"], generator=torch.manual_seed(13), **kw)
+    assert relmax(out, gold["mixing_" + name]) < 1e-4
+
+
 def test_decoded_image_vs_reference_golden(nets, inp, gold):
     ukey, cns, kw = mg.pipe_case_kwargs("a_none", inp)
     kw["output_type"] = "np"

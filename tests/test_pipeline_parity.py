@@ -101,6 +101,20 @@ def test_inpaint_pipeline_decoded_image_vs_reference_golden(mg, gold, tiny):
     assert np.abs(np.asarray(pil[0]).astype(np.int32) - np.round(ref[0] * 255).astype(np.int32)).max() <= 6
 
 
+@pytest.mark.parametrize("name", ["mix_a05", "mix_a02_smap"])
+def test_mixing_pipeline_vs_reference_golden(mg, gold, tiny, name):
+    """StableDiffusionControlNetInpaintMixingPipeline (…inpaint.py:1707-2088; editany_lora.py's tile refinement uses it):
+    the per-step alpha-weight blend with fresh noise from the GLOBAL generator -- `generator=torch.manual_seed(s)` is
+    the default generator, so latents, VAE noise and blend noise interleave as in the reference."""
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintMixingPipeline
+    cns, kw = mg.mix_case_kwargs(name, mg.pipe_inputs())
+    pipe = _pipe(StableDiffusionControlNetInpaintMixingPipeline, tiny, "unet", cns, True)
+    out = pipe(generator=torch.manual_seed(13), **kw).images
+    ref = gold["mixing_" + name]
+    assert tuple(out.shape) == ref.shape
+    assert rel_l2(out, ref) <= 2e-2, f"{name}: rel-L2 {rel_l2(out, ref):.3e}"
+
+
 @pytest.mark.parametrize("name", ["plain", "guess", "smap_two", "smap_one"])
 def test_generation_pipeline_vs_reference_golden(mg, gold, tiny, name):
     from editanything_amd.pipeline import StableDiffusionControlNetPipeline
