@@ -57,10 +57,12 @@ def pack_geglu(w, b):
 def fold_layernorm(w, b, gamma, beta, device):
     """LayerNorm -> Linear folded for `ops.gemm(ln_fold=...)`: (fp16 W * gamma, fp32 row sums of THAT fp16 weight -- the
     epilogue subtracts mean * colsum from an accumulator built with the rounded weight --, fp32 W beta + b)."""
-    w32, g32, b32 = w.float(), gamma.float(), beta.float()
+    w32, g32 = w.float(), gamma.float()
     wf = (w32 * g32[None, :]).to(torch.float16)
-    colsum = wf.float().sum(1)
-    bias = w32 @ b32 + (b.float() if b is not None else 0.0)
+    # float64 reductions: the CPU fp32 matmul / sum may split the work differently from call to call, and a 1e-8 wobble
+    # in these constants is enough to flip fp16 roundings downstream (two pipelines built from the same weights must agree)
+    colsum = wf.double().sum(1).float()
+    bias = ((w.double() * beta.double()[None, :]).sum(1) + (b.double() if b is not None else 0.0)).float()
     return wf.to(device).contiguous(), colsum.to(device).contiguous(), bias.to(device).contiguous()
 
 
