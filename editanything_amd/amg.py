@@ -135,6 +135,13 @@ class SamPromptDecoder:
         emb = torch.where(lab == -1, torch.zeros_like(emb), emb)
         return emb + (lab == -1) * self.not_a_point + (lab == 0) * self.point_emb[0] + (lab == 1) * self.point_emb[1]
 
+    def embed_boxes(self, boxes):
+        """PromptEncoder._embed_boxes: boxes [B, 4] XYXY in the input frame -> sparse embeddings fp32 [B, 2, C] (corner
+        encodings + point_embeddings[2] / [3]; no padding point when a box is given)."""
+        c = (boxes.to(self.device).float() + 0.5).reshape(-1, 2, 2)
+        emb = self._pe(c / float(self.img_size))
+        return emb + torch.cat([self.point_emb[2], self.point_emb[3]], dim=0)[None]
+
     # ------------------------------------------------------------------ mask decoder
     @staticmethod
     def _mlp3(layers, x):
@@ -367,12 +374,86 @@ class SamAutomaticMaskGenerator:
                      crop_box=[0, 0, W, H]) for i in range(len(iou_l))]
 
 
+def remove_small_regions(mask, area_thresh, mode):
+    """segment_anything utils/amg.py remove_small_regions (reference call: sam2groundingdino_edit.py:186-188, "holes",
+    400): connected components with 8-connectivity (scipy.ndimage.label in place of cv2.connectedComponentsWithStats --
+    the same components); "holes" fills background holes smaller than area_thresh, "islands" drops foreground islands
+    smaller than it (the largest one survives if all are small).  -> (bool mask, changed)."""
+    from scipy import ndimage
+    if mode not in ("holes", "islands"):
+        raise AssertionError(mode)
+    holes = mode == "holes"
+    working = (holes ^ np.asarray(mask).astype(bool)).astype(np.uint8)
+    regions, n = ndimage.label(working, structure=np.ones((3, 3), int))
+    sizes = np.bincount(regions.ravel(), minlength=n + 1)[1:]
+    small = [i + 1 for i, sz in enumerate(sizes) if sz < area_thresh]
+    if not small:
+        return np.asarray(mask).astype(bool), False
+    fill = [0] + small
+    if not holes:
+        fill = [i for i in range(n + 1) if i not in fill]
+        if not fill:
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
+class _ResizeLongestSide:
+    """The `sam_predictor.transform` the reference reaches into (sam2groundingdino_edit.py:177)."""
+
+    def __init__(self, target_length):
+        self.target_length = target_length
+
+    def apply_boxes_torch(self, boxes, original_size):
+        h, w = original_size
+        nh, nw = preprocess_shape(h, w, self.target_length)
+        b = boxes.float().reshape(-1, 2, 2).clone()
+        b[..., 0] *= nw / w
+        b[..., 1] *= nh / h
+        return b.reshape(-1, 4)
+
+    def apply_coords_torch(self, coords, original_size):
+        h, w = original_size
+        nh, nw = preprocess_shape(h, w, self.target_length)
+        c = coords.float().clone()
+        c[..., 0] *= nw / w
+        c[..., 1] *= nh / h
+        return c
+
+
 class SamPredictor:
-    """`SamPredictor(sam)` click prompts (editany_lora.py:527-543): set_image + predict(point_coords, point_labels)."""
+    """`SamPredictor(sam)`: click prompts (editany_lora.py:527-543: set_image + predict(point_coords, point_labels)) and
+    box prompts (sam2groundingdino_edit.py:176-183: transform.apply_boxes_torch + predict_torch(boxes=...))."""
 
     def __init__(self, encoder, decoder):
         self._gen = SamAutomaticMaskGenerator(encoder, decoder)
         self.decoder = decoder
+        self.transform = _ResizeLongestSide(decoder.img_size)
+
+    @torch.no_grad()
+    def predict_torch(self, point_coords=None, point_labels=None, boxes=None, mask_input=None, multimask_output=True,
+                      return_logits=False):
+        """Prompts ALREADY in the input frame (`transform.apply_*`), batched: point_coords [B, N, 2] + point_labels
+        [B, N] and / or boxes [B, 4] -> (masks [B, C, H, W] bool or logits, iou [B, C], low-res logits [B, C, h, w])."""
+        if mask_input is not None:
+            raise NotImplementedError("mask prompts (mask_downscaling) are outside the path: no reference caller passes one")
+        st, dec = self._st, self.decoder
+        (H, W), (in_h, in_w) = st["orig"], st["inp"]
+        sparse = None
+        if point_coords is not None:
+            if point_labels is None:
+                raise AssertionError("point_labels must be supplied if point_coords is supplied.")
+            sparse = dec.embed_points(point_coords, point_labels) if boxes is None else \
+                dec.embed_points(point_coords, point_labels)[:, :-1]          # the padding point only without boxes
+        if boxes is not None:
+            be = dec.embed_boxes(boxes)
+            sparse = be if sparse is None else torch.cat([sparse, be], dim=1)
+        if sparse is None:
+            raise ValueError("predict_torch needs point or box prompts")
+        low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, multimask_output)
+        masks = postprocess_masks(low, (in_h, in_w), (H, W), dec.img_size)
+        if not return_logits:
+            masks = masks > 0.0
+        return masks, iou, low
 
     def set_image(self, image_u8_hwc):
         self._st = self._gen.set_image(image_u8_hwc)

@@ -59,6 +59,50 @@ def embed_points(sd, points, labels, input_size=1024):
     return emb
 
 
+def embed_boxes(sd, boxes, input_size=1024):
+    """PromptEncoder._embed_boxes: boxes [B, 4] XYXY in input-frame pixels -> sparse embeddings [B, 2, C] (the two
+    corners, + point_embeddings[2] / [3]).  With boxes and no points the prompt is exactly these two tokens (the
+    padding point is only appended when there are NO boxes: `pad = boxes is None`).  Reference call site:
+    sam2groundingdino_edit.py:176-183 (`predict_torch(point_coords=None, point_labels=None, boxes=...)`)."""
+    gauss = sd["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
+    c = (boxes.float() + 0.5).reshape(-1, 2, 2)
+    emb = pe_encoding(gauss, c / float(input_size))
+    emb[:, 0] = emb[:, 0] + sd["prompt_encoder.point_embeddings.2.weight"][0]
+    emb[:, 1] = emb[:, 1] + sd["prompt_encoder.point_embeddings.3.weight"][0]
+    return emb
+
+
+def apply_boxes(boxes, orig_hw, long_side=1024):
+    """ResizeLongestSide.apply_boxes_torch: XYXY boxes of the original image -> the resized input frame."""
+    h, w = orig_hw
+    nh, nw = preprocess_shape(h, w, long_side)
+    b = boxes.float().reshape(-1, 2, 2).clone()
+    b[..., 0] = b[..., 0] * (nw / w)
+    b[..., 1] = b[..., 1] * (nh / h)
+    return b.reshape(-1, 4)
+
+
+def remove_small_regions(mask, area_thresh, mode):
+    """utils/amg.py remove_small_regions (cv2.connectedComponentsWithStats, 8-connectivity; here scipy.ndimage.label
+    with a 3x3 structure -- the same components): mode "holes" fills holes smaller than area_thresh, "islands" removes
+    islands smaller than it.  Returns (mask, changed).  Reference call: sam2groundingdino_edit.py:186-188."""
+    from scipy import ndimage
+    assert mode in ("holes", "islands")
+    correct_holes = mode == "holes"
+    working = (correct_holes ^ np.asarray(mask).astype(bool)).astype(np.uint8)
+    regions, n = ndimage.label(working, structure=np.ones((3, 3), int))
+    sizes = np.bincount(regions.ravel(), minlength=n + 1)[1:]
+    small = [i + 1 for i, sz in enumerate(sizes) if sz < area_thresh]
+    if len(small) == 0:
+        return np.asarray(mask).astype(bool), False
+    fill = [0] + small
+    if not correct_holes:
+        fill = [i for i in range(n + 1) if i not in fill]
+        if len(fill) == 0:                    # every region is below the threshold: keep the largest
+            fill = [int(np.argmax(sizes)) + 1]
+    return np.isin(regions, fill), True
+
+
 # ------------------------------------------------------------------ two-way transformer (modeling/transformer.py)
 def attention(sd, p, q, k, v, heads):
     q = F.linear(q, sd[p + "q_proj.weight"], sd[p + "q_proj.bias"])

@@ -229,6 +229,40 @@ def gen_sam_decoder():
                         low_res_masks=low_hf[0].numpy(), iou=iou_hf[0].numpy())
 
 
+def gen_sam_boxes():
+    """Box prompts (sam2groundingdino_edit.py:176-183): golden from the independent port's SamPromptEncoder /
+    SamMaskDecoder with `input_boxes`, multimask_output False."""
+    from transformers import SamConfig
+    from transformers.models.sam.modeling_sam import SamMaskDecoder, SamPromptEncoder
+    from oracle import amg_oracle
+    sd = synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), SEED + 5)
+    cfg = SamConfig()
+    pe, md = SamPromptEncoder(cfg).eval(), SamMaskDecoder(cfg.mask_decoder_config).eval()
+    hf = amg_oracle.to_hf_state_dict(sd)
+    pe.load_state_dict({k[len("prompt_encoder."):]: v for k, v in hf.items() if k.startswith("prompt_encoder.")}, strict=False)
+    md.load_state_dict({k[len("mask_decoder."):]: v for k, v in hf.items() if k.startswith("mask_decoder.")}, strict=False)
+    g = 16
+    emb = rnd((1, 256, g, g), 601)
+    rng = np.random.default_rng(602)
+    xy = rng.uniform(0, 700, size=(5, 2)).astype(np.float32)
+    boxes = torch.from_numpy(np.concatenate([xy, xy + rng.uniform(40, 300, size=(5, 2)).astype(np.float32)], 1))
+    with torch.no_grad():
+        sp_hf, _ = pe(None, None, boxes[None], None)                     # [1, 5, 2, C]
+        grid = torch.ones((g, g))
+        y_e, x_e = (grid.cumsum(dim=0) - 0.5) / g, (grid.cumsum(dim=1) - 0.5) / g
+        pe_hf = pe.shared_embedding(torch.stack([x_e, y_e], dim=-1)).permute(2, 0, 1)[None]
+        dense_hf = pe.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(1, -1, g, g)
+        low_hf, iou_hf = md(image_embeddings=emb, image_positional_embeddings=pe_hf, sparse_prompt_embeddings=sp_hf,
+                            dense_prompt_embeddings=dense_hf, multimask_output=False)
+        sparse = amg_oracle.embed_boxes(sd, boxes)
+        close(sparse, sp_hf[0], 1e-6, "SAM prompt encoder (boxes) vs HF port")
+        low, iou = amg_oracle.mask_decoder(sd, emb, amg_oracle.dense_pe(sd, (g, g)), sparse, False)
+        close(low, low_hf[0], 2e-4, "SAM mask decoder (box prompts, single mask) vs HF port")
+        close(iou, iou_hf[0], 2e-4, "SAM iou (box prompts) vs HF port")
+    np.savez_compressed(os.path.join(GOLD, "sam_boxes.npz"), embedding=emb.numpy(), boxes=boxes.numpy(), sparse=sp_hf[0].numpy(),
+                        low_res_masks=low_hf[0].numpy(), iou=iou_hf[0].numpy())
+
+
 def gen_host():
     show_anns = ref_import.extract_function("sam2image.py", "show_anns")
     rng = np.random.default_rng(401)
@@ -380,12 +414,15 @@ def gen_pipeline():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--sam-boxes" in sys.argv:
+        gen_sam_boxes()
+        sys.exit(0)
     if "--pipeline" in sys.argv:        # only the pipeline goldens (the rest is unchanged since round 1)
         ref_import.load()
         gen_pipeline()
         sys.exit(0)
     print("SAM ..."); gen_sam()          # before the import stubs (transformers probes for a real torchvision)
-    print("SAM prompt encoder + mask decoder ..."); gen_sam_decoder()
+    print("SAM prompt encoder + mask decoder ..."); gen_sam_decoder(); gen_sam_boxes()
     ns = ref_import.load()
     print("LDM (ControlNet/UNet/DDIM) ..."); gen_ldm(ns)
     print("VAE ..."); gen_vae(ns)

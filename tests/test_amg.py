@@ -290,3 +290,76 @@ def test_process_outputs_vs_oracle_chain():
         a = np.asarray(out[1 + i]).astype(np.float64) / 255.0
         mse = float(((a - imgs[i]) ** 2).mean())
         assert 10 * np.log10(1.0 / max(mse, 1e-12)) >= 30.0, (i, mse)
+
+
+# ----------------------------------------------------------------------------------------------- box prompts
+def test_oracle_box_prompts_vs_independent_port_golden():
+    """PromptEncoder._embed_boxes + single-mask decoding (sam2groundingdino_edit.py:176-183)."""
+    d = np.load(os.path.join(GOLD, "sam_boxes.npz"))
+    sd = decoder_sd()
+    emb, boxes = torch.from_numpy(d["embedding"]), torch.from_numpy(d["boxes"])
+    with torch.no_grad():
+        sparse = AO.embed_boxes(sd, boxes)
+        low, iou = AO.mask_decoder(sd, emb, AO.dense_pe(sd, emb.shape[-2:]), sparse, False)
+    assert float((sparse - torch.from_numpy(d["sparse"])).abs().max()) < 1e-6
+    assert low.shape[1] == 1 and rel_l2(low, d["low_res_masks"]) < 1e-4
+    assert float((iou - torch.from_numpy(d["iou"])).abs().max()) < 1e-4
+    b = AO.apply_boxes(torch.tensor([[10.0, 20.0, 110.0, 220.0]]), (480, 640))
+    assert torch.allclose(b, torch.tensor([[16.0, 32.0, 176.0, 352.0]]))          # 640 -> 1024: x 1.6 on both axes
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_remove_small_regions_known_answers(impl):
+    """utils/amg.py remove_small_regions (8-connectivity): holes below the threshold are filled, islands below it are
+    dropped, the largest island survives when all are small; (mask, changed)."""
+    if impl == "oracle":
+        rsr = AO.remove_small_regions
+    else:
+        from editanything_amd.amg import remove_small_regions as rsr
+    m = np.zeros((12, 12), bool)
+    m[1:9, 1:9] = True
+    m[3:5, 3:5] = False            # a 4-pixel hole
+    m[6, 6] = False                # a 1-pixel hole, diagonal neighbour of nothing else
+    m[10, 10] = True               # a 1-pixel island touching the block only diagonally?  (9,9) is outside the block: separate
+    out, changed = rsr(m, 3, "holes")
+    assert changed and out[6, 6] and not out[3, 3] and out[10, 10]
+    out, changed = rsr(m, 5, "holes")
+    assert changed and out[3:5, 3:5].all()
+    out, changed = rsr(m, 2, "islands")
+    assert changed and not out[10, 10] and out[1, 1]
+    out, changed = rsr(m, 1, "islands")
+    assert not changed and np.array_equal(out, m)
+    tiny = np.zeros((6, 6), bool)
+    tiny[0, 0] = True
+    tiny[3:5, 3] = True
+    out, changed = rsr(tiny, 10, "islands")
+    assert changed and out.sum() == 2 and out[3, 3]        # everything is small: the largest region is kept
+    diag = np.zeros((4, 4), bool)
+    diag[0, 0] = diag[1, 1] = True                           # 8-connected: ONE region of 2 pixels
+    assert not rsr(diag, 2, "islands")[1]
+
+
+@gpu
+def test_device_box_prompts_vs_golden_and_oracle(device_decoder):
+    from editanything_amd.amg import SamPredictor
+    d = np.load(os.path.join(GOLD, "sam_boxes.npz"))
+    dec = device_decoder
+    emb, boxes = torch.from_numpy(d["embedding"]), torch.from_numpy(d["boxes"])
+    with torch.no_grad():
+        sparse = dec.embed_boxes(boxes)
+        assert float((sparse.cpu() - torch.from_numpy(d["sparse"])).abs().max()) < 1e-4
+        low, iou = dec.predict_masks(dec.image_tokens(emb), tuple(emb.shape[-2:]), sparse, False)
+    assert low.shape[1] == 1 and rel_l2(low, d["low_res_masks"]) < 1e-2
+    ref = torch.from_numpy(d["iou"])
+    assert float((iou.cpu() - ref).abs().max()) < 2e-3 + 1e-2 * float(ref.abs().max())
+    # predictor surface: transform.apply_boxes_torch + predict_torch(boxes=...) as sam2groundingdino_edit.py:176-183
+    pred = SamPredictor(None, dec)
+    pred._st = dict(orig=(480, 640), inp=(768, 1024), tokens=dec.image_tokens(emb), emb_hw=tuple(emb.shape[-2:]))
+    tb = pred.transform.apply_boxes_torch(torch.tensor([[10.0, 20.0, 110.0, 220.0], [100.0, 50.0, 500.0, 400.0]]), (480, 640))
+    assert torch.allclose(tb[0], torch.tensor([16.0, 32.0, 176.0, 352.0]))
+    masks, iou2, low2 = pred.predict_torch(point_coords=None, point_labels=None, boxes=tb.to("cuda"), multimask_output=False)
+    assert tuple(masks.shape) == (2, 1, 480, 640) and masks.dtype == torch.bool and tuple(iou2.shape) == (2, 1)
+    with torch.no_grad():
+        sd = decoder_sd()
+        rl, _ = AO.mask_decoder(sd, emb, AO.dense_pe(sd, emb.shape[-2:]), AO.embed_boxes(sd, tb), False)
+    assert rel_l2(low2, rl) < 1e-2
