@@ -109,6 +109,24 @@ def synthetic_pipeline(name="sd21", seed=0, device="cuda", inpaint=True, use_gra
     return build_pipeline(name, u, c, v, device, inpaint, use_graph)
 
 
+def build_mask_generator(sam_cfg, encoder_sd, decoder_sd, device="cuda", precision="fp16", **amg_overrides):
+    """`SamAutomaticMaskGenerator(sam)` of the reference (sam2image.py:67-71) from upstream-named state dicts.
+    precision "fp16": the serving path (sam.py / amg.py: fp16 operands, fp32 accumulate);
+    precision "fp32": the fp32-accurate mode (sam_exact.py) -- what the reference computes (it never halves SAM), for an
+    id map that matches the fp32 chain pixel for pixel away from threshold ties, at ~1/3 of the encoder throughput."""
+    from .amg import SamAutomaticMaskGenerator, SamPromptDecoder
+    if precision == "fp32":
+        from .sam_exact import ImageEncoderViTExact, SamPromptDecoderExact
+        enc = ImageEncoderViTExact(sam_cfg, encoder_sd, device)
+        dec = SamPromptDecoderExact(decoder_sd, device, img_size=sam_cfg["img_size"])
+    elif precision == "fp16":
+        enc = ImageEncoderViT(sam_cfg, encoder_sd, device)
+        dec = SamPromptDecoder(decoder_sd, device, img_size=sam_cfg["img_size"])
+    else:
+        raise ValueError(f"precision must be 'fp16' or 'fp32', not {precision!r}")
+    return SamAutomaticMaskGenerator(enc, dec, **amg_overrides)
+
+
 def synthetic_sam_encoder(name="vit_h", seed=0, device="cuda"):
     cfg = SAM_CONFIGS[name]
     sd = synth.synth_state_dict_torch(arch.sam_encoder_param_shapes(cfg), seed + 3)
