@@ -1,0 +1,12 @@
+#!/bin/bash
+# Side builds of the attention / norm kernels with compile-time experiment flags (ea_attn.hip EA_ATTN_EXP mask), for
+# tools/op_bench A/B runs.  Usage: bash tools/build_attn_exp.sh 1 2 4 -> gpurun_exp/libea_attn_exp<N>.so
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_exp
+for m in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DEA_ATTN_EXP=$m \
+    -shared editanything_amd/csrc/ea_attn.hip editanything_amd/csrc/ea_norm.hip -o gpurun_exp/libea_attn_exp$m.so 2> gpurun_exp/build_attn_exp$m.log &
+done
+wait
+ls -la gpurun_exp/*.so
