@@ -461,6 +461,17 @@ def test_layernorm_rows_and_gather_add(kb):
     (1, 2, 40, 130, 40),    # SD1.5 head dim 40 (zero-padded to 48)
     (1, 1, 33, 96, 80),     # SAM ViT-H head dim
     (1, 1, 64, 64, 160),
+    # d = 64 from 4 key tiles up runs the software-pipelined loop: every arm of its tile schedule (even / odd count of
+    # full tiles, with and without a ragged last one); below that the in-order kernel (no full tile, 2 tiles); and a
+    # workgroup count that is not a multiple of 8 (XCD re-indexing remainder) for both
+    (1, 1, 32, 40, 64),
+    (1, 1, 32, 128, 64),
+    (1, 1, 32, 256, 64),
+    (1, 1, 32, 260, 64),
+    (1, 1, 32, 320, 64),
+    (1, 1, 32, 330, 64),
+    (1, 3, 400, 100, 64),
+    (1, 3, 400, 300, 64),
 ])
 def test_attention(kb, B, H, Nq, Nk, D):
     q, k, v = f16(B, Nq, H, D), f16(B, Nk, H, D), f16(B, Nk, H, D)
