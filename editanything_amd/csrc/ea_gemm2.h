@@ -749,15 +749,35 @@ void ea_gemm2_kernel(EaGemmParams p) {
     const int colbase = n0 + wn * WTN, rowbase = m0 + wm * WTM;
     const long long cb0 = (long long)batch * p.strideC, rb0 = (long long)batch * p.strideR;
     f16* outp = (f16*)e.out + cb0;
+    // Per-column terms.  Every global read of this epilogue is UNCONDITIONAL (clamped index, select afterwards) and sits
+    // in a wave-uniform block per operand: written as `if (n < N) x = load` hipcc branches around each load and parks an
+    // s_waitcnt vmcnt(0) behind it, which turned the NI row-vector reads + MI * NI / 2 residual reads of a tile into as
+    // many serial L2 round trips (guide section 5 trap (c); the round-2 ISA had 6 of them back to back).
     f32x4 cb[NI], cs[NI];
+    int ncl[NI];
+    bool nok[NI];
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = colbase + j * 16 + 4 * q4;
+      nok[j] = n < p.N;
+      ncl[j] = nok[j] ? n : 0;
       cb[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
       cs[j] = cb[j];
-      if (n < p.N) {
-        if (e.bias) cb[j] = *reinterpret_cast<const f32x4*>(e.bias + n);
-        if (TR == 2 && e.ln_stats) cs[j] = *reinterpret_cast<const f32x4*>(e.ln_colsum + n);
+    }
+    if (e.bias) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(e.bias + ncl[j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cb[j][r] = nok[j] ? t[r] : 0.0f;
+      }
+    }
+    if (TR == 2 && e.ln_stats) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(e.ln_colsum + ncl[j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[j][r] = nok[j] ? t[r] : 0.0f;
       }
     }
     auto ln_fold = [&](f32x4 x, int i, int j) {
@@ -847,15 +867,16 @@ void ea_gemm2_kernel(EaGemmParams p) {
     f16x8 rq[MI * JP + IP + 1];
     if (resp) {
 #pragma unroll
-      for (int v = 0; v < MI * JP + IP; ++v)
-        if (roff[v] >= 0) rq[v] = ea_ld8(resp + roff[v]);
+      for (int v = 0; v < MI * JP + IP; ++v) rq[v] = ea_ld8(resp + (roff[v] >= 0 ? roff[v] : 0));   // used only where voff >= 0
     }
     if (rvp) {
+      f32x4 rv[NI];
 #pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int n = colbase + j * 16 + 4 * q4;
-        if (n < e.N) cb[j] += *reinterpret_cast<const f32x4*>(rvp + n);
-      }
+      for (int j = 0; j < NI; ++j) rv[j] = *reinterpret_cast<const f32x4*>(rvp + ncl[j]);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cb[j][r] += nok[j] ? rv[j][r] : 0.0f;
     }
     auto finish = [&](f32x4 x, int i, int j) {
       x = ln_fold(x, i, j) + cb[j];

@@ -32,15 +32,36 @@ struct GnParams {
   int silu;
 };
 
-__device__ __forceinline__ f16x8 gn_load8(const GnParams& p, long long pix, int c0) {
-  if (c0 < p.c1) return ea_ld8(p.x1 + pix * p.c1 + c0);
-  const long long off = pix * p.c2 + (c0 - p.c1);
-  f16x8 v = ea_ld8(p.x2 + off);
-  if (p.x2_add) v = v + ea_ld8(p.x2_add + off);
-  return v;
-}
+// One thread's view of the (possibly two-source) input: its channel octet lives in ONE source for every pixel, so the
+// source choice is a per-thread pointer + stride fixed before the pixel loop, and a pixel's load is unconditional.
+// (Written as a branch per load -- `if (c0 < c1) load x1 else load x2` -- hipcc parks an s_waitcnt vmcnt(0) behind every
+// load and the "N loads in flight" of the loops below become N serial round trips: the round-2 profile had the
+// single-pass kernel at 18 us for 160 KB per workgroup.)
+template <bool ADD>
+struct GnSrc {
+  const f16* src; long long stride;
+  const f16* add;    // ADD only: the addend of an x2-side thread; an x1-side thread re-reads its own vector and drops it
+  bool second;
+  __device__ __forceinline__ void init(const GnParams& p, int c0) {
+    second = c0 >= p.c1;
+    src = second ? p.x2 + (c0 - p.c1) : p.x1 + c0;
+    stride = second ? p.c2 : p.c1;
+    add = (ADD && second) ? p.x2_add + (c0 - p.c1) : src;
+  }
+  __device__ __forceinline__ f16x8 load(long long pix) const {
+    f16x8 v = ea_ld8(src + pix * stride);
+    if (ADD) {
+      const f16x8 a = ea_ld8(add + pix * stride);
+      const f16x8 sum = v + a;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = second ? sum[j] : v[j];
+    }
+    return v;
+  }
+};
 
 // Pass 1: per-(sample, chunk, group) partial sums.  Four pixels in flight per thread before the first use.
+template <bool ADD>
 __global__ void ea_gn_stats_kernel(GnParams p) {
   EA_SMEM(smem);
   float* chs = reinterpret_cast<float*>(smem);  // [R][C]
@@ -52,31 +73,29 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
   const int p_begin = chunk * p.chunk_px;
   int p_end = p_begin + p.chunk_px;
   if (p_end > p.HW) p_end = p.HW;
+  GnSrc<ADD> in;
+  in.init(p, c0);
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
   const long long pix0 = (long long)b * p.HW;
-  int px = p_begin + pr;
-  for (; px + 3 * p.R < p_end; px += 4 * p.R) {
+  // every trip loads 4 pixels unconditionally (rows past the chunk end re-read its last pixel) and masks the sums
+  for (int px = p_begin + pr; px < p_end; px += 4 * p.R) {
     f16x8 x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = gn_load8(p, pix0 + px + u * p.R, c0);
+    for (int u = 0; u < 4; ++u) {
+      const int pu = px + u * p.R;
+      x[u] = in.load(pix0 + (pu < p_end ? pu : p_end - 1));
+    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 4; ++u) {
+      const float m = (px + u * p.R < p_end) ? 1.0f : 0.0f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float f = (float)x[u][j];
+        const float f = (float)x[u][j] * m;
         s[j] += f;
         q[j] += f * f;
       }
-  }
-  for (; px < p_end; px += p.R) {
-    f16x8 x = gn_load8(p, pix0 + px, c0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)x[j];
-      s[j] += f;
-      q[j] += f * f;
     }
   }
 #pragma unroll
@@ -108,7 +127,20 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
   }
 }
 
+template <bool SILU>
+__device__ __forceinline__ f16x8 gn_finish(const f16x8& x, const float (&a)[8], const float (&sh)[8]) {
+  f16x8 y;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float f = (float)x[j] * a[j] + sh[j];
+    if (SILU) f = ea_silu(f);
+    y[j] = (f16)f;
+  }
+  return y;
+}
+
 // Pass 2: fold the partials (in parallel, fixed order), normalise (+SiLU), write fp16.  Its own, finer chunking.
+template <bool ADD, bool SILU>
 __global__ void ea_gn_apply_kernel(GnParams p) {
   EA_SMEM(smem);
   float* part = reinterpret_cast<float*>(smem);   // [nsub][groups][2]
@@ -125,11 +157,23 @@ __global__ void ea_gn_apply_kernel(GnParams p) {
     if (nsub < 1) nsub = 1;
     for (int t = tid; t < nsub * p.groups; t += blockDim.x) {
       const int g = t % p.groups, sub = t / p.groups;
+      // chunks sub, sub + nsub, ... in that order, four loads in flight per trip (clamped index, masked sum)
       float gs = 0.0f, gq = 0.0f;
-      for (int ch = sub; ch < p.nchunk; ch += nsub) {
-        const float* src = p.partial + (((long long)b * p.nchunk + ch) * p.groups + g) * 2;
-        gs += src[0];
-        gq += src[1];
+      for (int ch = sub; ch < p.nchunk; ch += 4 * nsub) {
+        float ps[4], pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int cu = ch + u * nsub;
+          const float* src = p.partial + (((long long)b * p.nchunk + (cu < p.nchunk ? cu : p.nchunk - 1)) * p.groups + g) * 2;
+          ps[u] = src[0];
+          pq[u] = src[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = ch + u * nsub < p.nchunk;
+          gs += ok ? ps[u] : 0.0f;
+          gq += ok ? pq[u] : 0.0f;
+        }
       }
       part[(sub * p.groups + g) * 2] = gs;
       part[(sub * p.groups + g) * 2 + 1] = gq;
@@ -158,47 +202,37 @@ __global__ void ea_gn_apply_kernel(GnParams p) {
     a[j] = gst[g * 2 + 1] * p.gamma[c];
     sh[j] = p.beta[c] - gst[g * 2] * a[j];
   }
+  GnSrc<ADD> in;
+  in.init(p, c0);
   const long long pix0 = (long long)b * p.HW;
-  int px = p_begin + pr;
-  for (; px + 3 * p.R < p_end; px += 4 * p.R) {
+  for (int px = p_begin + pr; px < p_end; px += 4 * p.R) {
     f16x8 x[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) x[u] = gn_load8(p, pix0 + px + u * p.R, c0);
+    for (int u = 0; u < 4; ++u) {
+      const int pu = px + u * p.R;
+      x[u] = in.load(pix0 + (pu < p_end ? pu : p_end - 1));
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      f16x8 y;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float f = (float)x[u][j] * a[j] + sh[j];
-        if (p.silu) f = ea_silu(f);
-        y[j] = (f16)f;
-      }
-      ea_st8(p.out + (pix0 + px + u * p.R) * p.C + c0, y);
+      const int pu = px + u * p.R;
+      const f16x8 y = gn_finish<SILU>(x[u], a, sh);
+      if (pu < p_end) ea_st8(p.out + (pix0 + pu) * p.C + c0, y);
     }
-  }
-  for (; px < p_end; px += p.R) {
-    f16x8 x = gn_load8(p, pix0 + px, c0);
-    f16x8 y;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = (float)x[j] * a[j] + sh[j];
-      if (p.silu) f = ea_silu(f);
-      y[j] = (f16)f;
-    }
-    ea_st8(p.out + (pix0 + px) * p.C + c0, y);
   }
 }
 
 // Single pass for activations whose (sample, channel slab) fits the register file of one workgroup: one read, one
 // write, one launch.  A workgroup owns `SG` whole groups (slab = SG * cpg channels, a multiple of 8) of one sample for
 // ALL pixels; thread <-> (channel octet of the slab, pixel row), up to GN_MAXIT pixels per thread held in registers.
-constexpr int GN_MAXIT = 16;
+constexpr int GN_MAXIT = 16;   // pixels per thread, upper bound (the kernel is instantiated for 2 / 4 / 8 / 16)
 struct GnFusedParams {
   GnParams g;
   int slab_ch, slab_oct, sg;   // channels / octets / groups per slab
   int rows;                    // pixel rows per pass = threads / slab_oct
+  int its;                     // pixels per thread actually needed: ceil(HW / rows) rounded up to 2 / 4 / 8 / 16
 };
 
+template <bool ADD, bool SILU, int MAXIT>
 __global__ __launch_bounds__(512) void ea_gn_fused_kernel(GnFusedParams fp) {
   const GnParams& p = fp.g;
   EA_SMEM(smem);
@@ -212,18 +246,28 @@ __global__ __launch_bounds__(512) void ea_gn_fused_kernel(GnFusedParams fp) {
   const int cl = v * 8;                   // channel within the slab
   const int c0 = slab * fp.slab_ch + cl;  // global channel
   const long long pix0 = (long long)b * p.HW;
-  f16x8 x[GN_MAXIT];
+  GnSrc<ADD> in;
+  in.init(p, c0);
+  // all MAXIT loads issue back to back: pixels past the end (and the spare threads of the last pixel row) re-read
+  // the last pixel and are zeroed by a select afterwards
+  f16x8 x[MAXIT];
 #pragma unroll
-  for (int it = 0; it < GN_MAXIT; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
     const int px = pr + it * fp.rows;
-    if (on && px < p.HW) x[it] = gn_load8(p, pix0 + px, c0);
-    else x[it] = ea_zero8();
+    x[it] = in.load(pix0 + (px < p.HW ? px : p.HW - 1));
+  }
+#pragma unroll
+  for (int it = 0; it < MAXIT; ++it) {
+    const bool ok = on && pr + it * fp.rows < p.HW;
+    const f16x8 z = ea_zero8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[it][j] = ok ? x[it][j] : z[j];
   }
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
 #pragma unroll
-  for (int it = 0; it < GN_MAXIT; ++it)
+  for (int it = 0; it < MAXIT; ++it)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float f = (float)x[it][j];
@@ -271,30 +315,28 @@ __global__ __launch_bounds__(512) void ea_gn_fused_kernel(GnFusedParams fp) {
     sh[j] = p.beta[c0 + j] - gst[g * 2] * a[j];
   }
 #pragma unroll
-  for (int it = 0; it < GN_MAXIT; ++it) {
+  for (int it = 0; it < MAXIT; ++it) {
     const int px = pr + it * fp.rows;
-    if (px < p.HW) {
-      f16x8 y;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float f = (float)x[it][j] * a[j] + sh[j];
-        if (p.silu) f = ea_silu(f);
-        y[j] = (f16)f;
-      }
-      ea_st8(p.out + (pix0 + px) * p.C + c0, y);
-    }
+    const f16x8 y = gn_finish<SILU>(x[it], a, sh);
+    if (px < p.HW) ea_st8(p.out + (pix0 + px) * p.C + c0, y);
   }
 }
 
 // Slab of the single-pass kernel: the fewest whole groups whose channels are a multiple of 8 and span >= 64 bytes,
 // never straddling the x1 | x2 boundary of a two-source input.  Returns 0 when the single pass does not apply.
 static int gn_fused_plan(const GnParams& p, GnFusedParams& fp) {
+#ifdef EA_GN_NO_FUSED
+  return 0;
+#endif
   int sg = 0;
   for (int k = 1; k <= p.groups; ++k) {
     const int ch = k * p.cpg;
     if ((ch & 7) == 0 && ch >= 32 && (p.groups % k) == 0) { sg = k; break; }
   }
   if (!sg) return 0;
+  // from 32 x 32 latents up the two streaming passes win (B 8, 640 ch: 15.0 vs 17.1 us; 1280 ch concat: 20.8 vs 22.7):
+  // one workgroup per (sample, slab) leaves half the CUs idle and its phases run back to back
+  if (p.HW > 256) return 0;
   const int slab_ch = sg * p.cpg;
   if (p.c2 > 0 && (p.c1 % slab_ch) != 0) return 0;
   const int slab_oct = slab_ch / 8;
@@ -305,6 +347,8 @@ static int gn_fused_plan(const GnParams& p, GnFusedParams& fp) {
   if (rows < 1 || (long long)rows * GN_MAXIT < p.HW) return 0;
   fp.g = p;
   fp.sg = sg; fp.slab_ch = slab_ch; fp.slab_oct = slab_oct; fp.rows = rows;
+  const int need = (p.HW + rows - 1) / rows;
+  fp.its = need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
   return threads;
 }
 
@@ -456,6 +500,21 @@ __global__ __launch_bounds__(256) void ea_softmax_rows_kernel(const float* x, f1
 
 }  // namespace
 
+namespace {
+template <bool ADD, bool SILU>
+int gn_fused_launch_its(const GnFusedParams& fp, dim3 grid, int threads, int smem, void* stream) {
+  void (*kf)(GnFusedParams) = fp.its == 2 ? ea_gn_fused_kernel<ADD, SILU, 2> : fp.its == 4 ? ea_gn_fused_kernel<ADD, SILU, 4>
+                            : fp.its == 8 ? ea_gn_fused_kernel<ADD, SILU, 8> : ea_gn_fused_kernel<ADD, SILU, 16>;
+  ea_allow_big_lds(kf, smem);
+  EA_LAUNCH(kf, grid, dim3(threads, 1, 1), smem, stream, fp);
+  return ea_launch_status();
+}
+int gn_fused_launch(const GnFusedParams& fp, bool add, bool silu, dim3 grid, int threads, int smem, void* stream) {
+  if (add) return silu ? gn_fused_launch_its<true, true>(fp, grid, threads, smem, stream) : gn_fused_launch_its<true, false>(fp, grid, threads, smem, stream);
+  return silu ? gn_fused_launch_its<false, true>(fp, grid, threads, smem, stream) : gn_fused_launch_its<false, false>(fp, grid, threads, smem, stream);
+}
+}  // namespace
+
 extern "C" size_t ea_groupnorm_workspace_bytes(int B, int HW, int C, int groups) {
   if (B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return 0;
   return (size_t)B * EA_GN_MAX_CHUNKS * groups * 2 * sizeof(float);
@@ -481,24 +540,23 @@ extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, 
   if (st != EA_OK) return st;
   if (ws_bytes < ea_groupnorm_workspace_bytes(B, HW, p.C, groups)) return EA_ERR_WORKSPACE;
   p.partial = (float*)workspace;
+  const bool add = p.x2_add != nullptr;
   GnFusedParams fp;
   const int fthreads = gn_fused_plan(p, fp);
   if (fthreads > 0) {
     dim3 fgrid(p.C / fp.slab_ch, B, 1);
     const int fsmem = (2 * fp.rows * fp.slab_ch + 2 * fp.sg) * (int)sizeof(float);
-    auto kf = ea_gn_fused_kernel;
-    ea_allow_big_lds(kf, fsmem);
-    EA_LAUNCH(kf, fgrid, dim3(fthreads, 1, 1), fsmem, stream, fp);
-    return ea_launch_status();
+    return gn_fused_launch(fp, add, silu != 0, fgrid, fthreads, fsmem, stream);
   }
   dim3 grid(p.nchunk, B, 1), block(p.V * p.R, 1, 1);
   const int smem = 2 * p.R * p.C * (int)sizeof(float);
-  auto k1 = ea_gn_stats_kernel;
+  auto k1 = add ? ea_gn_stats_kernel<true> : ea_gn_stats_kernel<false>;
   ea_allow_big_lds(k1, smem);
   EA_LAUNCH(k1, grid, block, smem, stream, p);
   st = ea_launch_status();
   if (st != EA_OK) return st;
-  auto k2 = ea_gn_apply_kernel;
+  auto k2 = add ? (silu ? ea_gn_apply_kernel<true, true> : ea_gn_apply_kernel<true, false>)
+                : (silu ? ea_gn_apply_kernel<false, true> : ea_gn_apply_kernel<false, false>);
   int nsub = (p.V * p.R) / groups;
   if (nsub < 1) nsub = 1;
   const int smem2 = (2 * groups * nsub + 2 * groups) * (int)sizeof(float);

@@ -67,7 +67,7 @@ struct Case {
   int conv;            // 0 gemm, 1 conv
   int M, N, K;         // gemm
   int B, H, c1, c2, Cout, ksize, stride, ups;   // conv (square H x H input)
-  int act, residual;
+  int act, residual, rowvec;
   double flops;
 };
 
@@ -81,11 +81,11 @@ static std::vector<Case> all_cases() {
     c.flops = 2.0 * M * N * K;
     v.push_back(c);
   };
-  auto cv = [&](int B, int H, int c1, int c2, int Cout, int ks, int stride, int ups) {
+  auto cv = [&](int B, int H, int c1, int c2, int Cout, int ks, int stride, int ups, int rowvec = 0, int res = 0) {
     Case c{};
     char b[128];
-    snprintf(b, sizeof b, "conv%d B%d H%d c%d+%d->%d s%d u%d", ks, B, H, c1, c2, Cout, stride, ups);
-    c.name = b; c.conv = 1; c.B = B; c.H = H; c.c1 = c1; c.c2 = c2; c.Cout = Cout; c.ksize = ks; c.stride = stride; c.ups = ups;
+    snprintf(b, sizeof b, "conv%d B%d H%d c%d+%d->%d s%d u%d%s%s", ks, B, H, c1, c2, Cout, stride, ups, rowvec ? " emb" : "", res ? " res" : "");
+    c.name = b; c.conv = 1; c.rowvec = rowvec; c.residual = res; c.B = B; c.H = H; c.c1 = c1; c.c2 = c2; c.Cout = Cout; c.ksize = ks; c.stride = stride; c.ups = ups;
     const int Ho = ups ? 2 * H : (stride == 2 ? H / 2 : H);
     c.flops = 2.0 * B * Ho * Ho * Cout * ks * ks * (c1 + c2);
     v.push_back(c);
@@ -102,6 +102,11 @@ static std::vector<Case> all_cases() {
   cv(8, 32, 640, 0, 640, 3, 1, 1);    cv(8, 16, 1280, 0, 1280, 3, 1, 1); cv(8, 64, 320, 0, 320, 3, 2, 0);
   cv(8, 32, 320, 0, 640, 3, 1, 0);    cv(8, 16, 640, 0, 1280, 3, 1, 0);  cv(8, 64, 320, 320, 320, 1, 1, 0);
   cv(8, 64, 320, 0, 320, 1, 1, 0);    cv(8, 8, 1280, 0, 1280, 1, 1, 0);
+  // ResBlock forms of the same convolutions: in_layers conv + the per-sample embedding row vector (openaimodel.py:259-262),
+  // out_layers conv + the skip tensor as residual (openaimodel.py:263)
+  cv(8, 64, 320, 0, 320, 3, 1, 0, 1, 0);  cv(8, 64, 320, 0, 320, 3, 1, 0, 0, 1);
+  cv(8, 32, 640, 0, 640, 3, 1, 0, 1, 0);  cv(8, 32, 640, 0, 640, 3, 1, 0, 0, 1);
+  cv(8, 16, 1280, 0, 1280, 3, 1, 0, 1, 0);
   // SAM ViT-H linears (4 images: 16384 tokens / 19600 window tokens) and VAE decoder convs (batch 4)
   g(16384, 3840, 1280, 0, 0); g(16384, 1280, 1280, 0, 1); g(16384, 5120, 1280, 2, 0); g(16384, 1280, 5120, 0, 1);
   cv(4, 256, 256, 0, 256, 3, 1, 0);   cv(4, 512, 128, 0, 128, 3, 1, 0);
@@ -207,12 +212,14 @@ int main(int argc, char** argv) {
     void* bias = dev_f32(N, 0.1f);
     const int Nout = c.act == EA_ACT_GEGLU ? N / 2 : N;
     void* res = c.residual ? dev_f16((size_t)M * Nout, 1.0f) : nullptr;
+    void* rowvec = (c.conv && c.rowvec) ? dev_f32((size_t)c.B * N, 0.5f) : nullptr;
     void *o_test, *o_ref;
     HIP_CHECK(hipMalloc(&o_test, (size_t)M * Nout * 2));
     HIP_CHECK(hipMalloc(&o_ref, (size_t)M * Nout * 2));
     auto make_epi = [&](void* o) {
       ea_epilogue e{};
       e.bias = (const float*)bias; e.act = c.act; e.scale = 1.0f; e.rows_per_group = 1;
+      if (rowvec) { e.rowvec = (const float*)rowvec; e.rowvec_ld = N; e.rows_per_group = M / c.B; }
       e.residual = res; e.ldr = Nout; e.out = o; e.ldc = Nout; e.geglu_block = c.act == EA_ACT_GEGLU ? geglu : 0;
       return e;
     };
@@ -302,7 +309,7 @@ int main(int argc, char** argv) {
       fflush(stdout);
       if (out) { fputs(line, out); fputc('\n', out); fflush(out); }
     }
-    for (void* p : {A, A2, W, bias, res, o_test, o_ref})
+    for (void* p : {A, A2, W, bias, res, rowvec, o_test, o_ref})
       if (p) HIP_CHECK(hipFree(p));
   }
   if (out) fclose(out);
