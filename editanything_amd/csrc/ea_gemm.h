@@ -50,6 +50,8 @@ struct EaEpilogue {
   const float* ln_colsum; // [N_gemm] row sums of the gamma-folded fp16 weight
   float ln_eps;
   float* row_stats_out;   // [parts][M][2] partial (sum, sum of squares) of the OUTPUT rows, one part per wave-column block
+  float* gn_stats_out;    // [B][gn_hw / WTM][N / gn_cpg][2] GroupNorm partials of the OUTPUT (register-direct epilogue only)
+  int gn_hw, gn_cpg;
 };
 
 struct EaGemmParams {

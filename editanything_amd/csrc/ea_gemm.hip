@@ -57,6 +57,10 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
   e.ln_colsum = epi->ln_colsum;
   e.ln_eps = epi->ln_eps;
   e.row_stats_out = epi->row_stats_out;
+  e.gn_stats_out = epi->gn_stats_out;
+  e.gn_hw = epi->gn_rows_per_sample;
+  e.gn_cpg = epi->gn_cpg;
+  if (e.gn_stats_out && (e.gn_hw <= 0 || e.gn_cpg < 8 || (((uintptr_t)e.gn_stats_out) & 7) || epi->act == EA_ACT_GEGLU)) return EA_ERR_BAD_ARG;
   if (e.ln_stats && (!e.ln_colsum || e.ln_parts <= 0)) return EA_ERR_BAD_ARG;
   if ((((uintptr_t)e.ln_stats) & 7) || (((uintptr_t)e.ln_colsum) & 15) || (((uintptr_t)e.row_stats_out) & 7)) return EA_ERR_BAD_ARG;
   e.M = M;
@@ -192,6 +196,16 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   return t;
 }
 
+// rows per GroupNorm-statistics chunk of plan t (its wave tile height), 0 = the epilogue cannot emit them: the wave
+// tiles (bm/2 x bn/2) must hold whole groups and row ranges inside one sample
+static int gn_stats_rows(const Plan2& t, int M, int N, int hw, int cpg) {
+  if (t.splits != 1 || (t.kind != 1 && t.kind != 9) || g_no_tr) return 0;
+  const int wtm = t.bm / 2, wtn = t.bn / 2;
+  if (hw <= 0 || cpg < 8 || (M % hw) || (hw % wtm) || (wtn % cpg) || (N % t.bn) || (N % cpg)) return 0;
+  if (hw / wtm > 128) return 0;   // EA_GN_MAX_CHUNKS of the apply pass
+  return wtm;
+}
+
 static int launch_reduce(EaGemmParams& p, void* stream) {
   const long long total = (long long)p.batch * p.M * ((p.N + 7) / 8);
   long long nb = (total + 255) / 256;
@@ -268,6 +282,9 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
                    (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
   // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
   if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
+  // ... and so do the GroupNorm partials (callers ask ea_gemm_gn_stats_chunk_rows first)
+  if (p.epi.gn_stats_out && (!tr || t.splits > 1 || p.epi_fast != 1 || p.batch != 1 || !gn_stats_rows(t, p.M, p.N, p.epi.gn_hw, p.epi.gn_cpg)))
+    return EA_ERR_UNSUPPORTED;
 #define EA_LAUNCH_TR(BM_, BN_, TR_)                                                   \
   do {                                                                                \
     auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, TR_>;                     \
@@ -276,7 +293,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                           \
   } while (0)
   if (tr) {
-    const bool lnx = p.epi.ln_stats || (p.epi.row_stats_out && t.splits == 1);   // fold / statistics compiled in
+    const bool lnx = p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1);   // fold / statistics compiled in
     if (t.kind == 1) {
       if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
       else { if (lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
@@ -321,7 +338,7 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   read_env();
   if (!g_force_generic && fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
   if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
-  if (p.epi.ln_stats) return EA_ERR_UNSUPPORTED;
+  if (p.epi.ln_stats || p.epi.gn_stats_out) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
   TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);
   p.splits = t.splits;
@@ -370,6 +387,12 @@ extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
   Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
   return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
+}
+
+extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
+  if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+  Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
+  return gn_stats_rows(t, M, N, rows_per_sample, cpg);
 }
 
 extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {

@@ -878,6 +878,34 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cb[j][r] += nok[j] ? rv[j][r] : 0.0f;
     }
+    // ---- GroupNorm statistics of the output (TR == 2, e.gn_stats_out): per wave tile [WTM rows of one sample] x [WTN
+    // columns = whole groups], the (sum, sum of squares) of the ROUNDED fp16 outputs per group -- what the GroupNorm that
+    // reads this tensor needs (openaimodel.py:254-274: conv -> GroupNorm32 -> SiLU -> conv), so that norm runs as one
+    // streaming normalise pass with no statistics pass.  A lane's 8-column vector touches at most two groups (cpg >= 8):
+    // column sums are kept per vector position over the row tiles, then binned into (first group, second group).
+    const bool gn_on = TR == 2 && e.gn_stats_out != nullptr;
+    float gcs[8], gcq[8];          // column sums of the vector position being swept
+    float gbin[3][4];              // per vector position (2 column pairs + the odd tile): s0, q0, s1, q1
+    int gbin_g[3];                 // first group of each position (the second is + 1)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) { gbin_g[v] = 0; gbin[v][0] = gbin[v][1] = gbin[v][2] = gbin[v][3] = 0.0f; }
+    auto gn_reset = [&]() {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { gcs[r] = 0.0f; gcq[r] = 0.0f; }
+    };
+    auto gn_bin = [&](int slot, int ncol0) {     // ncol0: global column of the vector's first element
+      const int g0 = ncol0 / e.gn_cpg;
+      const int split = e.gn_cpg - (ncol0 - g0 * e.gn_cpg);   // columns of the vector that belong to group g0 (>= 8: all)
+      float s0 = 0.0f, q0 = 0.0f, s1 = 0.0f, q1 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const bool first = r < split;
+        s0 += first ? gcs[r] : 0.0f; q0 += first ? gcq[r] : 0.0f;
+        s1 += first ? 0.0f : gcs[r]; q1 += first ? 0.0f : gcq[r];
+      }
+      gbin_g[slot] = g0;
+      gbin[slot][0] = s0; gbin[slot][1] = q0; gbin[slot][2] = s1; gbin[slot][3] = q1;
+    };
     auto finish = [&](f32x4 x, int i, int j) {
       x = ln_fold(x, i, j) + cb[j];
       if (e.act == EA_ACT_SILU) {
@@ -918,19 +946,70 @@ void ea_gemm2_kernel(EaGemmParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
       ea_st8(outp + voff[v], h);
+      if (gn_on) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { const float f = (float)h[r]; gcs[r] += f; gcq[r] += f * f; }
+      }
     };
+    static_assert(JP <= 2, "GroupNorm statistics slots");
+    // column pairs outermost: one vector position is swept over all its row tiles before the next (store order only)
 #pragma unroll
-    for (int ii = 0; ii < MI; ++ii)
+    for (int jp = 0; jp < JP; ++jp) {
+      gn_reset();
 #pragma unroll
-      for (int jp = 0; jp < JP; ++jp)
+      for (int ii = 0; ii < MI; ++ii)
         emit(finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp : 0], ii, 2 * jp), finish(acc[MT == 16 ? ii : 0][MT == 16 ? 2 * jp + 1 : 0], ii, 2 * jp + 1),
              ii * JP + jp, ii, ii);
+      if (gn_on) gn_bin(jp, colbase + (2 * jp + sel) * 16 + coff);
+    }
+    gn_reset();
 #pragma unroll
     for (int ip = 0; ip < IP; ++ip)
       emit(finish(acc[MT == 16 ? 2 * ip : 0][MT == 16 ? NI - 1 : 0], 2 * ip, NI - 1),
            finish(acc[MT == 16 ? (2 * ip + 1 < MI ? 2 * ip + 1 : 0) : 0][MT == 16 ? NI - 1 : 0], 2 * ip + 1 < MI ? 2 * ip + 1 : 0, NI - 1), MI * JP + ip, 2 * ip,
            2 * ip + 1 < MI ? 2 * ip + 1 : 0);
+    if (gn_on && IP > 0) gn_bin(2, colbase + (NI - 1) * 16 + coff);
     stats_flush();
+    if (gn_on) {
+      // rows: the 16 lanes of a q4 group hold the same columns -> butterfly over lane bits 0..3; then the four q4
+      // lanes' bins go through LDS and lane g < groups-per-wave-tile sums the ones of ITS group in a fixed order
+      constexpr int NSLOT = (IP > 0) ? 3 : 2;
+#pragma unroll
+      for (int v = 0; v < NSLOT; ++v)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float x = gbin[v][k];
+          x += ea_shfl_xor(x, 1); x += ea_shfl_xor(x, 2); x += ea_shfl_xor(x, 4); x += ea_shfl_xor(x, 8);
+          gbin[v][k] = x;
+        }
+      __syncthreads();   // every wave is past its last fragment read: the stage ring is free
+      float* gl = reinterpret_cast<float*>(smem) + wave * (4 * NSLOT * 2 * 3);   // [q4][slot][half] x (group, s, q)
+      if (c16 == 0) {
+#pragma unroll
+        for (int v = 0; v < NSLOT; ++v)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            float* d = gl + ((q4 * NSLOT + v) * 2 + hf) * 3;
+            d[0] = (float)(gbin_g[v] + hf);
+            d[1] = gbin[v][2 * hf];
+            d[2] = gbin[v][2 * hf + 1];
+          }
+      }
+      ea_wave_lds_sync();
+      const int ngw = WTN / e.gn_cpg;               // groups of this wave tile
+      if (lane < ngw && colbase < e.N && rowbase < p.M) {
+        const int g = colbase / e.gn_cpg + lane;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int t = 0; t < 4 * NSLOT * 2; ++t) {
+          const bool mine = (int)gl[t * 3] == g;
+          s1 += mine ? gl[t * 3 + 1] : 0.0f;
+          s2 += mine ? gl[t * 3 + 2] : 0.0f;
+        }
+        const int b = rowbase / e.gn_hw, chunk = (rowbase - b * e.gn_hw) / WTM;
+        const int nchunk = e.gn_hw / WTM, groups = e.N / e.gn_cpg;
+        *reinterpret_cast<f32x2*>(e.gn_stats_out + (((long long)b * nchunk + chunk) * groups + g) * 2) = f32x2{s1, s2};
+      }
+    }
     EA_STAMP(4);
     return;
   }

@@ -564,6 +564,32 @@ extern "C" int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, 
   return ea_launch_status();
 }
 
+extern "C" int ea_groupnorm_apply_f16(const void* x, int C, const float* gamma, const float* beta, void* out, int B,
+                                      int HW, int groups, float eps, int silu, const float* partial, int nchunk,
+                                      void* stream) {
+  if (!x || !gamma || !beta || !out || !partial) return EA_ERR_BAD_ARG;
+  if (B <= 0 || HW <= 0 || C <= 0 || nchunk <= 0 || nchunk > EA_GN_MAX_CHUNKS) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)partial & 7)) return EA_ERR_BAD_ARG;
+  GnParams p;
+  memset(&p, 0, sizeof(p));
+  p.x1 = (const f16*)x; p.c1 = C;
+  p.gamma = gamma; p.beta = beta;
+  p.out = (f16*)out;
+  p.B = B; p.HW = HW; p.C = C; p.groups = groups;
+  p.eps = eps; p.silu = silu;
+  int st = gn_plan(p);
+  if (st != EA_OK) return st;
+  p.partial = const_cast<float*>(partial);   // read only by the apply pass
+  p.nchunk = nchunk;
+  dim3 block(p.V * p.R, 1, 1);
+  auto k2 = silu ? ea_gn_apply_kernel<false, true> : ea_gn_apply_kernel<false, false>;
+  int nsub = (p.V * p.R) / groups;
+  if (nsub < 1) nsub = 1;
+  const int smem2 = (2 * groups * nsub + 2 * groups) * (int)sizeof(float);
+  EA_LAUNCH(k2, dim3(p.anchunk, B, 1), block, smem2, stream, p);
+  return ea_launch_status();
+}
+
 extern "C" int ea_layernorm_f16(const void* x, int in_f32, const float* gamma, const float* beta, void* out,
                                 int M, int C, float eps, void* stream) {
   return ea_layernorm_rows_f16(x, in_f32, gamma, beta, out, M, C, eps, nullptr, stream);

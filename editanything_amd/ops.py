@@ -198,9 +198,24 @@ def _rows_per_group(rowvec, s):
     return s.Hout * s.Wout
 
 
+GN_EPILOGUE = os.environ.get("EA_GN_EPILOGUE", "1") != "0"      # A/B switch (tools/): 0 keeps the statistics passes
+
+
+def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
+    """Rows per GroupNorm-statistics chunk when a contraction of this shape can leave the partials of its OUTPUT behind
+    for the GroupNorm that reads it (`ea_epilogue.gn_stats_out`), else 0."""
+    if not GN_EPILOGUE or PROFILE is not None or N % groups:
+        return 0
+    return int(_lib().ea_gemm_gn_stats_chunk_rows(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
+
+
 def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
-           residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None):
-    """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin)."""
+           residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None,
+           gn_groups=0):
+    """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin).
+
+    gn_groups > 0: the caller's next op is a GroupNorm over this output -- returns (out, stats) with stats =
+    (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them."""
     _check_dev(x1, w)
     s = _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout)
     cout = w.shape[0]
@@ -208,15 +223,25 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
         out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
     ws = workspace(x1.device)
     e = _epilogue(out, cout, bias, act, scale, residual, rowvec, _rows_per_group(rowvec, s), row_scale)
+    stats = None
+    if gn_groups:
+        hw = s.Hout * s.Wout
+        rows = gn_stats_plan(s.B * hw, cout, w.shape[1], 1, hw, gn_groups) if out.dtype == torch.float16 else 0
+        if rows:
+            part = torch.empty((s.B, hw // rows, gn_groups, 2), dtype=torch.float32, device=x1.device)
+            e.gn_stats_out, e.gn_rows_per_sample, e.gn_cpg = _p(part), hw, cout // gn_groups
+            stats = (part, hw // rows)
     ev = _prof_begin()
     st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
     _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1],
               f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}")
     L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
-    return out
+    return (out, stats) if gn_groups else out
 
 
-def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=None, out=None):
+def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=None, out=None, stats=None):
+    """GroupNorm (+SiLU).  stats = (partials, nchunk) left behind by the contraction that produced x1 (conv2d / gemm
+    `gn_groups=`): the normalise pass alone, no statistics pass."""
     _check_dev(x1, gamma)
     B = x1.shape[0]
     c1 = x1.shape[-1]
@@ -224,6 +249,13 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
     HW = x1.numel() // (B * c1)
     if out is None:
         out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=torch.float16, device=x1.device)
+    if stats is not None:
+        assert x2 is None
+        part, nchunk = stats
+        st = _lib().ea_groupnorm_apply_f16(_p(x1), c1, _p(gamma), _p(beta), _p(out), B, HW, groups, eps, int(silu), _p(part),
+                                           nchunk, _stream())
+        L.check(st, "ea_groupnorm_apply_f16")
+        return out
     ws = workspace(x1.device)
     ev = _prof_begin()
     st = _lib().ea_groupnorm_f16(_p(x1), c1, _p(x2), c2, _p(x2_add), _p(gamma), _p(beta), _p(out), B, HW, groups, eps,
@@ -234,9 +266,18 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
 
 
 def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=None, x2_add=None, stride=1, pad=1,
-                           ups=False, residual=None, rowvec=None, scale=1.0, out_dtype=torch.float16):
-    """ResBlock half (openaimodel.py:254-274) as ONE C-ABI call."""
+                           ups=False, residual=None, rowvec=None, scale=1.0, out_dtype=torch.float16, gn_in=None,
+                           gn_out_groups=0):
+    """ResBlock half (openaimodel.py:254-274): GroupNorm32 -> SiLU -> conv3x3 (+ embedding row vector / + skip).
+
+    gn_in: this GroupNorm's statistics, left behind by the launch that produced x1 (then the norm is the streaming
+    normalise pass alone).  gn_out_groups > 0: the conv's epilogue leaves the statistics of ITS output for the next
+    GroupNorm -- returns (out, stats-or-None).  Without either it is ONE C-ABI call (statistics, normalise, conv)."""
     _check_dev(x1, w)
+    if gn_in is not None or gn_out_groups:
+        n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add, stats=gn_in)
+        return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype,
+                      gn_groups=gn_out_groups)
     if PROFILE is not None:     # roofline leg: same kernels, launched separately so events bracket only the MFMA kernel
         n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add)
         return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype)

@@ -81,14 +81,23 @@ class _Res:
             self.skip_w = pack_conv(sd[p + "skip_connection.weight"], device)
             self.skip_b = _f32(sd[p + "skip_connection.bias"], device)
 
-    def forward(self, x1, x2, emb_all):
+    def forward(self, x1, x2, emb_all, gn_in=None, gn_out=False):
+        """gn_in: statistics of x1 for in_layers' GroupNorm, left by the launch that produced x1 (single-source input
+        only).  gn_out: the caller's next op is a 32-group GroupNorm over the result (a SpatialTransformer's norm / the
+        next ResBlock's in_layers) -- returns (h, stats-or-None).  The out_layers GroupNorm always takes its statistics
+        from the in_layers conv's epilogue where that launch can emit them (ops.gn_stats_plan)."""
         rowvec = emb_all[:, self.emb_off:self.emb_off + self.cout]
-        h = ops.groupnorm_silu_conv3x3(x1, self.g1w, self.g1b, self.w1, self.b1, x2=x2, rowvec=rowvec)
+        h, st2 = ops.groupnorm_silu_conv3x3(x1, self.g1w, self.g1b, self.w1, self.b1, x2=x2, rowvec=rowvec,
+                                            gn_in=gn_in if x2 is None else None, gn_out_groups=32)
         if self.skip_w is not None:
             res = ops.conv2d(x1, self.skip_w, self.skip_b, ksize=1, pad=0, x2=x2)
         else:
             res = x1
-        return ops.groupnorm_silu_conv3x3(h, self.g2w, self.g2b, self.w2, self.b2, residual=res)
+        out = ops.groupnorm_silu_conv3x3(h, self.g2w, self.g2b, self.w2, self.b2, residual=res, gn_in=st2,
+                                         gn_out_groups=32 if gn_out else 0)
+        if gn_out:
+            return out
+        return out[0] if isinstance(out, tuple) else out
 
 
 class _Attn:
@@ -125,12 +134,12 @@ class _Attn:
         """Text K/V are step-invariant: [B, L, ctx] -> [B, L, 2*inner] once per call."""
         return ops.gemm(ctx16, self.wkv2)
 
-    def forward(self, x, kv):
+    def forward(self, x, kv, gn_in=None):
         B, H, W, Cc = x.shape
         inner = self.inner
         M = B * H * W
         xt = x.view(B, H * W, Cc)
-        xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False)
+        xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False, stats=gn_in)
         # a norm -> Linear pair runs as ONE launch when it can: the producer of h leaves the row partials behind
         # (row_stats), the consumer's epilogue applies the LayerNorm algebraically (ops.gemm ln_fold)
         fold = [ops.PROFILE is None and ops.ln_fold_ok(M, wf.shape[0], inner) for wf, _, _ in self.fold]
@@ -233,16 +242,23 @@ class _UNetBase:
         return [a.project_context(ctx16) for a in self._attn]
 
     def _run(self, mods, h, x2, emb_all, kvs, residual=None):
-        for kind, m in mods:
+        stats = None      # GroupNorm statistics of h left behind by the launch that produced it (ResBlock -> transformer)
+        for k, (kind, m) in enumerate(mods):
             if kind == "conv_in":
                 h = m.forward(h, residual=residual)
             elif kind == "res":
-                h = m.forward(h, x2, emb_all)
+                feeds_norm = k + 1 < len(mods) and mods[k + 1][0] == "attn"
+                if feeds_norm:
+                    h, stats = m.forward(h, x2, emb_all, gn_out=True)
+                else:
+                    h = m.forward(h, x2, emb_all)
                 x2 = None
+                continue
             elif kind == "attn":
-                h = m.forward(h, kvs[self._attn_index[id(m)]])
+                h = m.forward(h, kvs[self._attn_index[id(m)]], gn_in=stats)
             else:
                 h = m.forward(h)
+            stats = None
         return h
 
     def _index_attn(self):

@@ -86,6 +86,15 @@ typedef struct ea_epilogue {
   /* Row statistics of THIS launch's fp16 output, for the next launch's fold: [ea_row_stats_parts(N)][M][2].  Written by
    * the epilogue where it can, by one extra small launch otherwise (split-K, generic kernel).  NULL = off. */
   float* row_stats_out;
+  /* GroupNorm statistics of THIS launch's fp16 output, for the GroupNorm that consumes it (ResBlock in_layers conv ->
+   * out_layers GroupNorm, out_layers conv + skip -> SpatialTransformer GroupNorm: openaimodel.py:254-274,
+   * attention.py:308-311): per (sample, row chunk, group) partial (sum, sum of squares) of the ROUNDED outputs, written
+   * by the epilogue in the layout ea_groupnorm_apply_f16 folds: [B][rows_per_sample / chunk_rows][N / gn_cpg][2] with
+   * chunk_rows = ea_gemm_gn_stats_chunk_rows(...).  Only launches for which that query returns > 0 accept it
+   * (EA_ERR_UNSUPPORTED otherwise).  NULL = off. */
+  float* gn_stats_out;
+  int32_t gn_rows_per_sample;   /* output rows (pixels) per sample: M = B * gn_rows_per_sample */
+  int32_t gn_cpg;               /* channels per group (>= 8) */
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and
@@ -126,6 +135,10 @@ size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch);
  * of this shape can apply the fold. */
 int ea_row_stats_parts(int N);
 int ea_gemm_ln_fold_ok(int M, int N, int K);
+/* Rows per GroupNorm-statistics chunk (the wave tile height of the instantiation the planner picks) when a launch of
+ * this shape can emit `gn_stats_out` from its epilogue, else 0: unsplit register-direct launches whose wave tiles hold
+ * whole groups and whole-sample row ranges.  conv: 1 for ea_conv2d_f16 launches (M = B * Hout * Wout, K = ks*ks*Cin). */
+int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg);
 
 /* C[b] = epilogue(A[b] (MxK, lda) * W[b]^T (NxK, ldw)), b < batch. */
 int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
@@ -142,6 +155,10 @@ size_t ea_groupnorm_workspace_bytes(int B, int HW, int C, int groups);
 int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, const void* x2_add,
                      const float* gamma, const float* beta, void* out, int B, int HW, int groups,
                      float eps, int silu, void* workspace, size_t ws_bytes, void* stream);
+/* GroupNorm (+SiLU) from statistics a producing contraction left behind (`ea_epilogue.gn_stats_out`): the streaming
+ * normalise pass only -- one read, one write, no statistics pass.  partial: [B][nchunk][groups][2]. */
+int ea_groupnorm_apply_f16(const void* x, int C, const float* gamma, const float* beta, void* out, int B, int HW,
+                           int groups, float eps, int silu, const float* partial, int nchunk, void* stream);
 
 /* ResBlock half: out = epilogue(conv3x3(silu(groupnorm(cat(x1,x2+x2_add))))) -- one call.
  * `norm_out` is caller scratch [B*Hin*Win*(c1+c2)] fp16 for the normalised activation. */

@@ -874,6 +874,71 @@ def test_row_statistics_output(kb, M, N, K, res, variant, monkeypatch):
         assert np.abs(got[..., 1] - ref[..., 1]).max() <= 2e-3 * ref[..., 1].max()
 
 
+@pytest.mark.parametrize("B,H,cin,cout,groups,variant,emb,res", [
+    (2, 16, 64, 320, 32, "1", True, False),    # in_layers conv + embedding row vector, 128-row tiles: cpg 10 (vectors straddle groups)
+    (2, 16, 64, 320, 32, "9", False, True),    # out_layers conv + skip, 64-row tiles
+    (1, 16, 64, 640, 32, "1", False, False),   # cpg 20, 4 column tiles
+    (2, 8, 128, 1280, 32, "9", True, True),    # cpg 40, 8x8 samples = two 32-row chunks each
+    (1, 16, 64, 256, 32, "1", False, False),   # 128-wide tiles (64-column wave tiles), cpg 8: no odd column tile
+])
+def test_groupnorm_statistics_from_the_producing_conv(kb, B, H, cin, cout, groups, variant, emb, res):
+    """`gn_stats_out`: the conv epilogue leaves the per-(sample, row chunk, group) partial (sum, sum of squares) of its
+    rounded output behind, and ea_groupnorm_apply_f16 normalises from them in one pass == ea_groupnorm_f16 on the same
+    tensor == torch GroupNorm + SiLU (openaimodel.py:254-274: conv -> GroupNorm32 -> SiLU)."""
+    tune(kb, variant=int(variant), splits=1)    # (small test shapes: keep the planner from splitting K to fill the chip)
+    HW, M, K = H * H, B * H * H, 9 * cin
+    cpg = cout // groups
+    rows = kb.lib.ea_gemm_gn_stats_chunk_rows(M, cout, K, 1, HW, cpg)
+    assert rows == (64 if variant == "1" else 32)
+    nchunk = HW // rows
+    x = f16(B, H, H, cin)
+    W = f16(cout, K, scale=0.05)
+    bias = f32(cout)
+    rv = f32(B, cout) if emb else None
+    R = f16(M, cout) if res else None
+    part = kb.zeros((B, nchunk, groups, 2), np.float32)
+    y = kb.zeros((M, cout), np.float16)
+    e = epilogue(y, bias=bias, rowvec=rv, rows_per_group=HW, residual=R, gn_stats_out=part, gn_rows_per_sample=HW, gn_cpg=cpg)
+    src = conv_src(x)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, cout, K, 1))
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    yh = kb.down(y).astype(np.float64).reshape(B, nchunk, rows, groups, cpg)
+    got = kb.down(part).astype(np.float64)
+    ref = np.stack([yh.sum((2, 4)), (yh * yh).sum((2, 4))], -1)
+    assert np.abs(got[..., 0] - ref[..., 0]).max() <= 1e-4 * np.abs(yh).sum((2, 4)).max()
+    assert np.abs(got[..., 1] - ref[..., 1]).max() <= 1e-4 * ref[..., 1].max()
+    # the consumer: one normalise pass from the partials
+    gamma, beta = f32(cout), f32(cout)
+    out = kb.zeros((B, HW, cout), np.float16)
+    assert kb.lib.ea_groupnorm_apply_f16(ptr(y), cout, ptr(gamma), ptr(beta), ptr(out), B, HW, groups, 1e-5, 1, ptr(part),
+                                         nchunk, kb.stream) == 0
+    out2 = kb.zeros((B, HW, cout), np.float16)
+    ws2 = workspace(kb, kb.lib.ea_groupnorm_workspace_bytes(B, HW, cout, groups))
+    assert kb.lib.ea_groupnorm_f16(ptr(y), cout, None, 0, None, ptr(gamma), ptr(beta), ptr(out2), B, HW, groups, 1e-5, 1,
+                                   ptr(ws2), ws_nbytes(ws2), kb.stream) == 0
+    yt = t(kb.down(y)).reshape(B, HW, cout)
+    want = F.silu(F.group_norm(yt.permute(0, 2, 1), groups, t(gamma), t(beta), 1e-5)).permute(0, 2, 1).numpy()
+    assert relerr(kb.down(out), want) < 3e-3
+    assert np.abs(kb.down(out).astype(np.float32) - kb.down(out2).astype(np.float32)).max() <= 4e-3 * np.abs(want).max()
+
+
+def test_groupnorm_statistics_refused_where_they_cannot_be_emitted(kb):
+    """Shapes whose wave tiles do not hold whole groups / whole-sample row ranges, split-K plans and the generic kernel
+    say so up front (0 from the query, EA_ERR_UNSUPPORTED from the launch)."""
+    assert kb.lib.ea_gemm_gn_stats_chunk_rows(512, 320, 576, 1, 256, 12) == 0      # 80 % 12 != 0
+    assert kb.lib.ea_gemm_gn_stats_chunk_rows(512, 320, 576, 1, 48, 10) == 0       # chunk rows do not divide the sample
+    assert kb.lib.ea_gemm_gn_stats_chunk_rows(512, 200, 576, 1, 256, 10) == 0      # N is not whole tiles
+    assert kb.lib.ea_gemm_gn_stats_chunk_rows(512, 320, 100, 1, 256, 10) == 0      # K % 64: generic kernel
+    M, N, K = 256, 320, 100 * 8
+    A, W = f16(M, K), f16(N, K, scale=0.1)
+    part = kb.zeros((1, 4, 32, 2), np.float32)
+    y = kb.zeros((M, N), np.float16)
+    e = epilogue(y, gn_stats_out=part, gn_rows_per_sample=M, gn_cpg=10)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+    st = kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream)
+    assert st != 0
+
+
 @pytest.mark.parametrize("M,N,K,act,gb,variant", [
     (256, 960, 320, 0, 0, ""),        # LN1 -> fused q/k/v projection (no bias), level-0 width
     (200, 320, 320, 0, 0, "1"),       # LN2 -> to_q, 128-row tiles, ragged M
