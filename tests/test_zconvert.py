@@ -213,6 +213,44 @@ def test_add_control_keys_and_transfer_control():
             assert torch.allclose(v, target[k], atol=1e-6)
 
 
+@pytest.mark.parametrize("tool", ["tools/tool_add_control_sd21.py", "tools/tool_add_control_sd15.py"])
+def test_add_control_keys_vs_the_reference_tool_executed_from_source(tool):
+    """`convert.add_control_keys` against the reference tool's OWN merge loop: `get_node_name` and the
+    `for k in scratch_dict.keys()` statement of tools/tool_add_control_sd21.py:17-49 are compiled from the source where
+    it lies and run on a ControlLDM-shaped scratch state dict (control_model.* zero-initialised where the real modules
+    zero-initialise, model.diffusion_model.*, first_stage_model.*) and a plain SD checkpoint."""
+    import ast
+    ref = "/root/reference"
+    path = os.path.join(ref, tool)
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present (GPU box)")
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_node_name"]
+    loop = [n for n in tree.body if isinstance(n, ast.For) and isinstance(n.iter, ast.Call)
+            and ast.unparse(n.iter) == "scratch_dict.keys()"]
+    assert len(fn) == 1 and len(loop) == 1
+    g = torch.Generator().manual_seed(3)
+    ushapes = arch.unet_param_shapes(arch.TINY_UNET)
+    cshapes = arch.unet_param_shapes(arch.TINY_CONTROLNET, controlnet=True)
+    pretrained = {"model.diffusion_model." + k: torch.randn(sh, generator=g) for k, sh in ushapes.items()}
+    pretrained["first_stage_model.decoder.conv_in.weight"] = torch.randn(4, 3, generator=g)
+    pretrained["cond_stage_model.transformer.x"] = torch.randn(5, generator=g)
+    # the scratch model: what `create_model(...).state_dict()` holds before loading -- fresh tensors everywhere; the
+    # control-only modules are zero_module()s / the hint block (cldm/cldm.py:147-163, 281-283), zeros here like
+    # add_control_keys' fill value so the two results can be compared entry by entry
+    scratch = {k: torch.randn(v.shape, generator=g) for k, v in pretrained.items()}
+    for k, sh in cshapes.items():
+        twin = "model.diffusion_model." + k in pretrained
+        scratch["control_model." + k] = torch.randn(sh, generator=g) if twin else torch.zeros(sh)
+    ns = {"scratch_dict": scratch, "pretrained_weights": pretrained, "target_dict": {}, "print": lambda *a, **k: None}
+    exec(compile(ast.Module(body=fn + loop, type_ignores=[]), tool, "exec"), ns)
+    want = ns["target_dict"]
+    got = convert.add_control_keys(pretrained, cshapes)
+    assert set(got) == set(want)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+
+
 def test_state_dict_file_unwraps_nesting(tmp_path):
     sd = {"a": torch.arange(4.0)}
     p = str(tmp_path / "x.ckpt")
