@@ -15,9 +15,9 @@ What is deliberately different underneath (and why):
   * Models come from injectable factories (`pipe_factory`, `tile_factory`): there are no checkpoints and no network
     in this environment.  The default factories load local diffusers-format folders through `convert.py` and merge
     LoRA weights through `lora.py`, failing loudly when a path does not exist.
-  * BLIP2 captioning, reference-only control (`ref_image`, utils/stable_diffusion_reference.py) and textual inversion
-    are outside the hot path: `enable_auto_prompt` needs a user-supplied `captioner`,
-    `ref_image` raises NotImplementedError.
+  * BLIP2 captioning (`enable_auto_prompt`, `ref_auto_prompt`) and textual inversion are outside the hot path:
+    `enable_auto_prompt` needs a user-supplied `captioner`, `ref_auto_prompt` raises NotImplementedError.  Reference-only
+    control (`ref_image`, utils/stable_diffusion_reference.py) runs through `reference_only.py`.
   * UniPC (`:384, :418`) exists only inside diffusers: the pipelines keep their DDIM sampler.
 """
 import os
@@ -211,9 +211,14 @@ class EditAnythingLoraModel:
                 ref_prompt=None, ref_sam_scale=None, ref_inpaint_scale=None, ref_auto_prompt=False, ref_textinv=True,
                 ref_textinv_path=None, ref_scale=None, *, prompt_embeds=None, negative_prompt_embeds=None,
                 tile_prompt_embeds=None, tile_negative_prompt_embeds=None):
+        # reference-only control (editany_lora.py:705-745, 797-881): `ref_image` = {"image", "mask"}; the BLIP2 caption of
+        # the reference crop and textual-inversion embeddings (`ref_auto_prompt`, `ref_textinv`) need models that are not
+        # part of this path -- `ref_prompt` (or `ref_prompt_embeds` through the pipeline) carries the reference prompt
+        ref_mask = None
         if ref_image is not None:
-            raise NotImplementedError("reference-only control (utils/stable_diffusion_reference.py) is not on the hot "
-                                      "path (SURVEY.md section 8 row f4)")
+            if ref_auto_prompt:
+                raise NotImplementedError("ref_auto_prompt needs BLIP2 (outside SURVEY.md section 8): pass ref_prompt")
+            ref_mask, ref_image = ref_image["mask"], ref_image["image"]
         if condition_model is None or condition_model == "EditAnything":
             this_controlnet_path = self.default_controlnet_path
         else:
@@ -276,6 +281,13 @@ class EditAnythingLoraModel:
                 kw["controlnet_conditioning_scale_map"] = scale_map
             if isinstance(self.pipe, StableDiffusionControlNetInpaintMixingPipeline):     # :812-828
                 kw["alpha_weight"] = alpha_weight
+            elif ref_image is not None:                                                   # :855-881
+                ref_scales = [float(ref_sam_scale)] + ([float(ref_inpaint_scale)] if self.extra_inpaint else [])
+                kw.update(ref_image=ref_image, ref_mask=ref_mask, ref_prompt=ref_prompt,
+                          attention_auto_machine_weight=attention_auto_machine_weight,
+                          gn_auto_machine_weight=gn_auto_machine_weight, style_fidelity=style_fidelity,
+                          reference_attn=reference_attn, reference_adain=reference_adain,
+                          ref_controlnet_conditioning_scale=ref_scales, ref_scale=ref_scale)
             x_samples = self.pipe(image=img, mask_image=mask_image, prompt_embeds=pe, negative_prompt_embeds=ne,
                                   num_images_per_prompt=num_samples, num_inference_steps=ddim_steps,
                                   generator=generator, controlnet_conditioning_image=cond_images, height=H, width=W,

@@ -274,7 +274,12 @@ class StableDiffusionControlNetInpaintPipeline:
                  num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
                  cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
-                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None, **unused):
+                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None,
+                 ref_image=None, ref_mask=None, ref_controlnet_conditioning_scale=1.0, ref_prompt=None,
+                 ref_prompt_embeds=None, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0,
+                 style_fidelity=0.5, reference_attn=True, reference_adain=True, ref_scale=1.0, **unused):
+        """`ref_image` (+ `ref_mask`, `ref_prompt` or `ref_prompt_embeds`, ...): reference-only control,
+        …inpaint.py:1163-1182, 1307-1605 (reference_only.py).  Those calls run eagerly (no HIP graph)."""
         if controlnet_conditioning_image is None and "control_image" in unused:
             controlnet_conditioning_image = unused.pop("control_image")
         cond_images = controlnet_conditioning_image
@@ -350,6 +355,15 @@ class StableDiffusionControlNetInpaintPipeline:
                 keep = 1 - F.interpolate(msk, size=(h8, w8), mode="nearest")
                 keep = keep.repeat(n_img // keep.shape[0], 4, 1, 1).contiguous()
                 blend_mask = (1 - keep).contiguous()         # 1 where the sample is generated
+        ref_state = None
+        if ref_image is not None:
+            ref_state, ref_den, ref_lat, ref_noise = self._prepare_reference(
+                ref_image, ref_mask, ref_prompt, ref_prompt_embeds, ref_controlnet_conditioning_scale, hints, cond_images,
+                width, height, n_img, num_images_per_prompt, do_cfg, generator, lat.shape, msk if image is not None else None,
+                unet_in, dict(style_fidelity=style_fidelity, ref_scale=ref_scale,
+                              attention_auto_machine_weight=attention_auto_machine_weight,
+                              gn_auto_machine_weight=gn_auto_machine_weight, reference_attn=reference_attn,
+                              reference_adain=reference_adain), guess_mode)
         self._mark("inputs+vae_encode")
         self.denoiser.only_mid_control = False
         unipc = isinstance(sch, UniPCMultistepScheduler)
@@ -365,7 +379,7 @@ class StableDiffusionControlNetInpaintPipeline:
         # Control scales are baked into the captured launches, so they are part of the key; per-pixel scale maps are
         # per-call tensors -> such calls capture afresh.
         gkey = None
-        if self.use_graph and not step_noise and not in_loop_blend and \
+        if self.use_graph and not step_noise and not in_loop_blend and ref_state is None and \
                 all(not torch.is_tensor(v) for sc in per_net for v in sc):
             gkey = (type(sch).__name__, n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
                     tuple(tuple(h.shape) for h in hints), tuple(tuple(sc) for sc in per_net))
@@ -420,7 +434,17 @@ class StableDiffusionControlNetInpaintPipeline:
                 if step_noise else None
             blend_now = in_loop_blend and i < nsteps * alignment_ratio and i + 1 < nsteps
             st["blend_mask"] = blend_mask if blend_now else None
-            if gkey is not None or (self.use_graph and not step_noise and not in_loop_blend):
+            if ref_state is not None:
+                # …inpaint.py:1562-1605: the reference latents, noised to this step's level, go through ControlNet + UNet
+                # in write mode (features banked, output dropped); the real evaluation then reads the banks
+                a_t = float(sch.alphas_cumprod[int(timesteps[i])])
+                ref_xt = (a_t ** 0.5) * ref_lat + ((1.0 - a_t) ** 0.5) * ref_noise
+                ref_state.begin("write")
+                ref_den.eps(ref_xt, st["t"][:n_img])
+                ref_state.begin("read")
+                self._step(st)
+                ref_state.end()
+            elif gkey is not None or (self.use_graph and not step_noise and not in_loop_blend):
                 if graph is None:
                     graph = self._capture(st)
                     if gkey is not None:
@@ -447,6 +471,74 @@ class StableDiffusionControlNetInpaintPipeline:
         if not return_dict:
             return images, None
         return StableDiffusionPipelineOutput(images, None)
+
+    def _prepare_reference(self, ref_image, ref_mask, ref_prompt, ref_prompt_embeds, ref_scale_cn, hints, cond_images, width,
+                           height, n_img, nipp, do_cfg, generator, lat_shape, msk, unet_in, opts, guess_mode):
+        """Everything the reference prepares once per `ref_image` call (…inpaint.py:1307-1315, 1348-1358, 1398-1425,
+        1491-1534; prepare_ref_image / prepare_ref_latents stable_diffusion_reference.py:178-279): the reference prompt's
+        embedding (no CFG), the reference image as [-1, 1] tensor and as the LAST ControlNet's conditioning image (the
+        other nets keep the conditional half of theirs), its VAE latents, the noise it is re-noised with at every step, and
+        a second denoiser state over the same networks for the write pass."""
+        from .reference_only import ReferenceOnly
+        from .unet import ControlledDenoiser
+        if not self.controlnets:
+            raise ValueError("reference-only control patches the last ControlNet: the pipeline has none")
+        h8, w8 = height // 8, width // 8
+        if ref_prompt_embeds is None:
+            neg = ("longbody, lowres, bad anatomy, bad hands, missing fingers, extra digit, fewer digits, cropped, "
+                   "worst quality, low quality")
+            ref_embeds = self._encode_prompt(ref_prompt, nipp, False, neg, None, None)
+        else:
+            e = ref_prompt_embeds.to(self.device, torch.float32)
+            ref_embeds = e.repeat(1, nipp, 1).view(e.shape[0] * nipp, e.shape[1], -1)
+        if ref_embeds.shape[0] == 1 and n_img > 1:
+            ref_embeds = ref_embeds.expand(n_img, -1, -1).contiguous()
+        rmask = None
+        if ref_mask is not None:
+            rmask = F.interpolate(host.prepare_mask_image(ref_mask).float(), size=(h8, w8)).to(self.device)
+        else:
+            rmask = torch.ones(1, 1, h8, w8, device=self.device)
+        # prepare_ref_image: RGB, LANCZOS to (width, height), [-1, 1]; one image is repeated over the batch
+        rimg = ref_image
+        if not isinstance(rimg, torch.Tensor):
+            from PIL import Image as _PIL
+            ims = [rimg] if hasattr(rimg, "convert") else list(rimg)
+            if hasattr(ims[0], "convert"):
+                arr = np.concatenate([np.array(i.convert("RGB").resize((width, height), resample=_PIL.LANCZOS))[None] for i in ims], 0)
+                rimg = torch.from_numpy((arr.astype(np.float32) / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2)
+            else:
+                rimg = torch.cat(ims, dim=0)
+        rimg = rimg.float()
+        rimg = rimg.repeat_interleave(n_img if rimg.shape[0] == 1 else nipp, dim=0).to(self.device)
+        ref_hint = self._prepare_cond_image(ref_image, width, height, n_img, nipp, False)
+        ref_hints = [h[:h.shape[0] // 2] if do_cfg else h for h in hints]
+        ref_hints[-1] = ref_hint
+        # prepare_ref_latents: posterior sample from the call's generator (drawn after the inpaint latents, before the
+        # re-noising noise -- the reference's order), scaled; then `noise = randn_tensor(latents.shape, generator)` :1528-1534
+        g0 = generator if not isinstance(generator, list) else generator[0]
+        vnoise = randn_tensor((rimg.shape[0], 4, h8, w8), g0, self.device)
+        ref_lat = self.vae.encode(rimg, vnoise)
+        if ref_lat.shape[0] < n_img:
+            ref_lat = ref_lat.repeat(n_img // ref_lat.shape[0], 1, 1, 1)
+        ref_noise = randn_tensor(tuple(lat_shape), generator, self.device) if not isinstance(generator, list) else \
+            torch.cat([randn_tensor((1,) + tuple(lat_shape[1:]), g, self.device) for g in generator])
+        scales = ref_scale_cn if isinstance(ref_scale_cn, (list, tuple)) else [ref_scale_cn] * len(self.controlnets)
+        n_out = len(self.unet.plan["input"]) + 1
+        per_net = []
+        for sc in scales:
+            ramp = torch.logspace(-1, 0, n_out).tolist() if guess_mode else [1.0] * n_out
+            per_net.append([float(sc) * r for r in ramp])
+        den = ControlledDenoiser(self.unet, self.controlnets)
+        den.overlap = False
+        den.prepare(ref_embeds, ref_hints, per_net)
+        # the mask the AdaIN points restrict themselves to: `self.inpaint_mask = mask_image` after the pipeline's own
+        # latent-resolution conversion (4-channel UNet: 1 - mask, :1488-1489; 9-channel: the mask itself)
+        if msk is None:
+            imask = torch.ones(1, 1, h8, w8, device=self.device)
+        else:
+            imask = (1 - F.interpolate(msk[:1], size=(h8, w8), mode="nearest")) if unet_in == 4 else msk[:1]
+        state = ReferenceOnly(self.unet, self.controlnets[-1], n_img, do_cfg, rmask, imask, **opts)
+        return state, den, ref_lat.contiguous(), ref_noise
 
     def _mix_blend(self, lat, x_orig, gen_mask, a_next, alpha, renoise_kept, generator):
         """In place, with proper = sqrt(a) * x_orig + sqrt(1 - a) * fresh noise (scheduler.add_noise at the next timestep):

@@ -134,7 +134,9 @@ class _Attn:
         """Text K/V are step-invariant: [B, L, ctx] -> [B, L, 2*inner] once per call."""
         return ops.gemm(ctx16, self.wkv2)
 
-    def forward(self, x, kv, gn_in=None):
+    def forward(self, x, kv, gn_in=None, ref=None):
+        """ref: reference_only.ReferenceOnly when this block takes part in a reference-only pass -- attn1 is then
+        computed by it from the materialised norm1 output (banked / mixed, utils/stable_diffusion_reference.py:289-479)."""
         B, H, W, Cc = x.shape
         inner = self.inner
         M = B * H * W
@@ -142,7 +144,7 @@ class _Attn:
         xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False, stats=gn_in)
         # a norm -> Linear pair runs as ONE launch when it can: the producer of h leaves the row partials behind
         # (row_stats), the consumer's epilogue applies the LayerNorm algebraically (ops.gemm ln_fold)
-        fold = [ops.PROFILE is None and ops.ln_fold_ok(M, wf.shape[0], inner) for wf, _, _ in self.fold]
+        fold = [ref is None and ops.PROFILE is None and ops.ln_fold_ok(M, wf.shape[0], inner) for wf, _, _ in self.fold]
         st = [ops.row_stats_buffer(M, inner, x.device) if f else None for f in fold]
 
         def normed(h, i, w, b=None, act=ops.ACT_NONE):
@@ -152,9 +154,13 @@ class _Attn:
             return ops.ln_gemm(h, self.ln[i][0], self.ln[i][1], w, b, act=act)
 
         h = ops.gemm(xn, self.pin_w, self.pin_b, row_stats=st[0])
-        qkv = normed(h, 0, self.wqkv)
-        a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
-        h = ops.gemm(a, self.wo1, self.bo1, residual=h, row_stats=st[1])
+        if ref is not None:
+            n1 = ops.layernorm(h, self.ln[0][0], self.ln[0][1])
+            h = ops.add_f16(ref.self_attention(self, n1, (H, W)).contiguous(), h)
+        else:
+            qkv = normed(h, 0, self.wqkv)
+            a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
+            h = ops.gemm(a, self.wo1, self.bo1, residual=h, row_stats=st[1])
         q = normed(h, 1, self.wq2)
         a = ops.attention(q, kv[..., :inner], kv[..., inner:], self.heads, self.d)
         h = ops.gemm(a, self.wo2, self.bo2, residual=h, row_stats=st[2])
@@ -241,21 +247,26 @@ class _UNetBase:
         ctx16 = context.to(self.device, torch.float16).contiguous()
         return [a.project_context(ctx16) for a in self._attn]
 
+    ref = None        # reference_only.ReferenceOnly while a reference-only pass runs through this network
+
     def _run(self, mods, h, x2, emb_all, kvs, residual=None):
         stats = None      # GroupNorm statistics of h left behind by the launch that produced it (ResBlock -> transformer)
+        ref = self.ref
         for k, (kind, m) in enumerate(mods):
             if kind == "conv_in":
                 h = m.forward(h, residual=residual)
             elif kind == "res":
-                feeds_norm = k + 1 < len(mods) and mods[k + 1][0] == "attn"
-                if feeds_norm:
+                feeds_norm = ref is None and k + 1 < len(mods) and mods[k + 1][0] == "attn"
+                if ref is not None:
+                    h = ref.after_res(m, m.forward(h, x2, emb_all))      # AdaIN point of the attention-free levels
+                elif feeds_norm:
                     h, stats = m.forward(h, x2, emb_all, gn_out=True)
                 else:
                     h = m.forward(h, x2, emb_all)
                 x2 = None
                 continue
             elif kind == "attn":
-                h = m.forward(h, kvs[self._attn_index[id(m)]], gn_in=stats)
+                h = m.forward(h, kvs[self._attn_index[id(m)]], gn_in=stats, ref=ref if ref is not None and ref.wants_attn(m) else None)
             else:
                 h = m.forward(h)
             stats = None
@@ -288,6 +299,8 @@ class ControlledUnetModel(_UNetBase):
             h = self._run(mods, h, None, emb_all, kvs)
             hs.append(h)
         h = self._run(self.middle_block, h, None, emb_all, kvs)
+        if self.ref is not None:
+            h = self.ref.after_mid(self, h)
         return hs, h
 
     def decode(self, h, hs, emb_all, kvs):
@@ -337,7 +350,10 @@ class ControlNet(_UNetBase):
         for i, mods in enumerate(self.input_blocks):
             h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint if i == 0 else None)
             feats.append(h)
-        feats.append(self._run(self.middle_block, h, None, emb_all, kvs))
+        h = self._run(self.middle_block, h, None, emb_all, kvs)
+        if self.ref is not None:
+            h = self.ref.after_mid(self, h)
+        feats.append(h)
         return feats
 
     def add_features(self, feats, skips, mid, scales):
@@ -439,7 +455,7 @@ class ControlledDenoiser:
         code runs eagerly and inside the HIP-graph capture of a step."""
         B = x.shape[0]
         per_row = embs is not None and any(e.shape[0] != 1 for e in embs)
-        concurrent = self.overlap and ops.PROFILE is None
+        concurrent = self.overlap and ops.PROFILE is None and self.unet.ref is None     # reference-only passes: in order
         split = self.split if (concurrent and not per_row and B % self.split == 0 and B >= 2 * self.split) else 1
         n = B // split
         u = self.unet

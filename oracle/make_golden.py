@@ -360,6 +360,92 @@ def gen_case_kwargs(name, inp):
     return cns, kw
 
 
+REFONLY_CASES = {   # reference-only control: name -> extra kwargs of the inpaint call (two ControlNets, 4 DDIM steps)
+    "full": dict(),                                                            # reference_attn + reference_adain, style_fidelity 0.5
+    "attn_only": dict(reference_adain=False, style_fidelity=1.0, ref_scale=0.5),
+    "adain_only": dict(reference_attn=False, style_fidelity=0.0),
+    "partial_weights": dict(attention_auto_machine_weight=0.5, gn_auto_machine_weight=0.2, style_fidelity=0.3),
+}
+
+
+REFONLY_SIZE = 256     # 32 x 32 latents: the attention-free level is 4 x 4 (at 2 x 2 every spectrum is real and the
+#                        phase the frequency mix keeps degenerates to a sign that fp16 noise flips)
+
+
+def refonly_inputs():
+    S = REFONLY_SIZE
+    g = torch.Generator("cpu").manual_seed(23)
+    ref_img = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    ref_mask = torch.zeros(1, 1, S, S)
+    ref_mask[:, :, 0:S - 32, 0:S - 48] = 1.0
+    ref_embeds = torch.randn(1, 77, arch.TINY_UNET["context_dim"], generator=g) * 0.5
+    image = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    mask = torch.zeros(1, 1, S, S)
+    mask[:, :, S // 4:S - S // 8, S // 3:S - S // 16] = 1.0
+    hint = torch.rand(1, 3, S, S, generator=g)
+    hint2 = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    return dict(ref_img=ref_img, ref_mask=ref_mask, ref_embeds=ref_embeds, image=image, mask=mask, hint=hint, hint2=hint2)
+
+
+def refonly_case_kwargs(name, inp, rin):
+    """The call both the reference pipeline (`ref_prompt` str + stand-in embedding) and the product
+    (`ref_prompt_embeds`) receive, minus the reference-prompt argument."""
+    S = rin["image"].shape[-1]
+    kw = dict(prompt_embeds=inp["ctx"][:1], negative_prompt_embeds=inp["un_ctx"][:1], image=rin["image"].clone(),
+              mask_image=rin["mask"].clone(), num_inference_steps=4, guidance_scale=7.5, output_type="latent", height=S,
+              width=S, controlnet_conditioning_image=[rin["hint"].clone(), rin["hint2"].clone()], controlnet_conditioning_scale=[1.0, 0.6],
+              alignment_ratio=None, ref_image=rin["ref_img"].clone(), ref_mask=rin["ref_mask"].clone(),
+              ref_controlnet_conditioning_scale=[1.0, 0.6])
+    kw.update(REFONLY_CASES[name])
+    return kw
+
+
+def gen_reference_only():
+    """Reference-only control goldens: the reference's inpaint `__call__` with `ref_image`, its
+    StableDiffusionReferencePipeline base and every patched forward executed from source
+    (oracle/ref_reference_only.py) on the tiny networks."""
+    from oracle import ref_reference_only as rr
+    nets, inp, rin = pipe_nets(), pipe_inputs(), refonly_inputs()
+    out = {k: v.numpy() for k, v in rin.items()}
+    for name in REFONLY_CASES:
+        pipe = rr.inpaint_pipeline([nets["cn"], nets["cn2"]], nets["unet"], nets["vae"], rin["ref_embeds"])
+        kw = refonly_case_kwargs(name, inp, rin)
+        with torch.no_grad():
+            lat = pipe(ref_prompt="a photo", generator=torch.Generator("cpu").manual_seed(11), **kw).images
+        out["refonly_" + name] = lat.numpy()
+        # The frequency mix keeps only the PHASE of the live feature: spectral components near zero (at a 4 x 4 level four
+        # of sixteen are real, phase = sign) flip under a perturbation of fp16 size, and AdaIN divides by a 3..16-sample
+        # standard deviation.  How much of that the reference's own result shows: the same call with every feature that
+        # enters a mix perturbed by 2e-3 relative Gaussian noise (what the fp16 network delivers, measured 1.3e-3 .. 2.6e-3
+        # at those points) -- the product is held to a small multiple of this, not to the well-conditioned 1.5e-2.
+        g_ns = rr.namespace()["StableDiffusionReferencePipeline"].redefine_ref_model.__globals__
+        clean = g_ns["mix_ref_feature"]
+        gen = torch.Generator("cpu").manual_seed(1234)
+
+        def noisy(feature, bank, cfg=True, ref_scale=0.0, dim3=False):
+            rms = feature.float().pow(2).mean().sqrt()
+            feature = feature + 2e-3 * rms * torch.randn(feature.shape, generator=gen)
+            return clean(feature, bank, cfg=cfg, ref_scale=ref_scale, dim3=dim3)
+        g_ns["mix_ref_feature"] = noisy
+        try:
+            pipe2 = rr.inpaint_pipeline([nets["cn"], nets["cn2"]], nets["unet"], nets["vae"], rin["ref_embeds"])
+            with torch.no_grad():
+                lat2 = pipe2(ref_prompt="a photo", generator=torch.Generator("cpu").manual_seed(11), **refonly_case_kwargs(name, inp, rin)).images
+        finally:
+            g_ns["mix_ref_feature"] = clean
+        sens = float((lat2 - lat).norm() / lat.norm())
+        out["refonly_sens_" + name] = np.float32(sens)
+        print("reference-only", name, tuple(lat.shape), float(lat.abs().max()), "own sensitivity to 2e-3 feature noise: %.4f" % sens)
+    # how far the branch moves the result (the plain call on the same inputs), so a test cannot pass by ignoring it
+    pipe = rr.inpaint_pipeline([nets["cn"], nets["cn2"]], nets["unet"], nets["vae"], rin["ref_embeds"])
+    kw = refonly_case_kwargs("full", inp, rin)
+    for k in ("ref_image", "ref_mask", "ref_controlnet_conditioning_scale"):
+        kw.pop(k)
+    with torch.no_grad():
+        out["refonly_off"] = pipe(generator=torch.Generator("cpu").manual_seed(11), **kw).images.numpy()
+    np.savez_compressed(os.path.join(GOLD, "pipe_refonly.npz"), **out)
+
+
 def gen_pipeline():
     """Inpaint / generation pipeline goldens: the reference's OWN `__call__` code (oracle/ref_pipeline.py) on the tiny
     networks, 4 DDIM steps, CFG 7.5, seeded CPU generator; the restatement (oracle/pipeline_oracle.py) must agree."""
@@ -417,6 +503,9 @@ if __name__ == "__main__":
     if "--sam-boxes" in sys.argv:
         gen_sam_boxes()
         sys.exit(0)
+    if "--reference-only" in sys.argv:
+        gen_reference_only()
+        sys.exit(0)
     if "--pipeline" in sys.argv:        # only the pipeline goldens (the rest is unchanged since round 1)
         ref_import.load()
         gen_pipeline()
@@ -428,4 +517,5 @@ if __name__ == "__main__":
     print("VAE ..."); gen_vae(ns)
     print("host ..."); gen_host()
     print("pipelines (reference __call__ executed from source) ..."); gen_pipeline()
+    print("reference-only control ..."); gen_reference_only()
     print("golden vectors written to", GOLD)

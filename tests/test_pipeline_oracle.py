@@ -307,3 +307,52 @@ def test_lora_text_encoder_deltas_accumulate_over_files():
     _, te_ab = lora.merge_lora({}, [a, b])
     (k,) = te_ab.keys()
     assert torch.allclose(te_ab[k], te_a[k] + te_b[k])
+
+
+# ------------------------------------------------------------------------------------------------ reference-only control
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference not present")
+def test_reference_only_arithmetic_vs_reference_helpers_executed_from_source():
+    """reference_only.add_freq_feature / mix_norm_feature (NHWC) == the reference's add_freq_feature / mix_norm_feature
+    (utils/stable_diffusion_reference.py:57-94, 136-175, NCHW) executed from source: both forms of the bank argument the
+    patched forwards use (a list for the mid block, ONE tensor for the Down / Up blocks, whose `sum(bank) / len(bank)`
+    then averages over the batch rows), style-fidelity blend with the unconditional rows kept."""
+    from oracle import ref_reference_only as rr
+    from editanything_amd import reference_only as ro
+    h = rr.helpers()
+    g = torch.Generator().manual_seed(0)
+    B, Cc, H, W = 4, 8, 4, 6
+    x, r = torch.randn(B, Cc, H, W, generator=g), torch.randn(B, Cc, H, W, generator=g)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    for ratio in (1.0, 0.3):
+        want = h.add_freq_feature(r.clone(), x.clone(), ratio)
+        got = ro.add_freq_feature(nhwc(r), nhwc(x), ratio).permute(0, 3, 1, 2)
+        assert float((want - got).abs().max()) <= 1e-5
+    mask = torch.zeros(1, 1, 8, 12)
+    mask[:, :, 2:7, 1:9] = 1
+    sel = torch.nonzero(torch.nn.functional.interpolate(mask, scale_factor=0.5).reshape(-1) != 0).reshape(-1)
+    mean_b, var_b = torch.randn(B, Cc, 1, 1, generator=g), torch.rand(B, Cc, 1, 1, generator=g)
+    uc = torch.tensor([1, 1, 0, 0]).bool()
+    for sf in (0.0, 0.4, 1.0):
+        want = h.mix_norm_feature(x.clone(), mask, [mean_b], [var_b], True, sf, uc)
+        got = ro.mix_norm_feature(nhwc(x), sel, nhwc(mean_b), nhwc(var_b), True, sf, 2).permute(0, 3, 1, 2)
+        assert float((want - got).abs().max()) <= 1e-5
+        want = h.mix_norm_feature(x.clone(), mask, mean_b, var_b, True, sf, uc)          # the Down / Up block call form
+        got = ro.mix_norm_feature(nhwc(x), sel, nhwc(mean_b).mean(0, keepdim=True), nhwc(var_b).mean(0, keepdim=True), True, sf, 2)
+        assert float((want - got.permute(0, 3, 1, 2)).abs().max()) <= 1e-5
+    var, mean = ro.masked_stats(nhwc(x), sel)
+    mx = x[:, :, torch.nn.functional.interpolate(mask, scale_factor=0.5)[0, 0].bool()]
+    assert torch.allclose(mean[:, 0, 0], mx.mean(-1), atol=1e-6) and torch.allclose(var[:, 0, 0], mx.var(-1, correction=0), atol=1e-6)
+
+
+def test_reference_only_module_selection_levels():
+    """Which blocks are DownBlock2D / UpBlock2D (attention-free levels) and their gn weights, from the block plans."""
+    from editanything_amd import arch
+    from editanything_amd.reference_only import ReferenceOnly
+    for cfg in (arch.TINY_UNET, arch.SD21_UNET, arch.SD15_UNET):
+        plan = arch.unet_plan(cfg)
+        down = ReferenceOnly._levels(plan["input"], "down")
+        up = ReferenceOnly._levels(plan["output"], "up")
+        nlev = len(cfg["channel_mult"])
+        assert down[-1] == (nlev - 1, False) and all(a for l, a in down if l < nlev - 1)     # SD: only the deepest level
+        assert up[0] == (0, False) and up[-1][0] == nlev - 1 and all(a for l, a in up if l > 0)
+        assert [l for l, _ in down] == sorted(l for l, _ in down) and [l for l, _ in up] == sorted(l for l, _ in up)

@@ -252,8 +252,18 @@ def test_scale_map_and_explicit_mask_and_unsupported_branches():
     user = np.asarray(s["mask"])[:, :, 0] > 127
     assert bool((sm[0, 0].numpy()[user] == 0).all()) and bool((sm[0, 0].numpy()[~user] == 1).all())   # 1 - mask
     assert np.array_equal(np.asarray(call["mask_image"])[:, :, 0] > 0, explicit[:, :, 0] > 0)
+    # reference-only control: `ref_image` = {"image", "mask"} reaches the inpaint pipeline with the reference's keyword
+    # set (editany_lora.py:855-881); the BLIP2 caption of the reference crop is outside the path
+    ref = dict(image=Image.fromarray(np.full((128, 128, 3), 90, np.uint8)), mask=Image.fromarray(np.full((128, 128, 3), 255, np.uint8)))
+    m.process(s, enable_tile=False, ref_image=ref, ref_prompt="a cat", ref_sam_scale=0.7, ref_inpaint_scale=0.4, ref_textinv=False,
+              ref_scale=0.9, style_fidelity=0.3, reference_adain=False, **PROCESS_ARGS)
+    call = built[0].calls[-1]
+    assert call["ref_image"] is ref["image"] and call["ref_mask"] is ref["mask"] and call["ref_prompt"] == "a cat"
+    assert call["ref_controlnet_conditioning_scale"] == [0.7, 0.4][:len(call["controlnet_conditioning_scale"])]
+    assert call["style_fidelity"] == 0.3 and call["reference_adain"] is False and call["reference_attn"] is True
+    assert call["ref_scale"] == 0.9 and call["attention_auto_machine_weight"] == 1.0 and call["gn_auto_machine_weight"] == 1.0
     with pytest.raises(NotImplementedError):
-        m.process(s, enable_tile=False, ref_image=dict(image=None, mask=None), **PROCESS_ARGS)
+        m.process(s, enable_tile=False, ref_image=ref, ref_auto_prompt=True, **PROCESS_ARGS)
     with pytest.raises(ValueError):
         m.use_blip = True
         m.process(s, enable_tile=False, **dict(PROCESS_ARGS, enable_auto_prompt=True))
