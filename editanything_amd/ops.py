@@ -90,6 +90,14 @@ def _check_dev(*ts):
             raise RuntimeError("editanything_amd ops run on the MI355X only (tensor is on %s)" % t.device)
 
 
+def _dense(*ts):
+    """The NHWC entry points take raw pointers and assume dense row-major tensors: a permuted-stride tensor (e.g. the
+    result of torch.fft / .real, a channels-last view) would be read as garbage without any error -- refuse it."""
+    for t in ts:
+        if t is not None and not t.is_contiguous():
+            raise ValueError(f"editanything_amd ops need contiguous tensors, got strides {tuple(t.stride())} for shape {tuple(t.shape)}")
+
+
 def _epilogue(out, n_out, bias=None, act=ACT_NONE, scale=1.0, residual=None, rowvec=None, rows_per_group=1,
               row_scale=None, bias_per_row=False):
     e = L.Epilogue()
@@ -217,6 +225,7 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
     gn_groups > 0: the caller's next op is a GroupNorm over this output -- returns (out, stats) with stats =
     (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them."""
     _check_dev(x1, w)
+    _dense(x1, x2, x2_add, w, residual, out)
     s = _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout)
     cout = w.shape[0]
     if out is None:
@@ -243,6 +252,7 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
     """GroupNorm (+SiLU).  stats = (partials, nchunk) left behind by the contraction that produced x1 (conv2d / gemm
     `gn_groups=`): the normalise pass alone, no statistics pass."""
     _check_dev(x1, gamma)
+    _dense(x1, x2, x2_add, out)
     B = x1.shape[0]
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
@@ -274,6 +284,7 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
     normalise pass alone).  gn_out_groups > 0: the conv's epilogue leaves the statistics of ITS output for the next
     GroupNorm -- returns (out, stats-or-None).  Without either it is ONE C-ABI call (statistics, normalise, conv)."""
     _check_dev(x1, w)
+    _dense(x1, x2, x2_add, residual)
     if gn_in is not None or gn_out_groups:
         n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add, stats=gn_in)
         return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype,
@@ -296,6 +307,7 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
 
 def layernorm(x, gamma, beta, eps=1e-5):
     _check_dev(x, gamma)
+    _dense(x)
     Cc = x.shape[-1]
     M = x.numel() // Cc
     out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
