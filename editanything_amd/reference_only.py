@@ -120,7 +120,6 @@ class ReferenceOnly:
     @staticmethod
     def _levels(plan, end_kind):
         """(level, level has attention) per block of a plan; a block holding `end_kind` closes its level."""
-        out, lev = [], 0
         kinds = [[op[0] for op in blk] for blk in plan]
         # attention-ness is a property of the whole level
         bounds, start = [], 0

@@ -1,4 +1,5 @@
-"""Debug: reference-only product vs golden, per case, incl. distance to the plain result."""
+"""Reference-only control: product vs tests/golden/pipe_refonly.npz per case, with the distance to the plain result and
+the reference's own sensitivity beside it (GPU).   python tools/diag_refonly.py [case ...]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,14 +16,9 @@ tiny = dict(cn=ControlNet(n["cn"][1], n["cn"][0], DEV), cn2=ControlNet(n["cn2"][
 g = np.load(os.path.join("tests", "golden", "pipe_refonly.npz"))
 rin = {k: torch.from_numpy(g[k]) for k in ("ref_img", "ref_mask", "ref_embeds", "image", "mask", "hint", "hint2")}
 rel = lambda a, b: float((torch.as_tensor(a).float().cpu() - torch.as_tensor(b).float().cpu()).norm() / torch.as_tensor(b).float().norm())
-for name in [a for a in sys.argv[1:] if a != "none"] or ([] if "none" in sys.argv else ["full", "attn_only", "adain_only", "partial_weights"]):
+for name in sys.argv[1:] or list(mg.REFONLY_CASES):
     kw = mg.refonly_case_kwargs(name, mg.pipe_inputs(), rin)
     pipe = StableDiffusionControlNetInpaintPipeline(tiny["vae"], tiny["unet"], [tiny["cn"], tiny["cn2"]], DDIMScheduler(), device=DEV, use_graph=False)
     out = pipe(ref_prompt_embeds=rin["ref_embeds"], generator=torch.Generator("cpu").manual_seed(11), **kw).images
-    print(name, "vs golden", rel(out, g["refonly_" + name]), "vs plain golden", rel(out, g["refonly_off"]), "golden moved", rel(g["refonly_" + name], g["refonly_off"]))
-if os.environ.get("EA_REF_DEBUG"):
-    kw = mg.refonly_case_kwargs("adain_only", mg.pipe_inputs(), rin)
-    kw["num_inference_steps"] = 1
-    pipe = StableDiffusionControlNetInpaintPipeline(tiny["vae"], tiny["unet"], [tiny["cn"], tiny["cn2"]], DDIMScheduler(), device=DEV, use_graph=False)
-    out = pipe(ref_prompt_embeds=rin["ref_embeds"], generator=torch.Generator("cpu").manual_seed(11), **kw).images
-    print("out", float(out.abs().mean()))
+    print(name, "vs golden", rel(out, g["refonly_" + name]), "vs plain golden", rel(out, g["refonly_off"]), "golden moved", rel(g["refonly_" + name], g["refonly_off"]),
+          "reference's own sensitivity", float(g["refonly_sens_" + name]))
