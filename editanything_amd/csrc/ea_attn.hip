@@ -1075,6 +1075,42 @@ __global__ __launch_bounds__(256) void ea_relpos_kernel(RelposParams p) {
   *dst = acc;
 }
 
+// The same tables on the matrix pipe for the 64 x 64 token grid (SAM's global-attention blocks).  For a fixed query row
+// qh the outputs bias_h[(qh, qw)][kh] = q . Rh[qh - kh + 63] are a 64 x 64 x D product of that row's 64 queries with
+// 64 consecutive (descending) rows of the table; likewise bias_w for a fixed query column.  One workgroup per (query row
+// or column, axis, batch*head), one 32 x 32 output tile per wave, operands straight from global memory in MFMA fragment
+// order (no LDS); computed as out^T = R Q^T so a lane's four accumulators per register quad are four consecutive key
+// positions of ONE query: 16-byte stores into the [bh][q][S] tables.  (The one-thread-per-output kernel above took
+// 482 us per layer at ViT-H size: 5.4 GFLOP of scalar dot products for 134 MB of tables.)
+template <int D>
+__global__ __launch_bounds__(256) void ea_relpos_mfma_kernel(RelposParams p) {
+  constexpr int S = 64, NKS = D / 16;
+  static_assert(D % 16 == 0, "head dim");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int fix = blockIdx.x;              // qh (axis h) / qw (axis w)
+  const bool is_w = blockIdx.y != 0;
+  const int bh = blockIdx.z;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int tb = wave & 1, qb = wave >> 1;
+  const int qi = is_w ? (32 * qb + l31) * S + fix : fix * S + 32 * qb + l31;     // this lane's query (B operand column)
+  const f16* qv = p.q + b * p.q_sb + (long long)qi * p.q_sn + (long long)h * D;
+  const f16* rv = (is_w ? p.rel_w : p.rel_h) + (fix - (32 * tb + l31) + S - 1) * D;   // this lane's table row (A operand row)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    const f16x8 a = ea_ld8(rv + 16 * s + 8 * half);
+    const f16x8 q8 = ea_ld8(qv + 16 * s + 8 * half);
+    acc = ea_mfma_32x32x16(a, q8, acc);
+  }
+  float* dst = (is_w ? p.bias_w : p.bias_h) + ((long long)bh * (S * S) + qi) * S + 32 * tb + 4 * half;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+}
+
 }  // namespace
 
 extern "C" int ea_attention_f16(const void* q, const void* k, const void* v, void* out, int B, int H, int Nq,
@@ -1130,6 +1166,11 @@ extern "C" int ea_relpos_tables_f16(const void* q, int B, int H, int S, int D, l
   p.q = (const f16*)q; p.B = B; p.H = H; p.S = S; p.D = D; p.q_sb = q_sb; p.q_sn = q_sn;
   p.rel_h = (const f16*)rel_h; p.rel_w = (const f16*)rel_w; p.bias_h = bias_h; p.bias_w = bias_w;
   if (S > 256) return EA_ERR_BAD_SHAPE;          // N * 2S must fit 32 bits
+  if (S == 64 && (D == 64 || D == 80) && (((uintptr_t)bias_h | (uintptr_t)bias_w) & 15) == 0 && (((uintptr_t)rel_h | (uintptr_t)rel_w | (uintptr_t)q) & 15) == 0) {
+    auto mfn = D == 64 ? ea_relpos_mfma_kernel<64> : ea_relpos_mfma_kernel<80>;
+    EA_LAUNCH(mfn, dim3(64, 2, (unsigned)(B * H)), dim3(256), 0, stream, p);
+    return ea_launch_status();
+  }
   const int per_bh = S * S * 2 * S;
   auto kfn = ea_relpos_kernel;
   EA_LAUNCH(kfn, dim3((unsigned)((per_bh + 255) / 256), (unsigned)(B * H)), dim3(256), 0, stream, p);

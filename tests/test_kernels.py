@@ -709,6 +709,27 @@ def test_attention_sd21_shapes(kb, B, H, N, Nk, D):
     assert relerr(got[:, :512, :2], ref) < 3e-3
 
 
+@pytest.mark.parametrize("D,B,H", [(80, 1, 2), (64, 2, 1)])
+def test_relpos_tables_64x64_grid_matrix_pipe(kb, D, B, H):
+    """ea_relpos_tables_f16 at the 64 x 64 token grid (the MFMA kernel): bias_h[(qh, qw)][kh] = q . Rh[qh - kh + 63],
+    bias_w[(qh, qw)][kw] = q . Rw[qw - kw + 63] (segment_anything add_decomposed_rel_pos), fused-QKV strides."""
+    S = 64
+    N = S * S
+    qkv = f16(B, N, 3, H, D)
+    q = qkv[:, :, 0]
+    rel_h, rel_w = f16(2 * S - 1, D, scale=0.3), f16(2 * S - 1, D, scale=0.3)
+    bh, bw = kb.zeros((B * H, N, S), np.float32), kb.zeros((B * H, N, S), np.float32)
+    dq = kb.up(qkv)
+    assert kb.lib.ea_relpos_tables_f16(ptr(dq), B, H, S, D, N * 3 * H * D, 3 * H * D, ptr(rel_h), ptr(rel_w), ptr(bh), ptr(bw),
+                                       kb.stream) == 0
+    idx = (torch.arange(S)[:, None] - torch.arange(S)[None, :]) + (S - 1)
+    rq = t(np.ascontiguousarray(q)).permute(0, 2, 1, 3).reshape(B * H, S, S, D)
+    ref_h = torch.einsum("bhwc,hkc->bhwk", rq, t(rel_h)[idx]).reshape(B * H, N, S).numpy()
+    ref_w = torch.einsum("bhwc,wkc->bhwk", rq, t(rel_w)[idx]).reshape(B * H, N, S).numpy()
+    assert np.abs(kb.down(bh) - ref_h).max() <= 2e-3 * np.abs(ref_h).max()
+    assert np.abs(kb.down(bw) - ref_w).max() <= 2e-3 * np.abs(ref_w).max()
+
+
 def test_sam_global_attention_relpos_full(kb):
     _gpu_only(kb)
     S, D, B, H = 64, 80, 1, 2
