@@ -245,7 +245,7 @@ class StableDiffusionControlNetInpaintPipeline:
         x2 = torch.cat([lat] * 2) if st["cfg"] else lat
         if st["extra"] is not None:                               # 9-ch inpaint UNet: latents || mask || masked latents
             x2 = torch.cat([x2, st["extra"]], dim=1)
-        eps = self.denoiser.eps(x2, st["t"], embs=st.get("embs"))
+        eps = self.denoiser.eps(x2, st["t"], embs=st.get("embs"), cfg_halves=bool(st["cfg"]))
         if st["cfg"]:
             e_u, e_c = eps.chunk(2)
         else:

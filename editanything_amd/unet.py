@@ -20,6 +20,7 @@ MI355X-first data flow (not the reference's NCHW module tree):
   * all 22 (10) time-embedding projections of the ResBlocks are one GEMM per step.
 """
 import math
+import os
 
 import torch
 
@@ -134,18 +135,24 @@ class _Attn:
         """Text K/V are step-invariant: [B, L, ctx] -> [B, L, 2*inner] once per call."""
         return ops.gemm(ctx16, self.wkv2)
 
-    def forward(self, x, kv, gn_in=None, ref=None):
+    def forward(self, x, kv, gn_in=None, ref=None, dup_after_attn1=False):
         """ref: reference_only.ReferenceOnly when this block takes part in a reference-only pass -- attn1 is then
-        computed by it from the materialised norm1 output (banked / mixed, utils/stable_diffusion_reference.py:289-479)."""
+        computed by it from the materialised norm1 output (banked / mixed, utils/stable_diffusion_reference.py:289-479).
+        dup_after_attn1: x holds ONE copy of a batch whose two halves are identical up to here (the unconditional /
+        conditional halves of a classifier-free-guidance evaluation: same latents, same hint, same timestep -- only the
+        text differs, and the text first enters at attn2): norm, proj_in, norm1, self-attention and its residual run on
+        that copy, the rows are duplicated in front of the cross-attention, and the result has twice x's batch."""
         B, H, W, Cc = x.shape
         inner = self.inner
         M = B * H * W
+        M2 = 2 * M if dup_after_attn1 else M
         xt = x.view(B, H * W, Cc)
         xn = ops.groupnorm(xt, self.nw, self.nb, eps=1e-6, silu=False, stats=gn_in)
         # a norm -> Linear pair runs as ONE launch when it can: the producer of h leaves the row partials behind
         # (row_stats), the consumer's epilogue applies the LayerNorm algebraically (ops.gemm ln_fold)
-        fold = [ref is None and ops.PROFILE is None and ops.ln_fold_ok(M, wf.shape[0], inner) for wf, _, _ in self.fold]
-        st = [ops.row_stats_buffer(M, inner, x.device) if f else None for f in fold]
+        fold = [ref is None and ops.PROFILE is None and ops.ln_fold_ok(m, wf.shape[0], inner)
+                for m, (wf, _, _) in zip((M, M2, M2), self.fold)]
+        st = [ops.row_stats_buffer(m, inner, x.device) if f else None for m, f in zip((M, M, M2), fold)]
 
         def normed(h, i, w, b=None, act=ops.ACT_NONE):
             if fold[i]:
@@ -161,6 +168,10 @@ class _Attn:
             qkv = normed(h, 0, self.wqkv)
             a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
             h = ops.gemm(a, self.wo1, self.bo1, residual=h, row_stats=st[1])
+        if dup_after_attn1:
+            h, xt, B = torch.cat([h, h]), torch.cat([xt, xt]), 2 * B
+            if st[1] is not None:
+                st[1] = torch.cat([st[1], st[1]], dim=1)
         q = normed(h, 1, self.wq2)
         a = ops.attention(q, kv[..., :inner], kv[..., inner:], self.heads, self.d)
         h = ops.gemm(a, self.wo2, self.bo2, residual=h, row_stats=st[2])
@@ -249,7 +260,9 @@ class _UNetBase:
 
     ref = None        # reference_only.ReferenceOnly while a reference-only pass runs through this network
 
-    def _run(self, mods, h, x2, emb_all, kvs, residual=None):
+    def _run(self, mods, h, x2, emb_all, kvs, residual=None, dup=False):
+        """dup: h is one copy of a batch of two identical halves; the block's transformer duplicates it in front of
+        its cross-attention (_Attn.forward dup_after_attn1) and the result is the full batch."""
         stats = None      # GroupNorm statistics of h left behind by the launch that produced it (ResBlock -> transformer)
         ref = self.ref
         for k, (kind, m) in enumerate(mods):
@@ -266,11 +279,19 @@ class _UNetBase:
                 x2 = None
                 continue
             elif kind == "attn":
-                h = m.forward(h, kvs[self._attn_index[id(m)]], gn_in=stats, ref=ref if ref is not None and ref.wants_attn(m) else None)
+                h = m.forward(h, kvs[self._attn_index[id(m)]], gn_in=stats, ref=ref if ref is not None and ref.wants_attn(m) else None,
+                              dup_after_attn1=dup)
+                dup = False
             else:
                 h = m.forward(h)
             stats = None
         return h
+
+    def shares_cfg_prefix(self):
+        """True when the first block after conv_in is [ResBlock, SpatialTransformer] (every SD UNet / ControlNet): the
+        work in front of that transformer's cross-attention can be shared by the two halves of a CFG batch."""
+        blk = self.plan["input"]
+        return len(blk) > 1 and [op[0] for op in blk[0]] == ["conv_in"] and [op[0] for op in blk[1]] == ["res", "attn"]
 
     def _index_attn(self):
         self._attn_index = {id(a): i for i, a in enumerate(self._attn)}
@@ -292,11 +313,16 @@ class ControlledUnetModel(_UNetBase):
         self._finalize_emb()
         self._index_attn()
 
-    def encode(self, x_nhwc, emb_all, kvs):
+    def encode(self, x_nhwc, emb_all, kvs, shared=False):
+        """shared: x_nhwc is ONE copy of a CFG batch's identical halves (kvs / the result are full batch)."""
         hs = []
         h = x_nhwc
-        for mods in self.input_blocks:
-            h = self._run(mods, h, None, emb_all, kvs)
+        for i, mods in enumerate(self.input_blocks):
+            if shared and i == 0:
+                h = self._run(mods, h, None, emb_all, kvs)
+                hs.append(torch.cat([h, h]))
+                continue
+            h = self._run(mods, h, None, emb_all, kvs, dup=shared and i == 1)
             hs.append(h)
         h = self._run(self.middle_block, h, None, emb_all, kvs)
         if self.ref is not None:
@@ -344,11 +370,16 @@ class ControlNet(_UNetBase):
             h = ops.conv2d(h, w, b, stride=s, act=ops.ACT_SILU if i != 7 else ops.ACT_NONE)
         return h
 
-    def _features(self, x_nhwc, emb_all, kvs, guided_hint):
+    def _features(self, x_nhwc, emb_all, kvs, guided_hint, shared=False):
+        """shared: x_nhwc and guided_hint hold ONE copy of a CFG batch's identical halves."""
         feats = []
         h = x_nhwc
         for i, mods in enumerate(self.input_blocks):
-            h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint if i == 0 else None)
+            if shared and i == 0:
+                h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint)
+                feats.append(torch.cat([h, h]))
+                continue
+            h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint if i == 0 else None, dup=shared and i == 1)
             feats.append(h)
         h = self._run(self.middle_block, h, None, emb_all, kvs)
         if self.ref is not None:
@@ -365,11 +396,11 @@ class ControlNet(_UNetBase):
             else:
                 ops.conv2d(f, w, b, ksize=1, pad=0, scale=float(s), residual=tgt, out=tgt)
 
-    def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales):
+    def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales, shared=False):
         """Fused path: skips[i] += scales[i] * zero_conv_i(h_i); mid += scales[-1] * middle_block_out(h_mid)
         (cldm.py:300-303 + :338 + :34-41 in one epilogue per tensor).  `scales[i]` may be a float or a per-pixel
         fp32 row-scale tensor (ControlNetModel2 scale map, utils/stable_diffusion_controlnet.py:777-802)."""
-        feats = self._features(x_nhwc, emb_all, kvs, guided_hint)
+        feats = self._features(x_nhwc, emb_all, kvs, guided_hint, shared)
         targets = list(skips) + [mid]
         for f, (w, b), tgt, s in zip(feats, self.zero, targets, scales):
             if torch.is_tensor(s):
@@ -401,6 +432,7 @@ class ControlledDenoiser:
         # Measured at C2 (network batch 8): 2 groups 357 ms vs 1 group 336 ms per 20 evaluations -- halving M costs the
         # contraction kernels more than the extra overlap returns, so the default stays 1.
         self.split = 1
+        self.share_cfg_prefix = os.environ.get("EA_SHARE_CFG", "1") != "0"      # A/B switch (tools/): eps(cfg_halves=True)
         self._strm = []
 
     def static_state(self):
@@ -441,9 +473,17 @@ class ControlledDenoiser:
         to step i (`embs=`) instead of re-running five tiny GEMMs inside every step."""
         return [self.unet.time_embedding(timesteps)] + [cn.time_embedding(timesteps) for cn in self.controlnets]
 
-    def eps(self, x, timesteps, embs=None):
+    def eps(self, x, timesteps, embs=None, cfg_halves=False):
         """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32.  `embs`: optional precomputed
         `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch).
+
+        cfg_halves: the caller states that rows [0, B/2) and [B/2, B) of x, of every hint and of the timesteps are
+        IDENTICAL (a classifier-free-guidance batch `cat([latents] * 2)`: only the text differs).  Everything in front
+        of the first cross-attention -- conv_in (+ hint), the first ResBlock, the first transformer's norm / proj_in /
+        norm1 / self-attention, in the UNet and in every ControlNet -- is then computed on one copy and duplicated
+        (`_Attn.forward` dup_after_attn1): the reference evaluates it twice on the same numbers (cldm.py:22-45 on the
+        doubled batch of …inpaint.py:1540-1547).  Same outputs (to the rounding of a differently tiled launch); at SD2.1
+        64 x 64 that is 2 convolutions, 5 linears and the 4096-token self-attention per network at half the rows.
 
         Stream layout (`overlap`): the batch is cut into `split` contiguous row groups (the uncond / cond halves of a CFG
         batch) that run as independent evaluations, and inside each the ControlNet trunk runs beside the UNet encoder:
@@ -459,28 +499,32 @@ class ControlledDenoiser:
         split = self.split if (concurrent and not per_row and B % self.split == 0 and B >= 2 * self.split) else 1
         n = B // split
         u = self.unet
+        shared = bool(cfg_halves) and self.share_cfg_prefix and split == 1 and B % 2 == 0 and embs is not None and not per_row \
+            and u.ref is None and u.shares_cfg_prefix() and all(cn.shares_cfg_prefix() for cn in self.controlnets)
+        half = slice(0, B // 2)
         ctx = []
         for g in range(split):
             rows = slice(g * n, (g + 1) * n)
             xg, tg = x[rows], timesteps[rows]
-            c = dict(xin=u.to_nhwc(xg), emb_u=u.time_embedding(tg) if embs is None else embs[0],
+            c = dict(xin=u.to_nhwc(xg[half] if shared else xg), emb_u=u.time_embedding(tg) if embs is None else embs[0],
                      kv_u=[kv[rows] for kv in self.kv_u], jobs=[])
             for i, (cn, kv, gh, sc) in enumerate(zip(self.controlnets, self.kv_c, self.hints, self.control_scales)):
                 if gh is None:
                     continue
                 emb_c = cn.time_embedding(tg) if embs is None else embs[1 + i]
-                x_cn = c["xin"] if cn.cfg["in_channels"] == u.cfg["in_channels"] else cn.to_nhwc(xg[:, :cn.cfg["in_channels"]])
+                x_cn = c["xin"] if cn.cfg["in_channels"] == u.cfg["in_channels"] else \
+                    cn.to_nhwc((xg[half] if shared else xg)[:, :cn.cfg["in_channels"]])
                 if self.only_mid_control:
                     sc = [0.0] * (len(sc) - 1) + [sc[-1]]
                 per = [s.numel() // gh.shape[0] if torch.is_tensor(s) else 0 for s in sc]
                 sc = [s[rows.start * k:rows.stop * k] if torch.is_tensor(s) else s for s, k in zip(sc, per)]
-                c["jobs"].append((cn, x_cn, emb_c, [k[rows] for k in kv], gh[rows], sc))
+                c["jobs"].append((cn, x_cn, emb_c, [k[rows] for k in kv], gh[half] if shared else gh[rows], sc))
             ctx.append(c)
         if not concurrent:
             c = ctx[0]
-            hs, mid = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+            hs, mid = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared)
             for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]:
-                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc)
+                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared)
             return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         cur = torch.cuda.current_stream()
         streams = self._streams(split)
@@ -490,7 +534,7 @@ class ControlledDenoiser:
             if c["jobs"] and self.cn_overlap:
                 cn_s.wait_stream(cur)
                 with torch.cuda.stream(cn_s), ops.aux_workspace(2 * g + 1):
-                    c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+                    c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
             if g > 0:
                 enc_s.wait_stream(cur)
                 with torch.cuda.stream(enc_s), ops.aux_workspace(2 * g):
@@ -498,9 +542,9 @@ class ControlledDenoiser:
                     if c["jobs"] and not self.cn_overlap:
                         c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
         c = ctx[0]
-        c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+        c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared)
         if c["jobs"] and not self.cn_overlap:
-            c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+            c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
         for g in range(split):
             if g > 0:
                 cur.wait_stream(streams[g][0])

@@ -101,6 +101,31 @@ def test_inpaint_pipeline_decoded_image_vs_reference_golden(mg, gold, tiny):
     assert np.abs(np.asarray(pil[0]).astype(np.int32) - np.round(ref[0] * 255).astype(np.int32)).max() <= 6
 
 
+@pytest.mark.parametrize("nets", [["cn"], ["cn", "cn2"]])
+def test_shared_cfg_prefix_equals_the_doubled_batch(mg, tiny, nets):
+    """eps(cfg_halves=True): conv_in, the first ResBlock and the first transformer's self-attention computed on ONE copy
+    of the two identical halves of a CFG batch == the plain evaluation of the doubled batch (what the reference runs,
+    cldm.py:22-45 on `torch.cat([latents] * 2)`), to fp16 rounding of differently tiled launches."""
+    from editanything_amd.unet import ControlledDenoiser
+    inp = mg.pipe_inputs()
+    den = ControlledDenoiser(tiny["unet"], [tiny[c] for c in nets])
+    g = torch.Generator("cpu").manual_seed(5)
+    lat = torch.randn(2, 4, 16, 16, generator=g)
+    x = torch.cat([lat, lat]).to(DEV)
+    ctx = torch.cat([inp["un_ctx"], inp["ctx"]]).to(DEV)
+    hints = [torch.cat([h, h]).to(DEV) for h in ([inp["hint"]] if len(nets) == 1 else [inp["hint"], inp["hint2"].expand(2, -1, -1, -1)])]
+    t = torch.full((4,), 601, dtype=torch.long, device=DEV)
+    with torch.no_grad():
+        den.prepare(ctx, hints)
+        embs = [e[:1].clone() for e in den.time_embeddings(t[:1])]
+        a = den.eps(x, t, embs=embs, cfg_halves=True)
+        den.share_cfg_prefix = False
+        b = den.eps(x, t, embs=embs, cfg_halves=True)
+    assert den.unet.shares_cfg_prefix() and not torch.isnan(a).any()
+    assert rel_l2(a, b) <= 2e-3, rel_l2(a, b)
+    assert rel_l2(a[:2], a[2:]) > 1e-2          # the halves do differ (different text)
+
+
 @pytest.mark.parametrize("name", ["full", "attn_only", "adain_only", "partial_weights"])
 def test_reference_only_control_vs_reference_golden(mg, tiny, name):
     """`ref_image` (reference-only control, utils/stable_diffusion_reference.py + …inpaint.py:1307-1605): the product's
