@@ -210,7 +210,9 @@ def main():
                                f"{args.ddim_steps} DDIM steps, CFG 7.5 (network batch {2 * args.batch}), fp16, random-init weights; "
                                "inputs resident in HBM, control = synthetic SAM id map (SURVEY 8d: the mask decoder / AMG is not "
                                "part of the metric, the SAM embedding is computed and dropped), decoded images stay on the "
-                               "device (no D2H copy / PIL conversion in the timed region)",
+                               "device (no D2H copy / PIL conversion in the timed region); the part of an evaluation in "
+                               "front of the first cross-attention (conv_in, first ResBlock, first self-attention) is "
+                               "computed once for the two identical CFG halves",
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
