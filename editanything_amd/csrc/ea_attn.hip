@@ -508,15 +508,16 @@ __global__ __launch_bounds__(256, (D <= 64 && BIAS == 0 ? 3 : (D <= 80 && BIAS !
 //   (V(j-1) was last read in iteration j-1); then fetch K(j+3) / V(j+2) into the freed staging registers.
 // Everything else -- S^T = K Q^T operand swap, deferred rescale, fp16 probabilities with an fp32 dot2 row sum, V^T by
 // transpose reads -- is ea_attn_kernel's arithmetic, so the results are bit-identical to it.
-template <int D>
-__global__ __launch_bounds__(256, 2) void ea_attn_pipe_kernel(AttnParams p) {
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(AttnParams p) {
+  constexpr int NT = 64 * NW;                // threads; NW waves of 32 queries each
   static_assert(D % 32 == 0, "whole 32-channel blocks only");
   constexpr int NKS = D / 16, NDT = D / 32;
   constexpr int KROW = D * 2 + 16;
   constexpr int VROW = ((D * 2) % 256 == 64 || (D * 2) % 256 == 192) ? D * 2 : D * 2 + 64;
   constexpr int CH = D / 8;                  // 16-byte chunks per K / V row
-  constexpr int NLD = ATT_BK * CH / 256;     // chunks per thread per tile (every one of them real)
-  static_assert(ATT_BK * CH % 256 == 0, "tile chunks divide over the workgroup");
+  constexpr int NLD = ATT_BK * CH / NT;      // chunks per thread per tile (every one of them real)
+  static_assert(ATT_BK * CH % NT == 0, "tile chunks divide over the workgroup");
   constexpr int KSTAGE = ATT_BK * KROW, VSTAGE = ATT_BK * VROW;
   constexpr float LOG2E = 1.4426950408889634f;
   EA_SMEM(smem);
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void ea_attn_pipe_kernel(AttnParams p) {
   int qblk, bh;
   ea_attn_block(qblk, bh);
   const int b = bh / p.H, h = bh % p.H;
-  const int q_row = qblk * ATT_BQ + wave * 32 + l31;
+  const int q_row = qblk * (32 * NW) + wave * 32 + l31;
   const bool q_ok = q_row < p.Nq;
   const int q_ld = q_ok ? q_row : p.Nq - 1;
   const f16* qp = p.q + b * p.q_sb + (long long)h * D;
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void ea_attn_pipe_kernel(AttnParams p) {
   int klds[NLD], vlds[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int c = tid + 256 * i, row = c / CH, cc = c - row * CH;
+    const int c = tid + NT * i, row = c / CH, cc = c - row * CH;
     koff[i] = (unsigned)(row * p.k_sn + cc * 8);
     voff[i] = (unsigned)(row * p.v_sn + cc * 8);
     klds[i] = row * KROW + cc * 16;
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void ea_attn_pipe_kernel(AttnParams p) {
     } else {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         int row = c / CH;
         const int cc = c - row * CH;
         row = row < left ? row : left - 1;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void ea_attn_pipe_kernel(AttnParams p) {
     } else {
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + NT * i;
         int row = c / CH;
         const int cc = c - row * CH;
         row = row < left ? row : left - 1;
@@ -772,7 +773,9 @@ static int launch_attn(const AttnParams& p, void* stream) {
     // the pipelined loop pays a longer prologue: it wins from 4 key tiles up (self-attention), the in-order kernel
     // keeps the 77-token cross-attention (20.0 vs 22.1 us at Nq = 4096, 11.8 vs 14.2 us at Nq = 1024)
     if (p.Nk >= 4 * ATT_BK) {
-      auto pfn = ea_attn_pipe_kernel<D>;
+      // (NW = 8 -- 256 queries per workgroup, half the staging per wave -- measured +1..3 % where the workgroup count
+      // divides the chip evenly and -11 % at the level-0 shape, 640 workgroups on 256 CUs: profiles/r02_attention_counters.md)
+      auto pfn = ea_attn_pipe_kernel<D, 4>;
       ea_allow_big_lds(pfn, smem);
       EA_LAUNCH(pfn, grid, dim3(256), smem, stream, p);
       return ea_launch_status();

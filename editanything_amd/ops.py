@@ -149,6 +149,9 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
     ln_fold = (stats, colsum, eps): LayerNorm over a's rows folded into the contraction -- `w` carries gamma, `bias`
     carries W beta + b, `stats` are the partials the launch that produced `a` wrote."""
     _check_dev(a, w)
+    _dense(a, residual, out)
+    if w.stride(-1) != 1:
+        raise ValueError("gemm weight rows must be contiguous along K")
     K = a.shape[-1]
     M = a.numel() // K
     N = w.shape[0]
