@@ -102,6 +102,8 @@ static std::vector<Case> all_cases() {
   at(8, 8, 4096, 4096, 40, 0);  at(2, 5, 16384, 16384, 64, 0);
   // workgroup-count sweep around the level-0 shape (1280 workgroups = 5 per CU): 4 and 6 per CU
   at(8, 4, 4096, 4096, 64, 0);  at(8, 6, 4096, 4096, 64, 0);
+  // the shared CFG prefix runs the first level-0 self-attention on ONE copy of the batch: 640 workgroups
+  at(4, 5, 4096, 4096, 64, 0);
   // SAM ViT-H: global attention without the bias tables (4 images), fused window attention (100 windows)
   at(4, 16, 4096, 4096, 80, 0);
   wn(100, 16, 14, 80);
