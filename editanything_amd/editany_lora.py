@@ -219,6 +219,11 @@ class EditAnythingLoraModel:
             if ref_auto_prompt:
                 raise NotImplementedError("ref_auto_prompt needs BLIP2 (outside SURVEY.md section 8): pass ref_prompt")
             ref_mask, ref_image = ref_image["mask"], ref_image["image"]
+            if ref_textinv and ref_textinv_path:                     # :731-745: a missing / unloadable file is not an error there
+                try:
+                    self.pipe.load_textual_inversion(ref_textinv_path)
+                except Exception as exc:      # noqa: BLE001 -- the reference prints and goes on
+                    print("No textinvert embeddings found.", exc)
         if condition_model is None or condition_model == "EditAnything":
             this_controlnet_path = self.default_controlnet_path
         else:

@@ -76,6 +76,37 @@ class StableDiffusionControlNetInpaintPipeline:
     def enable_model_cpu_offload(self):
         pass
 
+    def load_textual_inversion(self, pretrained_model_name_or_path, token=None, **unused):
+        """diffusers `TextualInversionLoaderMixin.load_textual_inversion` as the reference uses it (one local embedding
+        file, editany_lora.py:733-735): a `.safetensors` / torch file holding either {token: vector(s)} or the
+        Automatic1111 layout {"string_to_param": {"*": vectors}, "name": token}.  The token (and `token_1 .. token_{n-1}`
+        for an n-vector embedding) is added to the tokenizer, the text encoder's embedding table is resized and the rows
+        are written.  Needs the transformers tokenizer / text-encoder pair (models.load_text_encoder)."""
+        if self.tokenizer is None or self.text_encoder is None or not hasattr(self.text_encoder, "resize_token_embeddings"):
+            raise ValueError("load_textual_inversion needs a tokenizer and a transformers text encoder on the pipeline")
+        from .convert import load_state_dict_file
+        sd = load_state_dict_file(pretrained_model_name_or_path)
+        if "string_to_param" in sd:
+            loaded_token, emb = sd.get("name", token), sd["string_to_param"]["*"]
+        else:
+            if len(sd) != 1:
+                raise ValueError("the embedding file must hold exactly one token")
+            (loaded_token, emb), = sd.items()
+        token = token if token is not None else loaded_token
+        emb = emb if emb.ndim > 1 else emb[None]
+        tokens = [token] + [f"{token}_{i}" for i in range(1, emb.shape[0])]
+        vocab = self.tokenizer.get_vocab()
+        if any(t in vocab for t in tokens):
+            raise ValueError(f"Token {token} already in tokenizer vocabulary. Please choose a different token name or remove it.")
+        self.tokenizer.add_tokens(tokens)
+        ids = self.tokenizer.convert_tokens_to_ids(tokens)
+        self.text_encoder.resize_token_embeddings(len(self.tokenizer))
+        table = self.text_encoder.get_input_embeddings().weight
+        with torch.no_grad():
+            for i, row in zip(ids, emb):
+                table[i] = row.to(table.dtype).to(table.device)
+        return tokens
+
     # ------------------------------------------------------------------ input handling
     def check_inputs(self, prompt, image, mask_image, cond_images, height, width, callback_steps, negative_prompt,
                      prompt_embeds, negative_prompt_embeds, cond_scale):

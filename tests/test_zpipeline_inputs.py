@@ -127,3 +127,58 @@ def test_call_front_half_with_bench_shaped_inputs():
     assert seen["vae_in"] == (4, 3, 512, 512) and seen["vae_noise"] == (4, 4, 64, 64)
     assert seen["embeds"] == (8, 77, 1024) and seen["hints"] == [(8, 3, 512, 512)]          # [uncond || cond]
     assert seen["scales"] == [[1.0] * 13]
+
+
+def test_load_textual_inversion_adds_tokens_and_rows(tmp_path):
+    """`pipe.load_textual_inversion(file)` (reference call editany_lora.py:733-735; diffusers TextualInversionLoaderMixin):
+    both file layouts, multi-vector embeddings -> token, token_1, ...; the rows land in the text encoder's table."""
+    import torch
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+
+    class Tok:
+        def __init__(self):
+            self.v = {"a": 0, "b": 1, "c": 2}
+
+        def get_vocab(self):
+            return dict(self.v)
+
+        def add_tokens(self, toks):
+            for t in toks:
+                self.v[t] = len(self.v)
+
+        def convert_tokens_to_ids(self, toks):
+            return [self.v[t] for t in toks]
+
+        def __len__(self):
+            return len(self.v)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Embedding(3, 8)
+
+        def get_input_embeddings(self):
+            return self.emb
+
+        def resize_token_embeddings(self, n):
+            new = torch.nn.Embedding(n, 8)
+            new.weight.data[:self.emb.num_embeddings] = self.emb.weight.data
+            self.emb = new
+
+    pipe = StableDiffusionControlNetInpaintPipeline.__new__(StableDiffusionControlNetInpaintPipeline)
+    pipe.tokenizer, pipe.text_encoder = Tok(), Enc()
+    old = pipe.text_encoder.emb.weight.data.clone()
+    v1 = torch.randn(2, 8)
+    torch.save({"string_to_param": {"*": v1}, "name": "<cat>"}, tmp_path / "a1111.pt")
+    assert pipe.load_textual_inversion(str(tmp_path / "a1111.pt")) == ["<cat>", "<cat>_1"]
+    w = pipe.text_encoder.get_input_embeddings().weight.data
+    assert torch.equal(w[:3], old) and torch.equal(w[3:5], v1) and len(pipe.tokenizer) == 5
+    v2 = torch.randn(8)
+    torch.save({"<dog>": v2}, tmp_path / "plain.bin")
+    assert pipe.load_textual_inversion(str(tmp_path / "plain.bin")) == ["<dog>"]
+    assert torch.equal(pipe.text_encoder.get_input_embeddings().weight.data[5], v2)
+    with pytest.raises(ValueError):
+        pipe.load_textual_inversion(str(tmp_path / "plain.bin"))          # token already there
+    pipe.tokenizer = None
+    with pytest.raises(ValueError):
+        pipe.load_textual_inversion(str(tmp_path / "plain.bin"))
