@@ -107,6 +107,9 @@ static std::vector<Case> all_cases() {
   cv(8, 64, 320, 0, 320, 3, 1, 0, 1, 0);  cv(8, 64, 320, 0, 320, 3, 1, 0, 0, 1);
   cv(8, 32, 640, 0, 640, 3, 1, 0, 1, 0);  cv(8, 32, 640, 0, 640, 3, 1, 0, 0, 1);
   cv(8, 16, 1280, 0, 1280, 3, 1, 0, 1, 0);
+  // the shared CFG prefix runs the first level-0 ResBlock / transformer projections on ONE copy of the batch (B = 4)
+  cv(4, 64, 320, 0, 320, 3, 1, 0, 1, 0);  cv(4, 64, 320, 0, 320, 3, 1, 0, 0, 1);
+  g(16384, 320, 320, 0, 1);  g(16384, 960, 320, 0, 0);
   // SAM ViT-H linears (4 images: 16384 tokens / 19600 window tokens) and VAE decoder convs (batch 4)
   g(16384, 3840, 1280, 0, 0); g(16384, 1280, 1280, 0, 1); g(16384, 5120, 1280, 2, 0); g(16384, 1280, 5120, 0, 1);
   cv(4, 256, 256, 0, 256, 3, 1, 0);   cv(4, 512, 128, 0, 128, 3, 1, 0);
