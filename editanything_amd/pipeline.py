@@ -310,7 +310,8 @@ class StableDiffusionControlNetInpaintPipeline:
                  ref_prompt_embeds=None, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0,
                  style_fidelity=0.5, reference_attn=True, reference_adain=True, ref_scale=1.0, **unused):
         """`ref_image` (+ `ref_mask`, `ref_prompt` or `ref_prompt_embeds`, ...): reference-only control,
-        …inpaint.py:1163-1182, 1307-1605 (reference_only.py).  Those calls run eagerly (no HIP graph)."""
+        …inpaint.py:1163-1182, 1307-1605 (reference_only.py).  Write pass + read pass + sampler step are captured as one
+        HIP graph per call (not cached across calls: banks, masks and module selection are per-call state)."""
         if controlnet_conditioning_image is None and "control_image" in unused:
             controlnet_conditioning_image = unused.pop("control_image")
         cond_images = controlnet_conditioning_image
@@ -395,6 +396,8 @@ class StableDiffusionControlNetInpaintPipeline:
                               attention_auto_machine_weight=attention_auto_machine_weight,
                               gn_auto_machine_weight=gn_auto_machine_weight, reference_attn=reference_attn,
                               reference_adain=reference_adain), guess_mode)
+            ref_ctx = dict(state=ref_state, den=ref_den, lat=ref_lat, noise=ref_noise, n_img=n_img, graph=None,
+                           coef=torch.zeros(2, dtype=torch.float32, device=self.device))
         self._mark("inputs+vae_encode")
         self.denoiser.only_mid_control = False
         unipc = isinstance(sch, UniPCMultistepScheduler)
@@ -467,14 +470,17 @@ class StableDiffusionControlNetInpaintPipeline:
             st["blend_mask"] = blend_mask if blend_now else None
             if ref_state is not None:
                 # …inpaint.py:1562-1605: the reference latents, noised to this step's level, go through ControlNet + UNet
-                # in write mode (features banked, output dropped); the real evaluation then reads the banks
+                # in write mode (features banked, output dropped); the real evaluation then reads the banks.  Both
+                # passes + the sampler step are ONE captured graph per call (the banks, masks and module selection
+                # are per-call state, so it is not cached across calls); the noise level comes from a static tensor.
                 a_t = float(sch.alphas_cumprod[int(timesteps[i])])
-                ref_xt = (a_t ** 0.5) * ref_lat + ((1.0 - a_t) ** 0.5) * ref_noise
-                ref_state.begin("write")
-                ref_den.eps(ref_xt, st["t"][:n_img])
-                ref_state.begin("read")
-                self._step(st)
-                ref_state.end()
+                ref_ctx["coef"].copy_(torch.tensor([a_t ** 0.5, (1.0 - a_t) ** 0.5], dtype=torch.float32))
+                if self.use_graph and not step_noise and not in_loop_blend:
+                    if ref_ctx["graph"] is None:
+                        ref_ctx["graph"] = self._capture(st, ref_ctx)
+                    ref_ctx["graph"].replay()
+                else:
+                    self._ref_step(st, ref_ctx)
             elif gkey is not None or (self.use_graph and not step_noise and not in_loop_blend):
                 if graph is None:
                     graph = self._capture(st)
@@ -587,19 +593,38 @@ class StableDiffusionControlNetInpaintPipeline:
                           mask=gen_mask, alt=alt)
         lat.copy_(out)
 
-    def _capture(self, st):
-        """Warm up once on a side stream (restoring the latents), then capture ONE step into a HIP graph."""
+    def _ref_step(self, st, ref):
+        """One denoising step under reference-only control: write pass over the noised reference latents, then the real
+        step reading the banks (…inpaint.py:1562-1605)."""
+        ref_xt = ref["coef"][0] * ref["lat"] + ref["coef"][1] * ref["noise"]
+        ref["state"].begin("write")
+        ref["den"].eps(ref_xt, st["t"][:ref["n_img"]])
+        ref["state"].begin("read")
+        self._step(st)
+        ref["state"].end()
+
+    def _capture(self, st, ref=None):
+        """Warm up once on a side stream (restoring the latents), then capture ONE step into a HIP graph.  The warm-up
+        also fills the per-call caches a capture could not (mask index lists, FFT plans)."""
+        step = (lambda: self._ref_step(st, ref)) if ref is not None else (lambda: self._step(st))
         saved = st["lat"].clone()
+        unipc_saved = {k: v.clone() for k, v in st["unipc"].items()} if st.get("unipc") is not None else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._step(st)
+            step()
         torch.cuda.current_stream().wait_stream(s)
         st["lat"].copy_(saved)
+        if unipc_saved is not None:                 # the multistep history the warm-up pushed
+            for k, v in unipc_saved.items():
+                st["unipc"][k].copy_(v)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._step(st)
+            step()
         st["lat"].copy_(saved)
+        if unipc_saved is not None:
+            for k, v in unipc_saved.items():
+                st["unipc"][k].copy_(v)
         return g
 
     def _level_sizes(self, height, width):

@@ -161,6 +161,21 @@ def test_reference_only_control_vs_reference_golden(mg, tiny, name):
     assert rel_l2(plain, off) <= 1.5e-2
 
 
+def test_reference_only_graph_replay_equals_eager(mg, tiny):
+    """The reference-only step (write pass + read pass + sampler step) captured as one graph per call == the same
+    launches issued eagerly."""
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+    g = np.load(os.path.join(GOLD, "pipe_refonly.npz"))
+    rin = {k: torch.from_numpy(g[k]) for k in ("ref_img", "ref_mask", "ref_embeds", "image", "mask", "hint", "hint2")}
+    outs = []
+    for graph in (False, True):
+        kw = mg.refonly_case_kwargs("full", mg.pipe_inputs(), rin)
+        pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, "unet", ["cn", "cn2"], graph)
+        outs.append(pipe(ref_prompt_embeds=rin["ref_embeds"], generator=torch.Generator("cpu").manual_seed(11), **kw).images)
+    assert not torch.isnan(torch.as_tensor(outs[1])).any()
+    assert rel_l2(outs[1], outs[0]) <= 1e-3, rel_l2(outs[1], outs[0])
+
+
 @pytest.mark.parametrize("name", ["mix_a05", "mix_a02_smap"])
 def test_mixing_pipeline_vs_reference_golden(mg, gold, tiny, name):
     """StableDiffusionControlNetInpaintMixingPipeline (…inpaint.py:1707-2088; editany_lora.py's tile refinement uses it):
