@@ -496,35 +496,72 @@ __global__ __launch_bounds__(256, (D <= 64 && BIAS == 0 ? 3 : (D <= 80 && BIAS !
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Software-pipelined flash loop for the bias-free head dims that are whole 32-channel blocks (the UNet's d = 64).
-// ea_attn_kernel runs a tile as QK^T -> softmax -> PV in one wave, in order: while the wave converts its 32 scores per
-// lane (80 VALU issues, the exponentials at half rate) the matrix pipe has nothing of this wave's to run, and the
-// counters say the co-resident waves do not fill it (MFMA busy 37 %, VALU busy 59 % of the kernel's cycles -- round-2
-// profiles/r02_attention_counters.md).  Here each iteration issues the NEXT tile's score MFMAs between this
-// tile's softmax instructions and this tile's PV MFMAs between the next tile's max reduction, so one wave keeps both
-// pipes busy.  The K ring therefore runs one tile ahead of the V ring (iteration j reads K(j+1) and V(j)); both are
-// two deep and one workgroup barrier per tile still orders every hand-off:
-//   end of iteration j: store K(j+2) -> kring[j & 1] (K(j) was last read in iteration j-1), V(j+1) -> vring[(j+1) & 1]
-//   (V(j-1) was last read in iteration j-1); then fetch K(j+3) / V(j+2) into the freed staging registers.
-// Everything else -- S^T = K Q^T operand swap, deferred rescale, fp16 probabilities with an fp32 dot2 row sum, V^T by
-// transpose reads -- is ea_attn_kernel's arithmetic, so the results are bit-identical to it.
-template <int D, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(AttnParams p) {
-  constexpr int NT = 64 * NW;                // threads; NW waves of 32 queries each
-  static_assert(D % 32 == 0, "whole 32-channel blocks only");
-  constexpr int NKS = D / 16, NDT = D / 32;
-  constexpr int KROW = D * 2 + 16;
-  constexpr int VROW = ((D * 2) % 256 == 64 || (D * 2) % 256 == 192) ? D * 2 : D * 2 + 64;
-  constexpr int CH = D / 8;                  // 16-byte chunks per K / V row
-  constexpr int NLD = ATT_BK * CH / NT;      // chunks per thread per tile (every one of them real)
-  static_assert(ATT_BK * CH % NT == 0, "tile chunks divide over the workgroup");
-  constexpr int KSTAGE = ATT_BK * KROW, VSTAGE = ATT_BK * VROW;
+// Software-pipelined flash loop with LDS-DMA staging for the UNet's self-attention (d = 64, no bias, >= 4 key tiles).
+// ea_attn_kernel runs a tile as QK^T -> softmax -> PV in one wave, in order.  Here each iteration issues the NEXT tile's
+// score MFMAs ahead of this tile's softmax and this tile's PV MFMAs ahead of the next tile's max reduction, so the K
+// ring runs one tile ahead of the V ring (iteration j reads K(j+1) and V(j)).  Everything else -- S^T = K Q^T operand
+// swap, deferred rescale, fp16 probabilities with an fp32 dot2 row sum, V^T by transpose reads -- is ea_attn_kernel's
+// arithmetic, so the results are bit-identical to it.
+// Staging: a K / V tile goes global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB = 8 rows of 128 bytes per wave
+// instruction): no staging registers, no ds_write, no vmcnt(0) in front of one.  (Round 2 first shipped this loop with
+// global -> VGPR -> LDS staging; the counters showed it WAITING on that chain -- 40 % of a wave's life in s_waitcnt /
+// s_barrier, profiles/r02_attention_counters.md -- and the DMA form measured +2.5..3.4 % in the same call, bit-identical.)
+// The rings are three deep, so a tile is requested TWO iterations before its first read and the end-of-iteration wait is
+// a counted vmcnt: the newest requests stay in flight across the barrier.
+// The DMA writes lane-linear, so rows are 128 bytes unpadded and the bank spread comes from an XOR of the 16-byte chunk
+// index applied on the SOURCE address (which chunk a lane fetches) and again on the fragment reads:
+//   K (ds_read_b128, 32 consecutive rows per half wave):   chunk ^ ((row >> 1) & 7)   -- conflict-free per 16 lanes
+//   V (ds_read_b64_tr_b16, 8 rows x 64 bytes per read):    chunk ^ (((row >> 1) & 1) << 2)
+// The V form only flips the 64-byte half, so it commutes with the row immediates (multiples of 8) the transpose reads
+// use; the two 32-channel blocks get one address register each.  Rows past Nk in the ragged last tile are fetched as
+// zeros (offset past the descriptor's range); their scores are masked to -inf, their probabilities are exactly 0.
+#ifdef EA_EMU
+struct AttnRsrc { const char* base; unsigned limit; };
+__device__ __forceinline__ AttnRsrc attn_make_rsrc(const void* p, unsigned bytes) { return AttnRsrc{(const char*)p, bytes}; }
+__device__ __forceinline__ void attn_dma16(AttnRsrc r, unsigned voff, unsigned soff, char* lds_base) {
+  char* dst = lds_base + 16 * ea_emu::lane_id();
+  if (voff >= r.limit) memset(dst, 0, 16);
+  else memcpy(dst, r.base + voff + soff, 16);
+}
+template <int N> __device__ __forceinline__ void attn_wait_dma() {}
+__device__ __forceinline__ void attn_barrier() { __syncthreads(); }
+#else
+typedef __amdgpu_buffer_rsrc_t AttnRsrc;
+__device__ __forceinline__ AttnRsrc attn_make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void attn_dma16(AttnRsrc r, unsigned voff, unsigned soff, char* lds_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 16, voff, soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void attn_wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// never __syncthreads() in this loop: its fence drains vmcnt to 0
+__device__ __forceinline__ void attn_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+#endif
+constexpr unsigned ATT_OOB = 0x80000000u;     // a byte offset past every buffer's num_records: the lane gets zeros
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
+  constexpr int D = 64, NKS = D / 16, NDT = D / 32;
+  constexpr int ROWB = 128;                          // LDS bytes per K / V row (unpadded: the DMA writes lane-linear)
+  constexpr int STAGE = ATT_BK * ROWB;               // 8 KiB per tile and operand
+  constexpr int RING = 3;
+  constexpr int NINS = STAGE / 1024 / NW;            // DMA instructions per wave, tile and operand
+  static_assert(STAGE % (1024 * NW) == 0, "whole 1-KiB pieces per wave");
   constexpr float LOG2E = 1.4426950408889634f;
   EA_SMEM(smem);
   char* const kring = smem;
-  char* const vring = smem + 2 * KSTAGE;
+  char* const vring = smem + RING * STAGE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+#ifdef EA_EMU
+  const int wave = tid >> 6;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
   const int half = lane >> 5, l31 = lane & 31;
   int qblk, bh;
   ea_attn_block(qblk, bh);
@@ -549,69 +586,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(
   const float sc2 = p.scale * LOG2E;
   const int nkt = (p.Nk + ATT_BK - 1) / ATT_BK, nfull = p.Nk / ATT_BK;
 
-  // staging: wave-uniform tile base + a loop-invariant 32-bit element offset per thread (one global_load with an SGPR
-  // base per chunk; no per-load 64-bit row * stride product, no predicates)
-  unsigned koff[NLD], voff[NLD];
-  int klds[NLD], vlds[NLD];
+  // staging: piece g = wave * NINS + i covers rows [8g, 8g + 8); lane -> row 8g + (lane >> 3), LDS chunk slot lane & 7,
+  // which holds the row's global chunk slot ^ swizzle(row)
+  const AttnRsrc rk = attn_make_rsrc(kp, (unsigned)(((long long)(p.Nk - 1) * p.k_sn + D) * 2));
+  const AttnRsrc rv = attn_make_rsrc(vp, (unsigned)(((long long)(p.Nk - 1) * p.v_sn + D) * 2));
+  unsigned koff[NINS], voff[NINS];
+  int srow[NINS];
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int c = tid + NT * i, row = c / CH, cc = c - row * CH;
-    koff[i] = (unsigned)(row * p.k_sn + cc * 8);
-    voff[i] = (unsigned)(row * p.v_sn + cc * 8);
-    klds[i] = row * KROW + cc * 16;
-    vlds[i] = row * VROW + cc * 16;
+  for (int i = 0; i < NINS; ++i) {
+    const int row = (wave * NINS + i) * 8 + (lane >> 3), slot = lane & 7;
+    srow[i] = row;
+    koff[i] = (unsigned)(row * p.k_sn + ((slot ^ ((row >> 1) & 7)) * 8)) * 2u;
+    voff[i] = (unsigned)(row * p.v_sn + ((slot ^ (((row >> 1) & 1) << 2)) * 8)) * 2u;
   }
-  f16x8 kreg[NLD], vreg[NLD];
-  // rows past Nk in the ragged last tile re-read the last key: their scores are masked to -inf, so their
-  // probabilities are exactly 0 and the duplicated V rows contribute nothing
-  auto k_load = [&](int t) {
+  auto k_issue = [&](int t, int slot) {
+    char* dst = kring + slot * STAGE + wave * NINS * 1024;
+    const unsigned soff = (unsigned)((long long)t * ATT_BK * p.k_sn * 2);
     const int left = p.Nk - t * ATT_BK;
-    const f16* tb = kp + (long long)t * ATT_BK * p.k_sn;
-    if (left >= ATT_BK) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) kreg[i] = ea_ld8(tb + koff[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int c = tid + NT * i;
-        int row = c / CH;
-        const int cc = c - row * CH;
-        row = row < left ? row : left - 1;
-        kreg[i] = ea_ld8(tb + (unsigned)(row * p.k_sn + cc * 8));
-      }
-    }
+    for (int i = 0; i < NINS; ++i) attn_dma16(rk, (left >= ATT_BK || srow[i] < left) ? koff[i] : ATT_OOB, soff, dst + i * 1024);
   };
-  auto v_load = [&](int t) {
+  auto v_issue = [&](int t, int slot) {
+    char* dst = vring + slot * STAGE + wave * NINS * 1024;
+    const unsigned soff = (unsigned)((long long)t * ATT_BK * p.v_sn * 2);
     const int left = p.Nk - t * ATT_BK;
-    const f16* tb = vp + (long long)t * ATT_BK * p.v_sn;
-    if (left >= ATT_BK) {
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) vreg[i] = ea_ld8(tb + voff[i]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int c = tid + NT * i;
-        int row = c / CH;
-        const int cc = c - row * CH;
-        row = row < left ? row : left - 1;
-        vreg[i] = ea_ld8(tb + (unsigned)(row * p.v_sn + cc * 8));
-      }
-    }
-  };
-  auto k_store = [&](int t) {
-    char* ks = kring + (t & 1) * KSTAGE;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f16x8*>(ks + klds[i]) = kreg[i];
-  };
-  auto v_store = [&](int t) {
-    char* vs = vring + (t & 1) * VSTAGE;
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f16x8*>(vs + vlds[i]) = vreg[i];
+    for (int i = 0; i < NINS; ++i) attn_dma16(rv, (left >= ATT_BK || srow[i] < left) ? voff[i] : ATT_OOB, soff, dst + i * 1024);
   };
 
-  // S^T = K Q^T of tile t: two 32-key score tiles, their MFMA chains interleaved
-  auto qk = [&](int t, f32x16 (&sc)[2]) {
-    const char* ks = kring + (t & 1) * KSTAGE + l31 * KROW + half * 16;
+  // fragment addresses inside a stage.  K: row 32u + l31 (u adds an immediate), chunk 2s + half; the swizzle term of a
+  // row does not depend on u.  V^T: row 4 * half + ((lane & 15) >> 2) (+ 16 tu, + 8: immediates), chunk 4e + cl.
+  int kfo[NKS];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) kfo[s] = l31 * ROWB + (((2 * s + half) ^ ((l31 >> 1) & 7)) << 4);
+  const int vrow0 = 4 * half + ((lane & 15) >> 2);
+  const int vcl = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1);
+  int vfo[NDT];
+#pragma unroll
+  for (int e = 0; e < NDT; ++e) vfo[e] = vrow0 * ROWB + (((4 * e + vcl) ^ (((vrow0 >> 1) & 1) << 2)) << 4) + 8 * (lane & 1);
+
+  auto qk = [&](int slot, f32x16 (&sc)[2]) {
+    const char* ks = kring + slot * STAGE;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -620,11 +635,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const f16x8 a = *reinterpret_cast<const f16x8*>(ks + 32 * u * KROW + 32 * s);
+        const f16x8 a = *reinterpret_cast<const f16x8*>(ks + kfo[s] + 32 * u * ROWB);
         sc[u] = ea_mfma_32x32x16(a, qf[s], sc[u]);
       }
   };
-  // running max of tile t's raw scores (ragged tile: keys >= Nk become -inf first) and the deferred rescale
   auto advance_max = [&](int t, f32x16 (&sc)[2], auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     float mx = -INFINITY;
@@ -655,23 +669,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(
     }
     m_use = (m_run == -INFINITY) ? 0.0f : m_run;
   };
-  const int vt_off = (4 * half + ((lane & 15) >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-  // one iteration: tile j's softmax and PV, with tile j+1's scores and max underneath.  NEXT: 0 no next tile,
-  // 1 a full one, 2 the ragged last one.
-  auto iter = [&](int j, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto next_tag) {
+  // iteration j: requests K(j+3) / V(j+2), reads K(j+1) (ring slot s1) and V(j) (slot s0); s0 = j % 3, s1 = (j+1) % 3,
+  // s2 = (j+2) % 3.  K(j+3) goes to K slot s0 (K(j), last read in iteration j-1), V(j+2) to V slot s2 (V(j-1), ditto).
+  auto iter = [&](int j, int s0, int s1, int s2, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto next_tag) {
     constexpr int NEXT = decltype(next_tag)::value;
-    const char* vbase = vring + (j & 1) * VSTAGE + vt_off;
+    const bool k_req = j + 3 < nkt, v_req = j + 2 < nkt;
+    if (k_req) k_issue(j + 3, s0);
+    if (v_req) v_issue(j + 2, s2);
+    const char* vb = vring + s0 * STAGE;
     f16x4 vlo[NDT][4], vhi[NDT][4];
-    ea_static_for<NDT>([&](auto e_tag) {           // V(j)^T fragments: in flight under the score MFMAs / softmax
+    ea_static_for<NDT>([&](auto e_tag) {
       constexpr int e = decltype(e_tag)::value;
+      const char* ve = vb + vfo[e];
       ea_static_for<4>([&](auto tu_tag) {
         constexpr int tu = decltype(tu_tag)::value;
-        vlo[e][tu] = ea_lds_read_tr16<(16 * tu) * VROW + 64 * e>(vbase);
-        vhi[e][tu] = ea_lds_read_tr16<(16 * tu + 8) * VROW + 64 * e>(vbase);
+        vlo[e][tu] = ea_lds_read_tr16<(16 * tu) * ROWB>(ve);
+        vhi[e][tu] = ea_lds_read_tr16<(16 * tu + 8) * ROWB>(ve);
       });
     });
-    if (NEXT) qk(j + 1, nxt);
+    if (NEXT) qk(s1, nxt);
     float psum = 0.0f;
     f16x8 pb[2][2];
 #pragma unroll
@@ -698,53 +715,54 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void ea_attn_pipe_kernel(
       }
     if (NEXT) {
       advance_max(j + 1, nxt, std::integral_constant<bool, NEXT == 2>{});
-        if (j + 2 < nkt) k_store(j + 2);
-      v_store(j + 1);
-      if (j + 3 < nkt) k_load(j + 3);
-      if (j + 2 < nkt) v_load(j + 2);
-      __syncthreads();
+      // the next iteration reads K(j+2) and V(j+1), requested one iteration ago; this iteration's requests stay in flight
+      if (k_req) attn_wait_dma<2 * NINS>();
+      else if (v_req) attn_wait_dma<NINS>();
+      else attn_wait_dma<0>();
+      attn_barrier();
     }
   };
 
   f32x16 sA[2], sB[2];
-  k_load(0);
-  v_load(0);
-  k_store(0);
-  v_store(0);
-  if (nkt > 1) {
-    k_load(1);
-    k_store(1);
-    v_load(1);
-    if (nkt > 2) k_load(2);
-  }
-  __syncthreads();
+  k_issue(0, 0);
+  v_issue(0, 0);
+  if (nkt > 1) k_issue(1, 1);
+  if (nkt > 2) k_issue(2, 2);
+  if (nkt > 1) v_issue(1, 1);
+  attn_wait_dma<0>();
+  attn_barrier();
   qk(0, sA);
   if (nfull == 0) advance_max(0, sA, std::true_type{});
   else advance_max(0, sA, std::false_type{});
 
-  auto take = [&]() {      // the odd hand-over between the two score buffers (once or twice per kernel)
+  auto take = [&]() {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sA[u][r] = sB[u][r];
   };
-  int j = 0;
+  int j = 0, s0 = 0, s1 = 1, s2 = 2;
+  auto rot = [&]() { const int t = s0; s0 = s1; s1 = s2; s2 = t; };
   const int nfn = nfull - 1;     // iterations whose next tile is a full one
   for (; j + 1 < nfn; j += 2) {
-    iter(j, sA, sB, std::integral_constant<int, 1>{});
-    iter(j + 1, sB, sA, std::integral_constant<int, 1>{});
+    iter(j, s0, s1, s2, sA, sB, std::integral_constant<int, 1>{});
+    rot();
+    iter(j + 1, s0, s1, s2, sB, sA, std::integral_constant<int, 1>{});
+    rot();
   }
   if (j < nfn) {
-    iter(j, sA, sB, std::integral_constant<int, 1>{});
+    iter(j, s0, s1, s2, sA, sB, std::integral_constant<int, 1>{});
+    rot();
     take();
     ++j;
   }
   if (nfull < nkt && nfull >= 1) {
-    iter(j, sA, sB, std::integral_constant<int, 2>{});
+    iter(j, s0, s1, s2, sA, sB, std::integral_constant<int, 2>{});
+    rot();
     take();
     ++j;
   }
-  iter(j, sA, sB, std::integral_constant<int, 0>{});
+  iter(j, s0, s1, s2, sA, sB, std::integral_constant<int, 0>{});
 
   const float l_tot = l_run + ea_shfl_xor(l_run, 32);
   const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
@@ -771,13 +789,16 @@ static int launch_attn(const AttnParams& p, void* stream) {
   dim3 grid((p.Nq + ATT_BQ - 1) / ATT_BQ, p.B * p.H, 1);
   if constexpr (BIAS == 0 && D == 64) {
     // the pipelined loop pays a longer prologue: it wins from 4 key tiles up (self-attention), the in-order kernel
-    // keeps the 77-token cross-attention (20.0 vs 22.1 us at Nq = 4096, 11.8 vs 14.2 us at Nq = 1024)
-    if (p.Nk >= 4 * ATT_BK) {
-      // (NW = 8 -- 256 queries per workgroup, half the staging per wave -- measured +1..3 % where the workgroup count
-      // divides the chip evenly and -11 % at the level-0 shape, 640 workgroups on 256 CUs: profiles/r02_attention_counters.md)
-      auto pfn = ea_attn_pipe_kernel<D, 4>;
-      ea_allow_big_lds(pfn, smem);
-      EA_LAUNCH(pfn, grid, dim3(256), smem, stream, p);
+    // keeps the 77-token cross-attention (20.0 vs 22.1 us at Nq = 4096, 11.8 vs 14.2 us at Nq = 1024).  Its buffer
+    // offsets are 32-bit: K / V of one (batch, head) must span < 2 GiB (always true for an fp16 projection output).
+    // (NW = 8 -- 256 queries per workgroup, half the staging per wave -- measured +1..3 % where the workgroup count
+    // divides the chip evenly and -11 % at the level-0 shape, 640 workgroups on 256 CUs: profiles/r02_attention_counters.md)
+    const long long span = (long long)p.Nk * (p.k_sn > p.v_sn ? p.k_sn : p.v_sn) * 2;
+    if (p.Nk >= 4 * ATT_BK && span < (1ll << 31)) {
+      auto dfn = ea_attn_dma_kernel<4>;
+      const int dsmem = 2 * 3 * ATT_BK * 128;        // K ring + V ring, three 8-KiB stages each
+      ea_allow_big_lds(dfn, dsmem);
+      EA_LAUNCH(dfn, grid, dim3(256), dsmem, stream, p);
       return ea_launch_status();
     }
   }
