@@ -20,7 +20,7 @@ for G in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA S
 import csv,sys,collections
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    if 'ea_attn_kernel' in r.get('Kernel_Name',''):
+    if 'ea_attn' in r.get('Kernel_Name',''):
         acc[r['Counter_Name']].append(float(r['Counter_Value']))
 for k,v in acc.items():
     # one row per dispatch (or per dispatch x dimension): report the per-dispatch total
