@@ -13,6 +13,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NV>
 __global__ __launch_bounds__(512) void probe(float* out, int mode, int n) {
   const int wave = threadIdx.x >> 6;
+  const int prio = mode >> 8;      // 1: the VALU waves run at s_setprio 3, 2: the MFMA waves do
+  mode &= 255;
+  if (prio == 1 && __builtin_amdgcn_readfirstlane(wave) >= 4) __builtin_amdgcn_s_setprio(3);
+  if (prio == 2 && __builtin_amdgcn_readfirstlane(wave) < 4) __builtin_amdgcn_s_setprio(3);
   f16x8 a, b;
   for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.001f * (threadIdx.x + j)); b[j] = (_Float16)(0.002f * j); }
   f32x16 acc[4];
@@ -62,18 +66,21 @@ int main() {
   const int n = 400000;    // MFMAs per wave (32 cycles each) / VALU groups of 8 FMAs per wave
   const char* names[] = {"MFMA waves only (4 of 8)", "VALU waves only (4 of 8)", "MFMA waves + VALU waves, one of each per SIMD", "8 MFMA waves, n/2 each",
                          "8 VALU waves, n/2 each", "one wave per SIMD: MFMA + 4 FMA interleaved", "VALU waves only, v_exp_f32 + mul",
-                         "one wave per SIMD: MFMA + 6 FMA", "one wave per SIMD: MFMA + 8 FMA", "one wave per SIMD: MFMA + 12 FMA"};
+                         "one wave per SIMD: MFMA + 6 FMA", "one wave per SIMD: MFMA + 8 FMA", "one wave per SIMD: MFMA + 12 FMA",
+                         "MFMA waves + VALU waves, the VALU waves at s_setprio 3", "MFMA waves + VALU waves, the MFMA waves at s_setprio 3"};
   for (int w = 0; w < 40; ++w) probe<4><<<256, 512>>>(d, 2, n);    // clocks up
   CK(hipDeviceSynchronize());
   for (int pass = 0; pass < 2; ++pass)
-  for (int mode = 0; mode < 10; ++mode) {
+  for (int mode = 0; mode < 12; ++mode) {
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
       CK(hipEventRecord(e0));
       if (mode < 7) probe<4><<<256, 512>>>(d, mode, n);
       else if (mode == 7) probe<6><<<256, 512>>>(d, 5, n);
       else if (mode == 8) probe<8><<<256, 512>>>(d, 5, n);
-      else probe<12><<<256, 512>>>(d, 5, n);
+      else if (mode == 9) probe<12><<<256, 512>>>(d, 5, n);
+      else if (mode == 10) probe<4><<<256, 512>>>(d, 2 | 256, n);
+      else probe<4><<<256, 512>>>(d, 2 | 512, n);
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
