@@ -77,6 +77,7 @@ struct EaGemmParams {
   int ktiles_per_split;
   int debug;       // bench-only ablation (EA_GEMM2_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
   int epi_fast;    // host-checked: the launch qualifies for ea_gemm2's streamlined epilogue (see launch_fast)
+  int raster_gm;   // ea_gemm3: tile rows per group of the grouped (L2-aware) tile order
   float* partial;  // [batch*splits][M][N] fp32 when splits > 1
   EaEpilogue epi;
 };

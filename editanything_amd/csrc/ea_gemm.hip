@@ -1,5 +1,6 @@
 // ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
 #include "ea_gemm2.h"
+#include "ea_gemm3.h"
 #include <stdlib.h>
 #include "../../include/editanything_hip.h"
 
@@ -225,7 +226,138 @@ static int launch_row_stats(EaGemmParams& p, void* stream) {
   return ea_launch_status();
 }
 
+// ---- ea_gemm3.h: the persistent 8-wave kernel.  Number of workgroups = CUs of the device (one resident per CU).
+static int cu_count() {
+#ifdef EA_EMU
+  return 4;   // host emulation: a tiny "device", so the tests walk several rounds of the persistent tile loop
+#else
+  static const int n = []() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+#endif
+}
+
+struct Plan3 {
+  int use;        // 0: stay on ea_gemm2
+  int bn, splits, ktiles_per_split, ks, gm, trx;
+  int epi_fast;
+};
+
+// Split-K factor of the persistent kernel: the launch runs ceil(tiles * s / CUs) rounds of (K tiles of a slice + a fixed
+// per-item cost, in K-tile units); split launches pay the reduce kernel and the fp32 partial round trip.
+static int plan3_splits(int tiles, int nk, long long MN, int allow_split) {
+  const int ncu = cu_count();
+  int best_s = 1;
+  double best = 1e30;
+  const int smax = allow_split ? 16 : 1;
+  for (int s = 1; s <= smax; ++s) {
+    if (g_force_splits > 0 && s != g_force_splits && allow_split) continue;
+    if (s > 1 && nk / s < 4 && g_force_splits == 0) break;
+    const int kps = (nk + s - 1) / s;
+    const int s_eff = (nk + kps - 1) / kps;
+    const double rounds = ceil((double)tiles * s_eff / ncu);
+    double cost = rounds * (kps * 0.55 + 4.0);
+    if (s_eff > 1) cost += 4.0 + 0.15 * s_eff + (double)MN * 4.0 * (s_eff + 1.0) / 6.0e6;
+    if (cost < best - 1e-9) { best = cost; best_s = s_eff; }
+  }
+  return best_s;
+}
+
+// Eligibility + plan of a launch on ea_gemm3 (the register-direct epilogue's conditions, batch 1).  `want`: 0 = the
+// automatic policy, 20 = forced with the automatic wave roles, 21 / 22 = forced m-split / k-split.
+static Plan3 plan3(const EaGemmParams& p, int want) {
+  Plan3 t{};
+  const EaEpilogue& e = p.epi;
+  if (want == 0) return t;                      // automatic policy: see plan3_auto()
+  if (p.batch != 1 || g_no_tr) return t;
+  const bool geglu = e.act == EA_ACT_GEGLU;
+  if (geglu && e.geglu_block != 32) return t;
+  t.bn = (p.N % 160 == 0 && !geglu) ? 160 : 128;
+  if (g_force_bn == 128) t.bn = 128;
+  const long long span = (long long)p.M * e.ldc + e.N;
+  bool ok = !e.out_f32 && !e.residual32 && !e.row_scale && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 &&
+            (((uintptr_t)e.out) & 15) == 0 && span < 0x7fffffffLL && (((uintptr_t)e.bias) & 15) == 0;
+  if (ok && e.residual) ok = (e.ldr & 7) == 0 && (((uintptr_t)e.residual) & 15) == 0 && (long long)p.M * e.ldr < 0x7fffffffLL;
+  if (ok && e.rowvec) ok = e.rows_per_group > 0 && (e.rows_per_group % 128) == 0 && (((uintptr_t)e.rowvec) & 15) == 0 && (e.rowvec_ld & 3) == 0;
+  if (ok && geglu) ok = !e.residual && !e.rowvec && (p.N % 128) == 0;
+  if (!ok) return t;
+  const int tiles = ((p.M + 127) / 128) * ((p.N + t.bn - 1) / t.bn);
+  const int nk = p.K / EA_BK;
+  const bool stats = e.ln_stats || e.gn_stats_out;
+  t.splits = plan3_splits(tiles, nk, (long long)p.M * p.N, !geglu && (p.N & 3) == 0);
+  if (stats && t.splits > 1) return t;          // the fold / GroupNorm partials exist in unsplit launches only (the queries say so)
+  t.ktiles_per_split = (nk + t.splits - 1) / t.splits;
+  t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
+  t.epi_fast = geglu ? 3 : 1;
+  t.trx = ((e.ln_stats || e.row_stats_out || e.gn_stats_out) && t.splits == 1) ? 2 : 1;
+  if (e.gn_stats_out) {
+    const int hw = e.gn_hw, cpg = e.gn_cpg;
+    if (hw <= 0 || cpg < 8 || (p.M % hw) || (hw % 32) || ((t.bn / 2) % cpg) || (p.N % t.bn) || (p.N % cpg) || hw / 32 > 128) return t;
+  }
+  t.ks = (want == 21) ? 1 : (want == 22) ? 2 : (t.ktiles_per_split >= 12 ? 2 : 1);
+  // grouped tile order: an XCD's run of (items per round) / 8 tiles should cover about as many A row panels as W column
+  // panels; with few tile columns take them all
+  const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + t.bn - 1) / t.bn;
+  int run = (tiles < cu_count() ? tiles : cu_count()) / 8;
+  if (run < 1) run = 1;
+  int gm = 1;
+  while (gm * gm < run) ++gm;                                  // ~ sqrt(run) rows x sqrt(run) columns
+  if (tiles_n * gm < run) gm = (run + tiles_n - 1) / tiles_n;  // few tile columns: take them all, more rows
+  if (gm > tiles_m) gm = tiles_m;
+  t.gm = gm;
+  t.use = 1;
+  return t;
+}
+
+static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t ws_bytes, void* stream) {
+  p.splits = t.splits;
+  p.ktiles_per_split = t.ktiles_per_split;
+  p.partial = nullptr;
+  p.debug = 0;
+  p.epi_fast = t.epi_fast;
+  p.raster_gm = t.gm;
+  if (t.splits > 1) {
+    const size_t need = (size_t)t.splits * p.M * p.N * sizeof(float);
+    if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
+    p.partial = (float*)workspace;
+  }
+  if ((p.epi.ln_stats || p.epi.gn_stats_out) && t.splits > 1) return EA_ERR_UNSUPPORTED;
+  const int items = ((p.M + 127) / 128) * ((p.N + t.bn - 1) / t.bn) * t.splits;
+  const int ncu = cu_count();
+  dim3 grid(items < ncu ? items : ncu, 1, 1);
+#define EA_LAUNCH_G3(BN_, TRX_, KS_)                                                  \
+  do {                                                                                \
+    auto kfn = ea_gemm3_kernel<BN_, TRX_, KS_>;                                       \
+    const int smem = ea_gemm3_lds_bytes(BN_);                                         \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);                           \
+  } while (0)
+  if (t.bn == 160) {
+    if (t.ks == 2) { if (t.trx == 2) EA_LAUNCH_G3(160, 2, 2); else EA_LAUNCH_G3(160, 1, 2); }
+    else { if (t.trx == 2) EA_LAUNCH_G3(160, 2, 1); else EA_LAUNCH_G3(160, 1, 1); }
+  } else {
+    if (t.ks == 2) { if (t.trx == 2) EA_LAUNCH_G3(128, 2, 2); else EA_LAUNCH_G3(128, 1, 2); }
+    else { if (t.trx == 2) EA_LAUNCH_G3(128, 2, 1); else EA_LAUNCH_G3(128, 1, 1); }
+  }
+#undef EA_LAUNCH_G3
+  int st = ea_launch_status();
+  if (st == EA_OK && t.splits > 1) {
+    st = launch_reduce(p, stream);
+    if (st == EA_OK) st = launch_row_stats(p, stream);
+  }
+  return st;
+}
+
 static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
+  {
+    const Plan3 t3 = plan3(p, (g_variant >= 20 && g_variant <= 22) ? g_variant : 0);
+    if (t3.use) return launch_fast3(p, t3, workspace, ws_bytes, stream);
+    if (g_variant >= 20 && g_variant <= 22) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
+  }
   Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
@@ -383,14 +515,39 @@ extern "C" int ea_row_stats_parts(int N) { return N > 0 ? row_stat_parts(N) : 0;
 
 // 1 when a LayerNorm-folded launch of this shape runs through the register-direct epilogue (fp16 output, 16-byte
 // aligned operands assumed): the 2-stage LDS-DMA tiles with no split-K.  act: EA_ACT_* (GEGLU = the 32-row packing).
+// a launch of this shape with every epilogue operand aligned, as the queries assume
+static EaGemmParams query_params(int M, int N, int K, int conv, int geglu32) {
+  EaGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.M = M; p.N = N; p.K = K; p.batch = 1; p.conv = conv;
+  p.epi.N = geglu32 ? N / 2 : N; p.epi.ldc = p.epi.N; p.epi.M = M;
+  p.epi.act = geglu32 ? EA_ACT_GEGLU : EA_ACT_NONE;
+  p.epi.geglu_block = geglu32 ? 32 : 64;
+  return p;
+}
+
 extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+  if (g_variant >= 20 && g_variant <= 22) {
+    EaGemmParams q = query_params(M, N, K, 0, 0);
+    static const float dummy = 0.0f;
+    q.epi.ln_stats = &dummy;
+    return plan3(q, g_variant).use;
+  }
   Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
   return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
 }
 
 extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+  if (g_variant >= 20 && g_variant <= 22) {
+    EaGemmParams q = query_params(M, N, K, conv ? 1 : 0, 0);
+    static float dummy = 0.0f;
+    q.epi.gn_stats_out = &dummy;
+    q.epi.gn_hw = rows_per_sample;
+    q.epi.gn_cpg = cpg;
+    return plan3(q, g_variant).use ? 32 : 0;
+  }
   Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
   return gn_stats_rows(t, M, N, rows_per_sample, cpg);
 }
@@ -404,6 +561,11 @@ extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
       Plan2 f = plan_fast(M, N, K, batch, 1, conv);
       if (f.splits > splits) splits = f.splits;
     }
+  }
+  if (K % EA_BK == 0 && batch == 1 && (N & 3) == 0) {   // the persistent kernel's own split choice
+    const int bn = (N % 160 == 0) ? 160 : 128;
+    const int s3 = plan3_splits(((M + 127) / 128) * ((N + bn - 1) / bn), K / EA_BK, (long long)M * N, 1);
+    if (s3 > splits) splits = s3;
   }
   if (splits <= 1) return 0;
   return (size_t)batch * splits * M * N * sizeof(float);

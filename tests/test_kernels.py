@@ -1030,3 +1030,146 @@ def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
     r = ref.reshape(M, N // 32, 2, 16)
     ref = (r[:, :, 0] * F.gelu(r[:, :, 1])).reshape(M, N // 2) * 0.5
     assert relerr(kb.down(out), ref.numpy()) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ea_gemm3.h: the persistent 8-wave kernel (tuning variant 21 = m-split wave roles, 22 = k-split groups + accumulator
+# exchange, 20 = the plan's own choice).  The emulated "device" has 4 CUs, so these shapes walk several rounds of the
+# persistent tile loop, with the DMA stream running across tile boundaries.
+def _gemm_run(kb, A, W, bias, act, R, rv, rpg, variant, splits=0, scale=0.75, gb=0):
+    M, K = A.shape
+    N = W.shape[0]
+    tune(kb, variant=int(variant), splits=int(splits))
+    No = N // 2 if act == 3 else N
+    out = kb.zeros((M, No), np.float16)
+    e = epilogue(out, bias=bias, act=act, scale=scale, residual=R, rowvec=rv, rows_per_group=rpg, geglu_block=gb)
+    ws = workspace(kb, max(kb.lib.ea_gemm_workspace_bytes(M, N, K, 1), 16 * M * N * 4 if splits else 0))
+    st = kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream)
+    assert st == 0, st
+    return kb.down(out).copy()
+
+
+@pytest.mark.parametrize("M,N,K,act,res,rowvec,splits", [
+    (600, 320, 256, 0, True, False, 0),      # 5 x 2 tiles of 128 x 160 = 10 items on 4 workgroups: 3 rounds, ragged M
+    (256, 160, 64, 1, False, False, 0),      # one K tile per item (nothing to prefetch inside an item)
+    (130, 192, 128, 2, True, False, 0),      # 128-wide column tiles, ragged M and N
+    (512, 256, 192, 1, False, True, 0),      # per-sample row vector, 4 samples of 128 rows
+    (256, 320, 768, 0, True, False, 3),      # split-K: 3 slices x 4 tiles, raw fp32 dump + reduce kernel
+    (384, 480, 1024, 0, False, False, 0),    # the plan's own split choice, 16 K tiles
+])
+@pytest.mark.parametrize("variant", [21, 22])
+def test_persistent_kernel_gemm(kb, M, N, K, act, res, rowvec, splits, variant):
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    rv = f32(M // 128, N) if rowvec else None
+    got = _gemm_run(kb, A, W, bias, act, R, rv, 128 if rowvec else 1, variant, splits)
+    base = _gemm_run(kb, A, W, bias, act, R, rv, 128 if rowvec else 1, 1, splits)
+    ref = t(A) @ t(W).T + t(bias)
+    if rowvec:
+        ref = ref + t(rv).repeat_interleave(128, 0)
+    ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(got, ref.numpy()) < 2e-3
+    if variant == 21 and not splits and K < 1024:
+        # m-split waves multiply the same products in the same order as ea_gemm2's 128-row tiles: bit-identical
+        assert np.array_equal(got, base)
+    else:
+        assert np.abs(got.astype(np.float32) - base.astype(np.float32)).max() <= 2e-3 * np.abs(ref.numpy()).max()
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,ksize,stride,ups,emb,res", [
+    (2, 16, 16, 64, 0, 160, 3, 1, 0, True, False),    # in_layers conv + embedding row vector
+    (2, 16, 16, 64, 64, 320, 3, 1, 0, False, True),   # decoder conv over a virtual concat + skip residual
+    (3, 16, 16, 128, 0, 128, 3, 2, 0, False, False),  # Downsample (stride 2), 128-wide tiles
+    (2, 8, 8, 64, 0, 160, 3, 1, 1, False, False),     # Upsample (nearest 2x inside the im2col)
+    (2, 16, 16, 64, 64, 160, 1, 1, 0, False, False),  # 1x1 skip_connection over a concat
+])
+@pytest.mark.parametrize("variant", [21, 22])
+def test_persistent_kernel_conv(kb, B, H, W, c1, c2, cout, ksize, stride, ups, emb, res, variant):
+    x1 = f16(B, H, W, c1)
+    x2 = f16(B, H, W, c2) if c2 else None
+    Ho = 2 * H if ups else (H // 2 if stride == 2 else H)
+    Wo = 2 * W if ups else (W // 2 if stride == 2 else W)
+    w, bias = f16(cout, c1 + c2, ksize, ksize, scale=0.1), f32(cout)
+    M = B * Ho * Wo
+    rv = f32(B, cout) if emb else None
+    R = f16(M, cout) if res else None
+    pad = 1 if ksize == 3 else 0
+    outs = []
+    for v in (variant, 1):
+        tune(kb, variant=int(v), splits=1)
+        src = conv_src(x1, x2, None, ksize, stride, pad, ups, Ho, Wo)
+        out = kb.zeros((M, cout), np.float16)
+        e = epilogue(out, bias=bias, act=1, residual=R, rowvec=rv, rows_per_group=Ho * Wo)
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(pack_conv_w(w)), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, t(w), t(bias), stride=stride, padding=pad)
+    if emb:
+        ref = ref + t(rv)[:, :, None, None]
+    ref = F.silu(ref).permute(0, 2, 3, 1).reshape(M, cout)
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 3e-3
+    if variant == 21:
+        assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("variant", [21, 22])
+def test_persistent_kernel_geglu_and_fold_and_stats(kb, variant):
+    """GEGLU (32-row packing), the LayerNorm fold with row statistics from a producing launch, and GroupNorm partials (chunks
+    of 32 rows), all through the persistent kernel."""
+    # GEGLU
+    M, N, K = 300, 512, 192
+    A, W, bias = f16(M, K), f16(N, K, scale=0.2), f32(N)
+    got = _gemm_run(kb, A, W, bias, 3, None, None, 1, variant, scale=0.5, gb=32)
+    r = (t(A) @ t(W).T + t(bias)).reshape(M, N // 32, 2, 16)
+    ref = (r[:, :, 0] * F.gelu(r[:, :, 1])).reshape(M, N // 2) * 0.5
+    assert relerr(got, ref.numpy()) < 3e-3
+    # producer with row statistics -> LayerNorm-folded consumer
+    tune(kb, variant=int(variant))
+    M, N, K = 384, 320, 320
+    assert kb.lib.ea_gemm_ln_fold_ok(M, N, K) == 1
+    A0, W0, R0 = f16(M, 64), f16(K, 64, scale=0.3), f16(M, K, scale=2.0) + np.float16(0.5)
+    parts = kb.lib.ea_row_stats_parts(K)
+    stats = kb.zeros((parts, M, 2), np.float32)
+    x = kb.zeros((M, K), np.float16)
+    e0 = epilogue(x, residual=R0, row_stats_out=stats)
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A0), 64, ptr(W0), 64, M, K, 64, 1, 0, 0, 0, 0, C.byref(e0), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    xh = kb.down(x).copy()
+    gamma, beta = (1.0 + 0.2 * RNG.standard_normal(K)).astype(np.float32), (0.1 * RNG.standard_normal(K)).astype(np.float32)
+    Wl = (RNG.standard_normal((N, K)) * 0.2).astype(np.float32)
+    b = f32(N)
+    Wf = (Wl * gamma[None, :]).astype(np.float16)
+    colsum = Wf.astype(np.float32).sum(1)
+    bf = (Wl @ beta + b).astype(np.float32)
+    out = kb.zeros((M, N), np.float16)
+    e = epilogue(out, bias=bf, ln_stats=stats, ln_parts=parts, ln_colsum=colsum, ln_eps=1e-5)
+    assert kb.lib.ea_gemm_f16(ptr(x) if not isinstance(x, np.ndarray) else ptr(xh), K, ptr(Wf), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ref = F.layer_norm(t(xh), (K,), t(gamma), t(beta), 1e-5) @ t(Wl).T + t(b)
+    assert relerr(kb.down(out), ref.numpy()) < 4e-3
+    # GroupNorm partials of a conv output
+    B, H, cin, cout, groups = 2, 16, 64, 320, 32
+    HW, Mc, Kc, cpg = H * H, B * H * H, 9 * cin, cout // groups
+    tune(kb, variant=int(variant), splits=1)
+    rows = kb.lib.ea_gemm_gn_stats_chunk_rows(Mc, cout, Kc, 1, HW, cpg)
+    assert rows == 32
+    nchunk = HW // rows
+    xc, Wc, bc, rvc = f16(B, H, H, cin), f16(cout, Kc, scale=0.05), f32(cout), f32(B, cout)
+    part = kb.zeros((B, nchunk, groups, 2), np.float32)
+    y = kb.zeros((Mc, cout), np.float16)
+    eg = epilogue(y, bias=bc, rowvec=rvc, rows_per_group=HW, gn_stats_out=part, gn_rows_per_sample=HW, gn_cpg=cpg)
+    src = conv_src(xc)
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(Wc), cout, C.byref(eg), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    yh = kb.down(y).astype(np.float64).reshape(B, nchunk, rows, groups, cpg)
+    gotp = kb.down(part).astype(np.float64)
+    refp = np.stack([yh.sum((2, 4)), (yh * yh).sum((2, 4))], -1)
+    assert np.abs(gotp[..., 0] - refp[..., 0]).max() <= 1e-4 * np.abs(yh).sum((2, 4)).max()
+    assert np.abs(gotp[..., 1] - refp[..., 1]).max() <= 1e-4 * refp[..., 1].max()

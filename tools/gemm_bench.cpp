@@ -115,6 +115,10 @@ static std::vector<Case> all_cases() {
   cv(4, 256, 256, 0, 256, 3, 1, 0);   cv(4, 512, 128, 0, 128, 3, 1, 0);
   // calibration cubes (the guide's ladder is quoted at 4096^3 / 8192^3): compare with tools/gemm8_probe in the same call
   g(4096, 4096, 4096, 0, 0);  g(8192, 8192, 8192, 0, 0);
+  // row-stride probes (round 3): the same launches with K moved off the power-of-two row strides (2560 / 10240 bytes), to see
+  // whether the L2 / fabric channel interleave penalises those strides ("--cases stride")
+  g(2048, 1280, 1344, 0, 0);  g(2048, 1280, 5184, 0, 1);  g(8192, 640, 2624, 0, 1);
+  for (size_t i = v.size() - 3; i < v.size(); ++i) v[i].name += " stride";
   return v;
 }
 
@@ -194,6 +198,7 @@ int main(int argc, char** argv) {
   HIP_CHECK(hipEventCreate(&e1));
 
   for (auto& c : all_cases()) {
+    if (cases_sel == "all" && (c.flops > 3e11 || c.name.find("stride") != std::string::npos)) continue;   // cubes / probes: by name only
     if (cases_sel != "all") {
       if (cases_sel == "gemm" ? c.conv != 0 : cases_sel == "conv" ? c.conv != 1 : c.name.find(cases_sel) == std::string::npos) continue;
     }
