@@ -78,6 +78,7 @@ struct EaGemmParams {
   int debug;       // bench-only ablation (EA_GEMM2_DEBUG): 1 = skip the epilogue, 2 = skip the K loop
   int epi_fast;    // host-checked: the launch qualifies for ea_gemm2's streamlined epilogue (see launch_fast)
   int raster_gm;   // ea_gemm3: tile rows per group of the grouped (L2-aware) tile order
+  unsigned long long* prof;   // ea_gemm3 -DEA_G3_PROF builds only (tools/g3_prof): per-wave phase cycle totals; NULL in the product
   float* partial;  // [batch*splits][M][N] fp32 when splits > 1
   EaEpilogue epi;
 };
@@ -89,6 +90,25 @@ __device__ __forceinline__ int ea_xcd_remap(int bid, int nwg) {
   const int xcd = bid % 8, idx = bid / 8;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// GROUPED tile order (L2-aware rasterisation): tile t of a tiles_m x tiles_n grid -> rows are taken `gm` at a time and a
+// group is walked column-major, so a run of consecutive tiles covers ~gm row panels of A x run/gm column panels of W
+// instead of one row panel x `run` column panels.  With a wide N (SAM's MLP / qkv Linears, the GEGLU projections) the
+// row-major order streams the whole weight matrix through an XCD's 4-MiB L2 once per tile row: measured 5.8-8.5x the
+// algorithmic HBM-side traffic, 5.9 TB/s on the fabric (profiles/r02_pmc_traffic_tap_major.json).
+// `id` may carry a split-K slice in front (slice-major): id = slice * tiles + t.
+__device__ __forceinline__ void ea_grouped_item(int id, int tiles_m, int tiles_n, int gm, int& tm, int& tn, int& split) {
+  const int tiles = tiles_m * tiles_n;
+  split = id / tiles;
+  const int t = id - split * tiles;
+  const int per_group = gm * tiles_n;
+  const int grp = t / per_group;
+  const int first_m = grp * gm;
+  const int gsz = (tiles_m - first_m) < gm ? (tiles_m - first_m) : gm;
+  const int r = t - grp * per_group;
+  tn = r / gsz;
+  tm = first_m + (r - tn * gsz);
 }
 
 // Store 8 consecutive outputs (row m, cols n..n+7) with the full epilogue.

@@ -320,6 +320,10 @@ static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t
   p.debug = 0;
   p.epi_fast = t.epi_fast;
   p.raster_gm = t.gm;
+#if EA_G3_PROF
+  // profiling side build: the phase totals go behind the split-K partials in the caller's workspace
+  p.prof = (workspace && ws_bytes >= ((size_t)t.splits * p.M * p.N * 4 + (1u << 20))) ? (unsigned long long*)((char*)workspace + (size_t)(t.splits > 1 ? t.splits : 0) * p.M * p.N * 4) : nullptr;
+#endif
   if (t.splits > 1) {
     const size_t need = (size_t)t.splits * p.M * p.N * sizeof(float);
     if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
@@ -396,6 +400,15 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
         return EA_ERR_UNSUPPORTED;
       p.epi_fast = 3;
     }
+  }
+  // grouped tile order for wide outputs (ea_gemm.h ea_grouped_item): ~64 tiles of an XCD are resident at a time
+  p.raster_gm = 0;
+  {
+    const int tiles_n = (p.N + t.bn - 1) / t.bn, tiles_m = t.tiles / tiles_n;
+    // ... when the weight matrix does not stay in a 4-MiB L2 anyway (measured on the MI355X, same call, row-major vs
+    // grouped: SAM MLP [16384 x 5120 x 1280] 305 -> 269 us, GEGLU [2048 x 10240 x 1280] 77 -> 63 us; the K = 320 GEGLU
+    // projection, whose 1.6-MB weight is L2 resident, LOSES 6 % and keeps the row-major order)
+    if (g_tune.debug != 20 && tiles_n > 8 && tiles_m >= 16 && (long long)p.N * p.K * 2 > (3ll << 20)) p.raster_gm = 8;   // debug 20: row-major everywhere (A/B)
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \

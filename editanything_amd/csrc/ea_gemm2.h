@@ -102,7 +102,13 @@ void ea_gemm2_kernel(EaGemmParams p) {
   const int tile = ea_xcd_remap(blockIdx.x, ntile);
   // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
   // (K position, descriptors, scalar offsets) stays in SGPRs -- otherwise every DMA is wrapped in a waterfall loop (T20)
-  const int tm = ea_uniform(tile / tiles_n), tn = tile - tm * tiles_n;
+  int tm = ea_uniform(tile / tiles_n), tn = tile - tm * tiles_n;
+  if (p.raster_gm > 1) {   // wide-N launches: grouped order, so an XCD's resident tiles share W column panels too
+    int unused;
+    ea_grouped_item(tile, ntile / tiles_n, tiles_n, p.raster_gm, tm, tn, unused);
+    tm = ea_uniform(tm);
+    tn = ea_uniform(tn);
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int bz = blockIdx.z;
   const int batch = ea_uniform(bz / p.splits), split = bz - batch * p.splits;

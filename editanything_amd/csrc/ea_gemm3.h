@@ -36,23 +36,24 @@
 #include "ea_epi_tr.h"
 
 #define EA_G3_STAGES 4
+// -DEA_G3_PROF=1 (tools/g3_prof, never in the product): per-wave cycle totals of the loop's phases (s_memtime) into the
+// workspace -- 0 counted wait, 1 barrier, 2 early issue, 3 fragment reads + MFMAs, 4 late issue, 5 end of item, 6 opening.
+#ifndef EA_G3_PROF
+#define EA_G3_PROF 0
+#endif
+// -DEA_G3_ABL=mask (side builds for tools/g3_prof only; results are wrong by construction): 1 no MFMAs, 2 no fragment
+// reads, 4 no per-K-tile barrier, 8 no DMA after the prologue
+#ifndef EA_G3_ABL
+#define EA_G3_ABL 0
+#endif
+#if EA_G3_PROF && !defined(EA_EMU)
+#define G3T(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); g3t[i] += t_ - g3last; g3last = t_; } while (0)
+#else
+#define G3T(i) do {} while (0)
+#endif
 #define EA_G3_SPARE 4096   // LDS behind the ring: GroupNorm-statistics bins of the epilogue (no DMA ever targets it)
 
 constexpr int ea_gemm3_lds_bytes(int bn) { return EA_G3_STAGES * (128 + bn) * 128 + 2 * EA_G3_SPARE; }   // + the exchange overflow
-
-// work item `id` of a launch with `tiles_m x tiles_n` tiles and `splits` K slices -> (tile row, tile column, slice)
-__device__ __forceinline__ void ea_g3_item(int id, int tiles_m, int tiles_n, int gm, int& tm, int& tn, int& split) {
-  const int tiles = tiles_m * tiles_n;
-  split = id / tiles;
-  const int t = id - split * tiles;
-  const int per_group = gm * tiles_n;
-  const int grp = t / per_group;
-  const int first_m = grp * gm;
-  const int gsz = (tiles_m - first_m) < gm ? (tiles_m - first_m) : gm;
-  const int r = t - grp * per_group;
-  tn = r / gsz;
-  tm = first_m + (r - tn * gsz);
-}
 
 template <int BN, int TRX, int KS>
 __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
     if ((int)blockIdx.x >= n_r) return false;
     const int id = base + ea_xcd_remap(blockIdx.x, n_r);
     int tm, tn;
-    ea_g3_item(id, tiles_m, tiles_n, p.raster_gm, tm, tn, split);
+    ea_grouped_item(id, tiles_m, tiles_n, p.raster_gm, tm, tn, split);
     tm = ea_uniform(tm); tn = ea_uniform(tn); split = ea_uniform(split);
     m0 = tm * BM;
     n0 = tn * BN;
@@ -181,6 +182,9 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
   };
   auto issue_next = [&]() {
     if (is_left == 0 && !open_item()) return;
+#if (EA_G3_ABL & 8) && !defined(EA_EMU)
+    if (issued >= 3) { ++issued; --is_left; return; }
+#endif
     char* sa = smem + (issued & (EA_G3_STAGES - 1)) * STAGE_BYTES;
     char* sb = sa + BM * 128;
     is_kcur = ea_uniform(is_kcur);     // loop-carried scalars: keep them provably wave-uniform (SGPR descriptors / offsets, T20)
@@ -221,10 +225,16 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
 
   // ---------------------------------------------------------------------------------------------- compute side
   const int frow = lane & 15, fq = lane >> 4;
+#if (EA_G3_ABL & 2) && !defined(EA_EMU)
+  int q_abl = -1;                         // ablation: fragment reads only before the first K tile
+#endif
   f32x4 acc[MI][NI];
   f16x8 fa[2][MI], fb[2][NI];
   // fragments of K step `ks` of the K tile in ring slot `s` -> register set `set`
   auto read_frags = [&](int s, int ks, int set) {
+#if (EA_G3_ABL & 2) && !defined(EA_EMU)
+    if (q_abl >= 0) return;
+#endif
     const char* sa = smem + s * STAGE_BYTES;
     const char* sb = sa + BM * 128;
     const int ch = ks * 4 + fq;
@@ -240,10 +250,17 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
     }
   };
   auto mfma_step = [&](int set) {
+#if (EA_G3_ABL & 1) && !defined(EA_EMU)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(fa[set][i]));
+#pragma unroll
+    for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(fb[set][j]));
+#else
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j) acc[i][j] = ea_mfma_16x16x32(fb[set][j], fa[set][i], acc[i][j]);
+#endif
   };
   // pin "one fragment read per MFMA (pair)" where a step's reads and MFMAs share a basic block (guide T19): left alone
   // hipcc sinks the reads to just before their first use and the matrix pipe waits out the LDS round trip
@@ -269,6 +286,11 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
   // loop with "if (first K tile) zero / read" keeps 150 registers alive through it and spills).
   constexpr int ME = 2;                   // row tiles a wave emits
   char* spare = smem + EA_G3_STAGES * STAGE_BYTES;
+#if EA_G3_PROF && !defined(EA_EMU)
+  unsigned long long g3t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long g3last = __builtin_readcyclecounter();
+  const unsigned long long g3start = g3last;
+#endif
 #pragma unroll 1
   for (int i = 0; i < 3; ++i) issue_next();
   if (issued == 0) return;                // nothing to do for this workgroup (uniform)
@@ -276,6 +298,9 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
   ea_raw_barrier();
 
   int q = 0;                              // job being multiplied
+#if (EA_G3_ABL & 2) && !defined(EA_EMU)
+  read_frags(0, 0, 0); read_frags(0, 1, 1); q_abl = 0;
+#endif
 #pragma unroll 1
   for (int round = 0; round < nrounds; ++round) {
     int m0, n0, split, kt0, nk;
@@ -326,6 +351,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
       }
     }
 
+    G3T(6);
     // One K tile: top = job q + 1 landed for this wave (the stream's last job has no successor: wait for the job itself),
     // barrier, issue job q + 3; then the MFMAs of job q with the next fragments read under them.
     // k-split: this wave's K step of a job sits in ONE register set, the next job's goes into the other.  The set index
@@ -333,42 +359,62 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
     // parities must not meet in a control-flow merge (hipcc then shuffles 72 fragment + 80 accumulator registers through
     // copies and spills): the K loop is unrolled by two, even K tiles on set 0, odd ones on set 1, an item always starts
     // on set 0.
+    // The DMA issue of an iteration (~60 clk per 1-KiB piece on the CU's one address path) is STAGGERED between the two
+    // halves of the workgroup: waves 0..3 issue before their MFMAs, waves 4..7 after theirs.  Every SIMD hosts one wave
+    // of each half, so one half's issue burst runs beside the other half's MFMAs instead of all eight waves bursting and
+    // then all multiplying (first GPU run of this kernel, all waves in phase: 30-55 % SLOWER than ea_gemm2, whose two
+    // workgroups per CU de-phase by themselves).
+    // The next fragments are read UNCONDITIONALLY (at the last K tile of the stream a stale slot: never used): a branch
+    // around the reads splits the block and hipcc parks an s_waitcnt lgkmcnt(0) in front of the MFMAs -- the whole LDS
+    // round trip exposed, every K tile (seen in the first build's ISA).
+    const bool early = wave < 4;
     if constexpr (KS == 2) {
 #pragma unroll 1
       for (int kt = 0; kt < nk; kt += 2) {
-        {
-          const bool last = kt + 1 == nk;
-          wait_job(q + 1 < issued ? q + 1 : q);
-          ea_raw_barrier();
-          issue_next();
-          if (!last) read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 1);
-          mfma_step(0);
-          ++q;
-          if (last) break;
-        }
-        {
-          const bool last = kt + 2 == nk;
-          wait_job(q + 1 < issued ? q + 1 : q);
-          ea_raw_barrier();
-          issue_next();
-          if (!last) read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 0);
-          mfma_step(1);
-          ++q;
-        }
+        wait_job(q + 1 < issued ? q + 1 : q);
+        G3T(0);
+        if (!(EA_G3_ABL & 4)) ea_raw_barrier();
+        G3T(1);
+        if (early) issue_next();
+        G3T(2);
+        read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 1);
+        mfma_step(0);
+        G3T(3);
+        if (!early) issue_next();
+        G3T(4);
+        ++q;
+        if (kt + 1 == nk) break;
+        wait_job(q + 1 < issued ? q + 1 : q);
+        G3T(0);
+        if (!(EA_G3_ABL & 4)) ea_raw_barrier();
+        G3T(1);
+        if (early) issue_next();
+        G3T(2);
+        read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 0);
+        mfma_step(1);
+        G3T(3);
+        if (!early) issue_next();
+        G3T(4);
+        ++q;
       }
     } else {
 #pragma unroll 1
       for (int kt = 0; kt < nk; ++kt, ++q) {
-        const bool last = kt + 1 == nk;
         wait_job(q + 1 < issued ? q + 1 : q);
-        ea_raw_barrier();
-        issue_next();
+        G3T(0);
+        if (!(EA_G3_ABL & 4)) ea_raw_barrier();
+        G3T(1);
+        if (early) issue_next();
+        G3T(2);
         // K step 0 is in set 0: read step 1 under it; then the next job's step 0 under step 1
         read_frags(q & (EA_G3_STAGES - 1), 1, 1);
         mfma_step(0);
         pin_interleave();
-        if (!last) read_frags((q + 1) & (EA_G3_STAGES - 1), 0, 0);
+        read_frags((q + 1) & (EA_G3_STAGES - 1), 0, 0);
         mfma_step(1);
+        G3T(3);
+        if (!early) issue_next();
+        G3T(4);
       }
     }
 
@@ -408,5 +454,13 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
     } else {
       ea_tr_epilogue<ME, NI, TRX, false>(p, acc, emit_row0, colbase, m0, 0, split, ln_mu, ln_rs, spare, wave);
     }
+    G3T(5);
   }
+#if EA_G3_PROF && !defined(EA_EMU)
+  if (lane == 0 && p.prof) {
+    unsigned long long* o = p.prof + ((long long)blockIdx.x * 8 + wave) * 8;
+    g3t[7] = g3last - g3start;
+    for (int i = 0; i < 8; ++i) o[i] = g3t[i];
+  }
+#endif
 }

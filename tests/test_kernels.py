@@ -1173,3 +1173,20 @@ def test_persistent_kernel_geglu_and_fold_and_stats(kb, variant):
     refp = np.stack([yh.sum((2, 4)), (yh * yh).sum((2, 4))], -1)
     assert np.abs(gotp[..., 0] - refp[..., 0]).max() <= 1e-4 * np.abs(yh).sum((2, 4)).max()
     assert np.abs(gotp[..., 1] - refp[..., 1]).max() <= 1e-4 * refp[..., 1].max()
+
+
+def test_grouped_tile_order_wide_output(kb):
+    """Wide outputs (tile columns > 8, tile rows >= 16) run the GROUPED tile order (ea_gemm.h ea_grouped_item); every tile
+    must still be produced exactly once: compare with the row-major order (tuning debug = 20) bit for bit, and with torch."""
+    M, N, K = 2048 + 72, 1536, 64           # 17 x 12 tiles of 128 x 128, the last group of tile rows is ragged
+    A, W, bias = f16(M, K), f16(N, K, scale=0.2), f32(N)
+    outs = []
+    for dbg in (0, 20):
+        tune(kb, variant=1, debug=dbg)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias)
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    assert relerr(outs[0], (t(A) @ t(W).T + t(bias)).numpy()) < 2e-3
