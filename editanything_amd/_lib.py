@@ -55,6 +55,7 @@ SIGNATURES = {
     "ea_version": (_i, []),
     "ea_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "ea_set_tuning": (_i, [C.POINTER(Tuning)]),
+    "ea_tools_build": (_i, []),
     "ea_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_row_stats_parts": (_i, [_i]),
     "ea_gemm_ln_fold_ok": (_i, [_i, _i, _i]),

@@ -228,19 +228,21 @@ __device__ __forceinline__ void ea_tr_epilogue(const EaGemmParams& p, f32x4 (&ac
 #pragma unroll
       for (int r = 0; r < 4; ++r) { a[r] += (float)rr[r]; b[r] += (float)rr[4 + r]; }
     }
+    f16x8 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
     if (TRX == 2 && e.row_stats_out) {
+      // statistics of the ROUNDED fp16 outputs -- what the consumer's LayerNorm sees, and what the fallback producer
+      // (ea_row_stats_kernel, split-K / generic launches) computes: both producers agree whatever path the planner picks
       float t1 = 0.0f, t2 = 0.0f;
       if (on) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { t1 += a[r] + b[r]; t2 += a[r] * a[r] + b[r] * b[r]; }
+        for (int r = 0; r < 8; ++r) { const float f = (float)h[r]; t1 += f; t2 += f * f; }
       }
       if (i0 == i1) { st1[i0] += t1; st2[i0] += t2; }
       else { st1[i0] += sel ? 0.0f : t1; st2[i0] += sel ? 0.0f : t2; st1[i1] += sel ? t1 : 0.0f; st2[i1] += sel ? t2 : 0.0f; }
     }
     if (!on) return;
-    f16x8 h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { h[r] = (f16)a[r]; h[4 + r] = (f16)b[r]; }
     ea_st8(outp + voff[v], h);
     if (gn_on) {
 #pragma unroll

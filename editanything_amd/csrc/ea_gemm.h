@@ -485,5 +485,6 @@ __global__ __launch_bounds__(256) void ea_row_stats_kernel(const f16* x, int ld,
   s1 = ea_wave_sum(s1);
   s2 = ea_wave_sum(s2);
   if (lane == 0) *reinterpret_cast<f32x2*>(stats + (long long)row * 2) = f32x2{s1, s2};
-  else if (lane < parts) *reinterpret_cast<f32x2*>(stats + ((long long)lane * M + row) * 2) = f32x2{0.0f, 0.0f};
+  for (int pp = lane; pp < parts; pp += 64)   // every other part is zero, however many there are (N > 5120: more than 64)
+    if (pp > 0) *reinterpret_cast<f32x2*>(stats + ((long long)pp * M + row) * 2) = f32x2{0.0f, 0.0f};
 }

@@ -203,6 +203,12 @@ static int gn_stats_rows(const Plan2& t, int M, int N, int hw, int cpg) {
   if (t.splits != 1 || (t.kind != 1 && t.kind != 9) || g_no_tr) return 0;
   const int wtm = t.bm / 2, wtn = t.bn / 2;
   if (hw <= 0 || cpg < 8 || (M % hw) || (hw % wtm) || (wtn % cpg) || (N % t.bn) || (N % cpg)) return 0;
+  // a workgroup tile must not straddle two samples: the launches that ask for the partials carry a per-sample row
+  // vector (ResBlock time embedding), and the register-direct epilogue that writes the partials needs all bm rows of a
+  // tile in ONE row-vector group (launch_fast: rows_per_group % bm == 0).  hw = 8x8, 24x24, 40x40, 56x56 with 128-row tiles
+  // used to pass this query and then fail the launch (round-2 advisor finding): now the query says 0 and the caller
+  // runs the statistics pass.
+  if (hw % t.bm) return 0;
   if (hw / wtm > 128) return 0;   // EA_GN_MAX_CHUNKS of the apply pass
   return wtm;
 }
@@ -366,7 +372,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
-  p.debug = g_tune.debug;
+  p.debug = EA_TOOLS ? g_tune.debug : 0;
   if (t.splits > 1) {
     const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
     if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
@@ -408,7 +414,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     // ... when the weight matrix does not stay in a 4-MiB L2 anyway (measured on the MI355X, same call, row-major vs
     // grouped: SAM MLP [16384 x 5120 x 1280] 305 -> 269 us, GEGLU [2048 x 10240 x 1280] 77 -> 63 us; the K = 320 GEGLU
     // projection, whose 1.6-MB weight is L2 resident, LOSES 6 % and keeps the row-major order)
-    if (g_tune.debug != 20 && tiles_n > 8 && tiles_m >= 16 && (long long)p.N * p.K * 2 > (3ll << 20)) p.raster_gm = 8;   // debug 20: row-major everywhere (A/B)
+    if (!(EA_TOOLS && g_tune.debug == 20) && tiles_n > 8 && tiles_m >= 16 && (long long)p.N * p.K * 2 > (3ll << 20)) p.raster_gm = 8;   // debug 20: row-major everywhere (A/B)
   }
   dim3 grid(t.tiles, 1, p.batch * t.splits);
 #define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
@@ -456,6 +462,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 #undef EA_LAUNCH_TR
   switch (t.kind) {
     case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
+#if EA_TOOLS
     case 2: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 0); break;
     case 3: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 0); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 0); break;
     case 4: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 2, 2, 3, 16, 0); else EA_LAUNCH_G2(256, 128, 2, 2, 3, 16, 0); break;
@@ -463,11 +470,14 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 6: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 1); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 1); break;
     case 7: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 3, 16, 1); else EA_LAUNCH_G2(128, 128, 2, 2, 3, 16, 1); break;
     case 8: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 1, 3, 32, 1); else EA_LAUNCH_G2(256, 128, 4, 1, 3, 32, 1); break;
+#endif
     case 9: if (t.bn == 160) EA_LAUNCH_G2(64, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(64, 128, 2, 2, 2, 16, 0); break;
+#if EA_TOOLS
     case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
     case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
     case 13: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 2); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 2); break;   // ping-pong
     case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
+#endif
     default: return EA_ERR_UNSUPPORTED;
   }
 #undef EA_LAUNCH_G2
@@ -523,6 +533,8 @@ extern "C" int ea_set_tuning(const ea_tuning* t) {
   else g_tune = ea_tuning{0, 0, 0, 0, 0, 0};
   return EA_OK;
 }
+
+extern "C" int ea_tools_build(void) { return EA_TOOLS; }
 
 extern "C" int ea_row_stats_parts(int N) { return N > 0 ? row_stat_parts(N) : 0; }
 

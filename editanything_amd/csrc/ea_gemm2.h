@@ -37,6 +37,14 @@
 #ifndef EA_EXP
 #define EA_EXP 0   // bit mask of compile-time experiments (tools/build_exp.sh builds side libraries; 0 in the product)
 #endif
+// EA_TOOLS = 1 (tools/build_exp.sh side libraries and the CPU emulation build of the tests; 0 in the product): compiles in
+// the K-loop / epilogue ablation selectors (EaGemmParams::debug) and the opt-in instantiations (launch_fast kinds 2-8,
+// 10-13).  The shipped library carries the two planned instantiations (128- / 64-row 2-stage tiles, each with the
+// register-direct epilogue forms) and the persistent kernel of ea_gemm3.h, and no debug selector reaches its kernels.
+#ifndef EA_TOOLS
+#define EA_TOOLS 0
+#endif
+#define EA_DBG(n) (EA_TOOLS && p.debug == (n))
 // Phase timestamps for tools/phase_times.py (EA_GEMM2_DEBUG=3): wave 0 / lane 0 of every workgroup stores the
 // constant-rate wall clock (100 MHz) at a few program points into the (otherwise unused) split-K workspace.
 #ifdef EA_EMU
@@ -44,7 +52,7 @@
 #else
 #define EA_STAMP(i)                                                                                   \
   do {                                                                                                \
-    if (p.debug == 3 && tid == 0)                                                                     \
+    if (EA_DBG(3) && tid == 0)                                                                     \
       reinterpret_cast<unsigned long long*>(p.partial)[(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = wall_clock64(); \
   } while (0)
 #endif
@@ -117,7 +125,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   const int kt_begin = split * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > nk_total) kt_end = nk_total;
-  const int nk = (p.debug == 2) ? 0 : kt_end - kt_begin;
+  const int nk = EA_DBG(2) ? 0 : kt_end - kt_begin;
 
   const ea_rsrc rs_a1 = ea_make_rsrc(p.a1 + batch * p.strideA);
   const ea_rsrc rs_a2 = ea_make_rsrc(p.a2 ? p.a2 + batch * p.strideA : p.a1);
@@ -426,12 +434,12 @@ void ea_gemm2_kernel(EaGemmParams p) {
     // for the texture path, then both for the matrix pipe).  Workgroups b and b + 256 normally share a CU (dispatch
     // is round-robin over XCDs, then CUs): delaying the second one by ~half an iteration lets them alternate
     // (measured +8..12 % on the 512-tile 64x64-level convolutions; a speed heuristic only, never correctness).
-    if (p.debug != 8 && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
+    if (!EA_DBG(8) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
 #endif
     for (int kt = 0; kt < nk; ++kt) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
       // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
-      if (p.debug != 12) __syncthreads();                               // debug 12: compute only, no barrier either
+      if (!EA_DBG(12)) __syncthreads();                               // debug 12: compute only, no barrier either
 #if (EA_EXP & 4) && !defined(EA_EMU)
       // experiment: the first K step's fragment reads go out BEFORE the next tile's DMA burst (whose ~9 x 60 clk of
       // VMEM issue then covers their LDS latency) instead of after it
@@ -441,8 +449,8 @@ void ea_gemm2_kernel(EaGemmParams p) {
       __builtin_amdgcn_sched_barrier(0);
       compute_tile(kt & 1, false, true);
 #else
-      if (kt + 1 < nk && p.debug != 11 && p.debug != 12) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
-      if (p.debug != 10) compute_tile(kt & 1);                         // debug 10: staging only
+      if (kt + 1 < nk && !EA_DBG(11) && !EA_DBG(12)) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
+      if (!EA_DBG(10)) compute_tile(kt & 1);                         // debug 10: staging only
 #endif
     }
   } else if (ILV == 2) {
@@ -539,7 +547,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     ea_raw_barrier();
     // one loop per group (no control-flow merges inside the K loop: a shared loop makes the fragment registers loop-
     // carried PHIs of both roles and hipcc spills ~36 registers into the loop); both execute two barriers per tile
-    const bool do_mfma = p.debug != 10, do_dma = p.debug != 11;   // ablation knobs (tools/gemm_bench --debug): staging only / compute only
+    const bool do_mfma = !EA_DBG(10), do_dma = !EA_DBG(11);   // ablation knobs (tools/gemm_bench --debug): staging only / compute only
     if (grp == 0) {
       for (int kt = 0; kt < nk; ++kt) {
         if (do_mfma) pp_mfma();                                 // slot A
@@ -608,7 +616,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   // memory latency of the epilogue is paid once per slab, not once per output vector (a per-vector load -> use -> store
   // chain measured 25 us per [32768 x 320] launch -- more than the whole K loop of the K = 320 linears).
   const EaEpilogue& e = p.epi;
-  if (p.debug == 1) {   // ablation: keep the accumulators live, write (almost) nothing
+  if (EA_DBG(1)) {   // ablation: keep the accumulators live, write (almost) nothing
     float sum = 0.0f;
 #pragma unroll
     for (int i = 0; i < MI; ++i)

@@ -57,13 +57,19 @@ def _aux_tag():
 def workspace(device):
     """Persistent fp32 scratch per (device, host thread, stream tag) -- split-K partials, GroupNorm partial sums: one
     for the main stream and one per concurrent side stream (`aux_workspace`).  Allocated once, before any HIP-graph
-    capture; ops on one stream use theirs serially.  Keyed by the host thread too, so two threads driving one GPU never
-    share scratch."""
+    capture; ops on one stream use theirs serially.  The buffers live in the calling thread's `threading.local`, so
+    two threads driving one GPU never share scratch and a thread's buffers are released with the thread (a pool of
+    short-lived server threads does not accumulate them).  A HIP graph captured on a thread bakes that thread's
+    buffer addresses in: keep the thread (or the tensors, `workspace(...)` returns them) alive as long as the graph."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (idx, threading.get_ident(), _aux_tag())
-    if key not in _ws:
-        _ws[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
-    return _ws[key]
+    store = getattr(_tls, "ws", None)
+    if store is None:
+        store = _tls.ws = {}
+    key = (idx, _aux_tag())
+    buf = store.get(key)
+    if buf is None:
+        buf = store[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+    return buf
 
 
 class aux_workspace:

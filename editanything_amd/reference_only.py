@@ -17,8 +17,11 @@ What is mixed, per patched module (names as in the reference):
     (UpBlock2D): FFT-magnitude mix with the banked feature, then AdaIN towards the reference's masked mean / variance
     inside the inpaint mask, blended the same way.
 Here the network runs on this package's kernels (NHWC fp16); the mixing itself is tensor arithmetic on small feature
-maps between launches (torch.fft + elementwise, fp32) -- an eager path, never captured in a HIP graph, off the measured
-path.  Tested against the reference's own patched forwards executed from source (oracle/ref_reference_only.py).
+maps between launches (torch.fft + elementwise, fp32), off the measured path.  The pipeline captures one whole
+reference-only step (write pass + read pass + sampler update) into a per-call HIP graph (pipeline._capture): nothing in
+here may synchronise or allocate differently on replay, which is why the mask selections (`torch.nonzero` synchronises)
+are computed for every level size when the object is built (`_prepare_masks`), not on first use.  Tested against the
+reference's own patched forwards executed from source (oracle/ref_reference_only.py).
 """
 import torch
 import torch.nn.functional as F
@@ -83,6 +86,7 @@ class ReferenceOnly:
         self.mode = None
         self.bank = {}
         self._sel = {}
+        self._prepare_masks()
         # ---- module selection (redefine_ref_model :895-1086)
         self.attn = set()
         if reference_attn:
@@ -162,10 +166,20 @@ class ReferenceOnly:
             self.controlnet.ref = None
         self.mode = None
 
+    def _prepare_masks(self):
+        """Mask selections for every feature-map size the networks can present (latent size / 1, 2, 4, 8), for both masks,
+        up front: `torch.nonzero` synchronises, and a size first seen inside a HIP-graph capture would abort it."""
+        h8, w8 = self.ref_mask.shape[-2:]
+        for mask in (self.ref_mask, self.inpaint_mask):
+            for f in (1, 2, 4, 8):
+                if h8 % f == 0 and w8 % f == 0 and mask.shape[2] % (h8 // f) == 0:
+                    self._mask_sel(mask, h8 // f, w8 // f)
+
     def _mask_sel(self, mask, h, w):
         """Nearest-neighbour resize of a latent-resolution mask to (h, w) (F.interpolate(scale_factor=1 / ratio), the
         reference's default mode) -> (mask [1, h, w, 1], flat indices of its non-zero positions)."""
-        key = (id(mask), h, w)
+        role = "ref" if mask is self.ref_mask else "inpaint"      # keyed by the mask's ROLE (ids get recycled)
+        key = (role, h, w)
         if key not in self._sel:
             ratio = mask.shape[2] / h
             m = F.interpolate(mask, scale_factor=1.0 / ratio)

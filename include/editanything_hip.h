@@ -123,6 +123,10 @@ typedef struct ea_tuning {
   int32_t debug;               /* K-loop / epilogue ablation selector */
 } ea_tuning;
 int ea_set_tuning(const ea_tuning* t);
+/* 1 when the library was built with -DEA_TOOLS=1 (side builds of tools/, the tests' CPU emulation build): the opt-in
+ * instantiations (variant 2-8, 10-13) and the `debug` ablation selectors exist; 0 in the shipped library, where forcing one
+ * of those variants returns EA_ERR_UNSUPPORTED and `debug` is ignored. */
+int ea_tools_build(void);
 
 /* library / device info */
 int ea_version(void);

@@ -20,9 +20,16 @@ import torch.nn.functional as F
 from emu_util import conv_src, epilogue, ptr, relerr
 
 
+TOOLS_ONLY_VARIANTS = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13}   # opt-in instantiations: EA_TOOLS builds only (ea_gemm2.h)
+
+
 def tune(kb, **fields):
-    """Contraction tuning of this thread through the explicit C-ABI setter (reset by the `kb` fixture's teardown)."""
+    """Contraction tuning of this thread through the explicit C-ABI setter (reset by the `kb` fixture's teardown).  The
+    shipped library does not carry the opt-in instantiations or the ablation selectors (`ea_tools_build() == 0`): tests
+    that force one are for the tools build (the CPU emulation build is one) and skip on the product library."""
     from editanything_amd import _lib
+    if (int(fields.get("variant", 0) or 0) in TOOLS_ONLY_VARIANTS or fields.get("debug")) and not kb.lib.ea_tools_build():
+        pytest.skip("opt-in instantiation / ablation selector: tools build only")
     assert _lib.set_tuning(kb.lib, **fields) == 0
 
 
@@ -1190,3 +1197,27 @@ def test_grouped_tile_order_wide_output(kb):
         outs.append(kb.down(out).copy())
     assert np.array_equal(outs[0], outs[1])
     assert relerr(outs[0], (t(A) @ t(W).T + t(bias)).numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("B,H", [(2, 24), (3, 8), (1, 40)])
+def test_groupnorm_statistics_query_matches_the_launch(kb, B, H):
+    """Round-2 advisor finding: for samples whose pixel count is an odd multiple of 64 (8x8, 24x24, 40x40) the query used
+    to promise partials that the launch -- a per-sample row vector needs every 128-row tile inside one sample -- then
+    refused.  Whatever the query answers now, the launch must agree with it."""
+    cin, cout, groups = 64, 320, 32
+    HW, M, K, cpg = H * H, B * H * H, 9 * cin, cout // groups
+    rows = kb.lib.ea_gemm_gn_stats_chunk_rows(M, cout, K, 1, HW, cpg)
+    x, W, bias, rv = f16(B, H, H, cin), f16(cout, K, scale=0.05), f32(cout), f32(B, cout)
+    y = kb.zeros((M, cout), np.float16)
+    src = conv_src(x)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, cout, K, 1))
+    if rows > 0:
+        part = kb.zeros((B, HW // rows, groups, 2), np.float32)
+        e = epilogue(y, bias=bias, rowvec=rv, rows_per_group=HW, gn_stats_out=part, gn_rows_per_sample=HW, gn_cpg=cpg)
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        yh = kb.down(y).astype(np.float64).reshape(B, HW // rows, rows, groups, cpg)
+        ref = np.stack([yh.sum((2, 4)), (yh * yh).sum((2, 4))], -1)
+        assert np.abs(kb.down(part).astype(np.float64) - ref).max() <= 1e-4 * max(ref[..., 1].max(), 1.0)
+    else:
+        e = epilogue(y, bias=bias, rowvec=rv, rows_per_group=HW)
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
