@@ -249,7 +249,7 @@ static int cu_count() {
 
 struct Plan3 {
   int use;        // 0: stay on ea_gemm2
-  int bn, splits, ktiles_per_split, ks, gm, trx;
+  int bn, splits, ktiles_per_split, ks, gm, trx, gn_rows;
   int epi_fast;
 };
 
@@ -274,7 +274,7 @@ static int plan3_splits(int tiles, int nk, long long MN, int allow_split) {
 }
 
 // Eligibility + plan of a launch on ea_gemm3 (the register-direct epilogue's conditions, batch 1).  `want`: 0 = the
-// automatic policy, 20 = forced with the automatic wave roles, 21 / 22 = forced m-split / k-split.
+// automatic policy, 20 = forced with the automatic wave roles, 21 / 22 / 23 = forced m-split / k-split / loader waves.
 static Plan3 plan3(const EaGemmParams& p, int want) {
   Plan3 t{};
   const EaEpilogue& e = p.epi;
@@ -300,11 +300,13 @@ static Plan3 plan3(const EaGemmParams& p, int want) {
   t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
   t.epi_fast = geglu ? 3 : 1;
   t.trx = ((e.ln_stats || e.row_stats_out || e.gn_stats_out) && t.splits == 1) ? 2 : 1;
+  const int ks_ = (want == 21) ? 1 : (want == 22) ? 2 : (want == 23) ? 0 : (t.ktiles_per_split >= 12 ? 2 : 1);
+  t.gn_rows = ks_ == 0 ? 64 : 32;               // rows a wave emits = rows per GroupNorm-statistics chunk
   if (e.gn_stats_out) {
     const int hw = e.gn_hw, cpg = e.gn_cpg;
-    if (hw <= 0 || cpg < 8 || (p.M % hw) || (hw % 32) || ((t.bn / 2) % cpg) || (p.N % t.bn) || (p.N % cpg) || hw / 32 > 128) return t;
+    if (hw <= 0 || cpg < 8 || (p.M % hw) || (hw % 128) || ((t.bn / 2) % cpg) || (p.N % t.bn) || (p.N % cpg) || hw / t.gn_rows > 128) return t;
   }
-  t.ks = (want == 21) ? 1 : (want == 22) ? 2 : (t.ktiles_per_split >= 12 ? 2 : 1);
+  t.ks = (want == 21) ? 1 : (want == 22) ? 2 : (want == 23) ? 0 : (t.ktiles_per_split >= 12 ? 2 : 1);
   // grouped tile order: an XCD's run of (items per round) / 8 tiles should cover about as many A row panels as W column
   // panels; with few tile columns take them all
   const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + t.bn - 1) / t.bn;
@@ -344,15 +346,17 @@ static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t
     auto kfn = ea_gemm3_kernel<BN_, TRX_, KS_>;                                       \
     const int smem = ea_gemm3_lds_bytes(BN_);                                         \
     ea_allow_big_lds(kfn, smem);                                                      \
-    EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);                           \
+    EA_LAUNCH(kfn, grid, dim3(KS_ == 0 ? 768 : 512, 1, 1), smem, stream, p);          \
   } while (0)
-  if (t.bn == 160) {
-    if (t.ks == 2) { if (t.trx == 2) EA_LAUNCH_G3(160, 2, 2); else EA_LAUNCH_G3(160, 1, 2); }
-    else { if (t.trx == 2) EA_LAUNCH_G3(160, 2, 1); else EA_LAUNCH_G3(160, 1, 1); }
-  } else {
-    if (t.ks == 2) { if (t.trx == 2) EA_LAUNCH_G3(128, 2, 2); else EA_LAUNCH_G3(128, 1, 2); }
-    else { if (t.trx == 2) EA_LAUNCH_G3(128, 2, 1); else EA_LAUNCH_G3(128, 1, 1); }
-  }
+#define EA_LAUNCH_G3K(BN_, TRX_)                                                      \
+  do {                                                                                \
+    if (t.ks == 2) EA_LAUNCH_G3(BN_, TRX_, 2);                                        \
+    else if (t.ks == 1) EA_LAUNCH_G3(BN_, TRX_, 1);                                   \
+    else EA_LAUNCH_G3(BN_, TRX_, 0);                                                  \
+  } while (0)
+  if (t.bn == 160) { if (t.trx == 2) EA_LAUNCH_G3K(160, 2); else EA_LAUNCH_G3K(160, 1); }
+  else { if (t.trx == 2) EA_LAUNCH_G3K(128, 2); else EA_LAUNCH_G3K(128, 1); }
+#undef EA_LAUNCH_G3K
 #undef EA_LAUNCH_G3
   int st = ea_launch_status();
   if (st == EA_OK && t.splits > 1) {
@@ -364,9 +368,9 @@ static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t
 
 static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
   {
-    const Plan3 t3 = plan3(p, (g_variant >= 20 && g_variant <= 22) ? g_variant : 0);
+    const Plan3 t3 = plan3(p, (g_variant >= 20 && g_variant <= 23) ? g_variant : 0);
     if (t3.use) return launch_fast3(p, t3, workspace, ws_bytes, stream);
-    if (g_variant >= 20 && g_variant <= 22) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
+    if (g_variant >= 20 && g_variant <= 23) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
   }
   Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
   p.splits = t.splits;
@@ -553,7 +557,7 @@ static EaGemmParams query_params(int M, int N, int K, int conv, int geglu32) {
 
 extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
-  if (g_variant >= 20 && g_variant <= 22) {
+  if (g_variant >= 20 && g_variant <= 23) {
     EaGemmParams q = query_params(M, N, K, 0, 0);
     static const float dummy = 0.0f;
     q.epi.ln_stats = &dummy;
@@ -565,13 +569,14 @@ extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
 
 extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
-  if (g_variant >= 20 && g_variant <= 22) {
+  if (g_variant >= 20 && g_variant <= 23) {
     EaGemmParams q = query_params(M, N, K, conv ? 1 : 0, 0);
     static float dummy = 0.0f;
     q.epi.gn_stats_out = &dummy;
     q.epi.gn_hw = rows_per_sample;
     q.epi.gn_cpg = cpg;
-    return plan3(q, g_variant).use ? 32 : 0;
+    const Plan3 t3 = plan3(q, g_variant);
+    return t3.use ? t3.gn_rows : 0;
   }
   Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
   return gn_stats_rows(t, M, N, rows_per_sample, cpg);

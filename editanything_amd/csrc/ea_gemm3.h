@@ -56,10 +56,10 @@
 constexpr int ea_gemm3_lds_bytes(int bn) { return EA_G3_STAGES * (128 + bn) * 128 + 2 * EA_G3_SPARE; }   // + the exchange overflow
 
 template <int BN, int TRX, int KS>
-__global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
-  constexpr int BM = 128, NW = 8;
+__global__ __launch_bounds__(KS == 0 ? 768 : 512) void ea_gemm3_kernel(EaGemmParams p) {
+  constexpr int BM = 128, NW = 8;                  // NW: waves that ISSUE the LDS-DMA (KS = 0: the eight loader waves)
   constexpr int WTN = BN / 2, NI = WTN / 16;
-  constexpr int MI = (KS == 2) ? 4 : 2;            // accumulator row tiles per wave (k-split: 64 rows, m-split: 32)
+  constexpr int MI = (KS == 1) ? 2 : 4;            // accumulator row tiles per wave (m-split: 32 rows, else 64)
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;   // 1-KiB LDS-DMA instructions per K tile
   constexpr int A_PW = A_INSTR / NW;                   // 2
@@ -67,16 +67,19 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
   constexpr int B_EXTRA = B_INSTR % NW;                // waves [0, B_EXTRA) issue B_PW pieces, the rest B_PW - 1 (0: all B_PW)
   constexpr int P_HI = A_PW + B_PW, P_LO = A_PW + (B_EXTRA ? B_PW - 1 : B_PW);
   static_assert(A_INSTR % NW == 0, "A rows divide evenly over the waves");
-  static_assert(KS == 1 || KS == 2, "wave roles");
+  static_assert(KS >= 0 && KS <= 2, "wave roles");
   EA_SMEM(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = ea_uniform(tid >> 6);
+  const int wave_all = ea_uniform(tid >> 6);
+  // KS = 0: waves 0..3 multiply (2 x 2, wave tile 64 x BN/2, both K steps), waves 4..11 only issue the LDS-DMA
+  const bool is_loader = KS == 0 && wave_all >= 4;
+  const int wave = is_loader ? wave_all - 4 : wave_all;        // index among the issuing waves / among the multiplying waves
   const int grp = (KS == 2) ? (wave >> 2) : 0;                 // k-split group
-  const int wm = (KS == 2) ? ((wave & 3) >> 1) : (wave >> 1);  // wave row: 64-row (k-split) / 32-row (m-split) units
+  const int wm = (KS == 1) ? (wave >> 1) : ((wave & 3) >> 1);  // wave row: 32-row (m-split) / 64-row units
   const int wn = wave & 1;
-  const bool p_hi = B_EXTRA != 0 && wave < B_EXTRA;            // this wave issues P_HI pieces per K tile
+  const bool p_hi = B_EXTRA != 0 && wave < B_EXTRA;            // this (issuing) wave issues P_HI pieces per K tile
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   const int nitems = tiles_m * tiles_n * p.splits;
@@ -262,8 +265,10 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
       for (int j = 0; j < NI; ++j) acc[i][j] = ea_mfma_16x16x32(fb[set][j], fa[set][i], acc[i][j]);
 #endif
   };
-  // pin "one fragment read per MFMA (pair)" where a step's reads and MFMAs share a basic block (guide T19): left alone
-  // hipcc sinks the reads to just before their first use and the matrix pipe waits out the LDS round trip
+  // pin "one fragment read per MFMA (pair)" for a step whose reads (of the NEXT step's fragments, into the other register
+  // set) and MFMAs share a basic block (guide T19).  Left alone hipcc sinks the reads BEHIND the MFMAs to reuse the
+  // current fragments' registers -- and every K tile then pays the whole LDS round trip in front of the barrier, all 8
+  // waves at once (first builds of this kernel: the loop WITHOUT any DMA ran at 36 % of the MFMA rate)
   auto pin_interleave = [&]() {
 #ifndef EA_EMU
     constexpr int MF = MI * NI;
@@ -284,8 +289,97 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
   //   then:                job q + 3 is issued into that slot;  job q is multiplied, job q + 1's first fragments are read
   // Items are the outer loop so that the accumulators / fragment registers are provably dead across the epilogue (a flat
   // loop with "if (first K tile) zero / read" keeps 150 registers alive through it and spills).
-  constexpr int ME = 2;                   // row tiles a wave emits
   char* spare = smem + EA_G3_STAGES * STAGE_BYTES;
+  if constexpr (KS == 0) {
+    // ---------------------------------------------------------------------------------- loader-wave roles (KS = 0)
+    // Measured on the MI355X (tools/probe_dma2/3, profiles/r03_probe_dma_*): ONE wave issues an LDS-DMA instruction
+    // (1 KiB) every 75-125 cycles at best, whatever it has outstanding -- 8-13 B/clk per wave; a CU reaches 64 B/clk with
+    // 8 waves issuing and 100-128 B/clk with 16.  A 128 x 160 x 64 K tile is 36 instructions: issued by the four waves
+    // that also multiply it (ea_gemm2) it takes ~1000 cycles of each wave's time against 640 cycles of MFMA work, which
+    // is where every earlier restructuring of that loop ended up.  Here eight EXTRA waves do nothing but issue (4-5
+    // instructions each per K tile, ~450 cycles) and the four multiplying waves -- one per SIMD -- never touch the
+    // memory pipe: barrier, fragment reads, 40 MFMAs.  One barrier per K tile for all twelve waves.
+    bool any = false;
+    {
+      int m0_, n0_, sp_, kt0_, nk_;
+      for (int r = 0; r < nrounds; ++r) any = any || (my_item(r, m0_, n0_, sp_, kt0_, nk_) && nk_ > 0);
+    }
+    if (!any) return;                       // (uniform over the workgroup)
+    if (is_loader) {
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) issue_next();
+      wait_job(0);
+      ea_raw_barrier();
+#pragma unroll 1
+      for (int q = 0; q < issued; ++q) {
+        wait_job(q + 1 < issued ? q + 1 : q);
+        ea_raw_barrier();
+        issue_next();
+      }
+      return;
+    }
+    ea_raw_barrier();                       // job 0 landed
+    int q = 0;
+#pragma unroll 1
+    for (int round = 0; round < nrounds; ++round) {
+      int m0, n0, split, kt0, nk;
+      if (!my_item(round, m0, n0, split, kt0, nk) || nk <= 0) continue;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      read_frags(q & (EA_G3_STAGES - 1), 0, 0);
+      const int emit_row0 = m0 + wm * 64;
+      float ln_mu[MI], ln_rs[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { ln_mu[i] = 0.0f; ln_rs[i] = 1.0f; }
+      if (TRX == 2 && p.epi.ln_stats) {
+        constexpr int CH = 8;
+        float s1[MI], s2[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { s1[i] = 0.0f; s2[i] = 0.0f; }
+        for (int pp0 = 0; pp0 < p.epi.ln_parts; pp0 += CH) {
+          f32x2 t2[CH][MI];
+#pragma unroll
+          for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              int m = emit_row0 + i * 16 + frow;
+              m = m < p.M ? m : p.M - 1;
+              int pp = pp0 + u;
+              pp = pp < p.epi.ln_parts ? pp : p.epi.ln_parts - 1;
+              t2[u][i] = *reinterpret_cast<const f32x2*>(p.epi.ln_stats + ((long long)pp * p.M + m) * 2);
+            }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const float keep = (pp0 + u < p.epi.ln_parts) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) { s1[i] += keep * t2[u][i][0]; s2[i] += keep * t2[u][i][1]; }
+          }
+        }
+        const float inv = 1.0f / (float)p.K;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const float mu = s1[i] * inv;
+          ln_mu[i] = mu;
+          ln_rs[i] = 1.0f / sqrtf(fmaxf(s2[i] * inv - mu * mu, 0.0f) + p.epi.ln_eps);
+        }
+      }
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt, ++q) {
+        ea_raw_barrier();                   // job q + 1 landed; every wave is past its reads of job q - 1's slot
+        read_frags(q & (EA_G3_STAGES - 1), 1, 1);
+        mfma_step(0);
+        pin_interleave();
+        read_frags((q + 1) & (EA_G3_STAGES - 1), 0, 0);
+        mfma_step(1);
+        pin_interleave();
+      }
+      ea_tr_epilogue<MI, NI, TRX, false>(p, acc, emit_row0, n0 + wn * WTN, m0, 0, split, ln_mu, ln_rs, spare, wave);
+    }
+    return;
+  }
+  constexpr int ME = 2;                   // row tiles a wave emits
 #if EA_G3_PROF && !defined(EA_EMU)
   unsigned long long g3t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long g3last = __builtin_readcyclecounter();
@@ -379,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
         G3T(2);
         read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 1);
         mfma_step(0);
+        pin_interleave();
         G3T(3);
         if (!early) issue_next();
         G3T(4);
@@ -392,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
         G3T(2);
         read_frags((q + 1) & (EA_G3_STAGES - 1), grp, 0);
         mfma_step(1);
+        pin_interleave();
         G3T(3);
         if (!early) issue_next();
         G3T(4);
@@ -412,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
         pin_interleave();
         read_frags((q + 1) & (EA_G3_STAGES - 1), 0, 0);
         mfma_step(1);
+        pin_interleave();
         G3T(3);
         if (!early) issue_next();
         G3T(4);
@@ -451,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void ea_gemm3_kernel(EaGemmParams p) {
         ea_raw_barrier();                   // reads retired (lgkmcnt(0) inside) before the regions are rewritten / restaged
       }
       ea_tr_epilogue<ME, NI, TRX, false>(p, fin, emit_row0, colbase, m0, 0, split, ln_mu, ln_rs, spare, wave);
-    } else {
+    } else if constexpr (KS == 1) {
       ea_tr_epilogue<ME, NI, TRX, false>(p, acc, emit_row0, colbase, m0, 0, split, ln_mu, ln_rs, spare, wave);
     }
     G3T(5);

@@ -1041,7 +1041,7 @@ def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------------------------
 # ea_gemm3.h: the persistent 8-wave kernel (tuning variant 21 = m-split wave roles, 22 = k-split groups + accumulator
-# exchange, 20 = the plan's own choice).  The emulated "device" has 4 CUs, so these shapes walk several rounds of the
+# exchange, 23 = four multiplying + eight loader waves, 20 = the plan's own choice).  The emulated "device" has 4 CUs, so these shapes walk several rounds of the
 # persistent tile loop, with the DMA stream running across tile boundaries.
 def _gemm_run(kb, A, W, bias, act, R, rv, rpg, variant, splits=0, scale=0.75, gb=0):
     M, K = A.shape
@@ -1064,7 +1064,7 @@ def _gemm_run(kb, A, W, bias, act, R, rv, rpg, variant, splits=0, scale=0.75, gb
     (256, 320, 768, 0, True, False, 3),      # split-K: 3 slices x 4 tiles, raw fp32 dump + reduce kernel
     (384, 480, 1024, 0, False, False, 0),    # the plan's own split choice, 16 K tiles
 ])
-@pytest.mark.parametrize("variant", [21, 22])
+@pytest.mark.parametrize("variant", [21, 22, 23])
 def test_persistent_kernel_gemm(kb, M, N, K, act, res, rowvec, splits, variant):
     A, W = f16(M, K), f16(N, K, scale=0.2)
     bias = f32(N)
@@ -1079,11 +1079,8 @@ def test_persistent_kernel_gemm(kb, M, N, K, act, res, rowvec, splits, variant):
     if res:
         ref = ref + t(R)
     assert relerr(got, ref.numpy()) < 2e-3
-    if variant == 21 and not splits and K < 1024:
-        # m-split waves multiply the same products in the same order as ea_gemm2's 128-row tiles: bit-identical
-        assert np.array_equal(got, base)
-    else:
-        assert np.abs(got.astype(np.float32) - base.astype(np.float32)).max() <= 2e-3 * np.abs(ref.numpy()).max()
+    # (same products as ea_gemm2's tiles; the fp32 summation order differs -- k-split groups, ea_gemm2's rotated K walk)
+    assert np.abs(got.astype(np.float32) - base.astype(np.float32)).max() <= 2e-3 * np.abs(ref.numpy()).max()
 
 
 @pytest.mark.parametrize("B,H,W,c1,c2,cout,ksize,stride,ups,emb,res", [
@@ -1093,7 +1090,7 @@ def test_persistent_kernel_gemm(kb, M, N, K, act, res, rowvec, splits, variant):
     (2, 8, 8, 64, 0, 160, 3, 1, 1, False, False),     # Upsample (nearest 2x inside the im2col)
     (2, 16, 16, 64, 64, 160, 1, 1, 0, False, False),  # 1x1 skip_connection over a concat
 ])
-@pytest.mark.parametrize("variant", [21, 22])
+@pytest.mark.parametrize("variant", [21, 22, 23])
 def test_persistent_kernel_conv(kb, B, H, W, c1, c2, cout, ksize, stride, ups, emb, res, variant):
     x1 = f16(B, H, W, c1)
     x2 = f16(B, H, W, c2) if c2 else None
@@ -1124,11 +1121,10 @@ def test_persistent_kernel_conv(kb, B, H, W, c1, c2, cout, ksize, stride, ups, e
     if res:
         ref = ref + t(R)
     assert relerr(outs[0], ref.numpy()) < 3e-3
-    if variant == 21:
-        assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0].astype(np.float32) - outs[1].astype(np.float32)).max() <= 3e-3 * np.abs(ref.numpy()).max()
 
 
-@pytest.mark.parametrize("variant", [21, 22])
+@pytest.mark.parametrize("variant", [21, 22, 23])
 def test_persistent_kernel_geglu_and_fold_and_stats(kb, variant):
     """GEGLU (32-row packing), the LayerNorm fold with row statistics from a producing launch, and GroupNorm partials (chunks
     of 32 rows), all through the persistent kernel."""
@@ -1167,7 +1163,7 @@ def test_persistent_kernel_geglu_and_fold_and_stats(kb, variant):
     HW, Mc, Kc, cpg = H * H, B * H * H, 9 * cin, cout // groups
     tune(kb, variant=int(variant), splits=1)
     rows = kb.lib.ea_gemm_gn_stats_chunk_rows(Mc, cout, Kc, 1, HW, cpg)
-    assert rows == 32
+    assert rows == (64 if variant == 23 else 32)
     nchunk = HW // rows
     xc, Wc, bc, rvc = f16(B, H, H, cin), f16(cout, Kc, scale=0.05), f32(cout), f32(B, cout)
     part = kb.zeros((B, nchunk, groups, 2), np.float32)

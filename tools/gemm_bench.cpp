@@ -119,6 +119,9 @@ static std::vector<Case> all_cases() {
   // whether the L2 / fabric channel interleave penalises those strides ("--cases stride")
   g(2048, 1280, 1344, 0, 0);  g(2048, 1280, 5184, 0, 1);  g(8192, 640, 2624, 0, 1);
   for (size_t i = v.size() - 3; i < v.size(); ++i) v[i].name += " stride";
+  // L2-resident operands (2 x 2 MB) with many tiles: what does the DMA stream deliver when nothing misses? ("--cases l2fit")
+  g(4096, 4096, 256, 0, 0);  g(2048, 2048, 512, 0, 0);
+  for (size_t i = v.size() - 2; i < v.size(); ++i) v[i].name += " l2fit";
   return v;
 }
 
@@ -198,7 +201,7 @@ int main(int argc, char** argv) {
   HIP_CHECK(hipEventCreate(&e1));
 
   for (auto& c : all_cases()) {
-    if (cases_sel == "all" && (c.flops > 3e11 || c.name.find("stride") != std::string::npos)) continue;   // cubes / probes: by name only
+    if (cases_sel == "all" && (c.flops > 3e11 || c.name.find("stride") != std::string::npos || c.name.find("l2fit") != std::string::npos)) continue;   // cubes / probes: by name only
     if (cases_sel != "all") {
       if (cases_sel == "gemm" ? c.conv != 0 : cases_sel == "conv" ? c.conv != 1 : c.name.find(cases_sel) == std::string::npos) continue;
     }

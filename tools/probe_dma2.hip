@@ -27,7 +27,7 @@ __device__ __forceinline__ unsigned lane_off(int pat, int l, unsigned pitch) {
 }
 
 template <int DEPTH>
-__global__ __launch_bounds__(512) void dma_probe(const char* src, int pat, unsigned pitch, int rows_per_wg, int iters, unsigned long long* cyc, int shared) {
+__global__ __launch_bounds__(1024) void dma_probe(const char* src, int pat, unsigned pitch, int rows_per_wg, int iters, unsigned long long* cyc, int shared) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nw = blockDim.x >> 6;
@@ -58,35 +58,35 @@ __global__ __launch_bounds__(512) void dma_probe(const char* src, int pat, unsig
   if (lane == 0 && wave == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+template <int DEPTH>
+static void run(const char* src, unsigned long long* cyc, int nwaves, int pat, unsigned pitch, int shared) {
+  if (nwaves * DEPTH > 144) return;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipFuncSetAttribute((const void*)dma_probe<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, nwaves * DEPTH * 1024));
+  const int rows = shared ? 288 : 128, iters = 2048 / DEPTH, grid = 256;
+  dma_probe<DEPTH><<<grid, nwaves * 64, nwaves * DEPTH * 1024>>>(src, pat, pitch, rows, 4, cyc, shared);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  dma_probe<DEPTH><<<grid, nwaves * 64, nwaves * DEPTH * 1024>>>(src, pat, pitch, rows, iters, cyc, shared);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(256); CK(hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost));
+  double c = 0; for (auto v : h) c += v; c /= 256;
+  const double instr = (double)iters * DEPTH * nwaves;
+  printf("{\"shared\": %d, \"waves\": %d, \"outstanding_per_wave\": %d, \"pattern\": %d, \"cycles_per_instr_per_wave\": %.1f, \"bytes_per_clk_per_cu\": %.1f, \"in_flight_KB_per_cu\": %d, \"implied_latency_cycles\": %.0f, \"chip_TB_s\": %.2f}\n",
+         shared, nwaves, DEPTH, pat, c / (iters * DEPTH), instr * 1024 / c, nwaves * DEPTH, (double)nwaves * DEPTH * 1024 / (instr * 1024 / c), (double)grid * instr * 1024 / (ms * 1e-3) / 1e12);
+}
+
 int main() {
   const size_t bytes = (size_t)1 << 30;
   char* src; CK(hipMalloc(&src, bytes)); CK(hipMemset(src, 1, bytes));
   unsigned long long* cyc; CK(hipMalloc(&cyc, 256 * 8));
-  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  constexpr int DEPTH = 8;
-  CK(hipFuncSetAttribute((const void*)dma_probe<DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * DEPTH * 1024));
-  const char* names[10] = {"1 KiB contiguous", "8 rows x 128 B in order", "8x128 16-B XOR (r>>1)", "8x128 16-B XOR (all rows differ)", "8x128 32-B-granular XOR",
-                           "8x128 64-B-granular XOR", "16 rows x 64 B in order", "16x64 16-B XOR", "4 rows x 256 B in order", "8x128 chunks reversed"};
-  for (int shared : {1}) for (int nwaves : {8, 4}) {
-    for (unsigned pitch : {2560u, 640u}) {
-      for (int pat = 0; pat < 10; ++pat) {
-        const int rows = 288;             // a 128 + 160 row panel pair per workgroup
-        const int iters = 256;
-        const int grid = 256;
-        if ((size_t)grid * rows * pitch > bytes) continue;
-        dma_probe<DEPTH><<<grid, nwaves * 64, nwaves * DEPTH * 1024>>>(src, pat, pitch, rows, 4, cyc, shared);
-        CK(hipDeviceSynchronize());
-        CK(hipEventRecord(e0));
-        dma_probe<DEPTH><<<grid, nwaves * 64, nwaves * DEPTH * 1024>>>(src, pat, pitch, rows, iters, cyc, shared);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        std::vector<unsigned long long> h(256); CK(hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost));
-        double c = 0; for (auto v : h) c += v; c /= 256;
-        const double instr = (double)iters * DEPTH * nwaves;          // per workgroup (= per CU)
-        printf("{\"shared\": %d, \"waves\": %d, \"pitch\": %u, \"pattern\": \"%s\", \"cycles_per_instr_per_cu\": %.1f, \"bytes_per_clk_per_cu\": %.1f, \"chip_TB_s\": %.2f}\n", shared, nwaves, pitch,
-               names[pat], c / instr, instr * 1024 / c, (double)grid * instr * 1024 / (ms * 1e-3) / 1e12);
-      }
+  // shared = 1: the 32 CUs of an XCD read ONE panel (every L2 line is requested 32 times); shared = 0 with a small private
+  // panel per workgroup (64 rows x 640 B = 40 KB, 1.3 MB per XCD: L2 resident, every line requested by ONE CU)
+  for (int shared : {1, 0})
+    for (int nwaves : {4, 8, 16}) {
+      run<8>(src, cyc, nwaves, 2, 640, shared);
+      run<16>(src, cyc, nwaves, 2, 640, shared);
     }
-  }
   return 0;
 }
