@@ -56,6 +56,9 @@ SIGNATURES = {
     "ea_device_info": (_i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _i]),
     "ea_set_tuning": (_i, [C.POINTER(Tuning)]),
     "ea_tools_build": (_i, []),
+    "ea_sam_vo_perm": (_i, [_i]),
+    "ea_sam_i2t_f16": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "ea_sam_upscale_tail_f16": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ea_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_row_stats_parts": (_i, [_i]),
     "ea_gemm_ln_fold_ok": (_i, [_i, _i, _i]),
@@ -76,6 +79,7 @@ SIGNATURES = {
     "ea_sam_window_attn_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _ll, _f, _vp, _vp, _vp]),
     "ea_relpos_tables_f16": (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _vp, _vp]),
     "ea_sam_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "ea_sam_mask_postprocess_indexed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "ea_softmax_rows_f32_f16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ea_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "ea_nchw_f32_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),

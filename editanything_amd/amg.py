@@ -27,6 +27,9 @@ import torch.nn.functional as F
 
 from . import ops
 
+DECODE_BATCH = 1024  # prompts per decoder call (keys [1024, 4096, 256] fp16 = 2 GB, ~13 GB of activations in all: the
+                     # whole 32 x 32 grid in one call; results do not depend on it)
+
 AMG_DEFAULTS = dict(points_per_side=32, points_per_batch=64, pred_iou_thresh=0.88, stability_score_thresh=0.95,
                     stability_score_offset=1.0, box_nms_thresh=0.7, mask_threshold=0.0)
 
@@ -154,8 +157,9 @@ class SamPromptDecoder:
     def _ln(self, x, wb, eps=1e-5):
         return F.layer_norm(x, (x.shape[-1],), wb[0], wb[1], eps)
 
-    def predict_masks(self, image_tokens, emb_hw, sparse, multimask_output=True):
-        """image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
+    def predict_masks_unfused(self, image_tokens, emb_hw, sparse, multimask_output=True):
+        """(The round-1/2 formulation: kept as the A/B reference of `predict_masks`, tests/test_amg.py.)
+        image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
         -> low-res mask logits fp32 [B, 3|1, 4h, 4w], iou predictions fp32 [B, 3|1]."""
         B, C = sparse.shape[0], self.C
         h, w = emb_hw
@@ -216,6 +220,116 @@ class SamPromptDecoder:
         iou = self._mlp3(self.iou_head, iou_tok)
         sl = slice(1, None) if multimask_output else slice(0, 1)
         return masks[:, sl], iou[:, sl]
+
+    # ---- the image-token side restated per token (csrc/ea_sam.hip): what crosses the ABI per block
+    def _heads(self, a):
+        """An _Attn module's projections as per-head blocks: Wq/Wk/Wv [h, d, C], biases [h, d], Wo [C, h, d]."""
+        if not hasattr(a, "_blocks"):
+            h, Ci = self.heads, a.internal
+            d = Ci // h
+            a._blocks = dict(d=d, wq=a.w["q"].float().reshape(h, d, -1), wk=a.w["k"].float().reshape(h, d, -1),
+                             wv=a.w["v"].float().reshape(h, d, -1), bq=a.b["q"].reshape(h, d), bk=a.b["k"].reshape(h, d),
+                             bv=a.b["v"].reshape(h, d), wo=a.wo.float().reshape(-1, h, d))
+        return a._blocks
+
+    def _t2i_folded(self, a, q_in, kp, k):
+        """Token -> image cross attention with PER-PROMPT keys, without projecting the image side: scores = G (keys + pe)^T
+        with G[h, j] = Wk_h^T q_hj (the key bias is constant over the image tokens and drops out of their softmax), output
+        = Wv_h (P keys) + bv_h.  kp / k fp16 [B, T, C]; q_in fp32 [B, 7, C] -> fp32 [B, 7, C] (before the residual)."""
+        bl = self._heads(a)
+        B, n, Cc = q_in.shape
+        h, d, T = self.heads, bl["d"], k.shape[-2]
+        qh = (F.linear(q_in, a.w["q"].float(), a.b["q"])).reshape(B, n, h, d)
+        G = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_in.device)
+        G[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", qh, bl["wk"]).half()
+        if k.dim() == 2:
+            # block 0: ONE image-token tensor for every prompt -- two plain contractions over all B * 64 score rows
+            S = ops.gemm(G.reshape(B * 64, Cc), kp, out_dtype=torch.float32).reshape(B, 64, T)
+            P = ops.softmax_rows(S, 1.0 / math.sqrt(d))
+            ctx = ops.gemm(P.reshape(B * 64, T), k.t().contiguous()).float().reshape(B, h, 8, Cc)[:, :, :n]
+        else:
+            S = torch.empty((B, 64, T), dtype=torch.float32, device=q_in.device)
+            ops.gemm_batched(G, kp, S, 64, T, Cc, B, 64 * Cc, T * Cc, 64 * T)
+            P = ops.softmax_rows(S, 1.0 / math.sqrt(d))                               # fp16 [B, 64, T]
+            ctx = torch.bmm(P, k).float().reshape(B, h, 8, Cc)[:, :, :n]              # [B, h, 7, C]
+        o = torch.einsum("bhjc,hdc->bjhd", ctx, bl["wv"]) + bl["bv"]
+        return F.linear(o.reshape(B, n, h * d), a.wo.float(), a.bo)
+
+    def _i2t_fused(self, a, q_pe, q_val, kp, k, key_pe, norm, B, want_kp):
+        """Image -> token cross attention + residual + norm4, one pass (ops.sam_i2t).  q_pe = queries + point embedding
+        (the attention's keys), q_val = queries (its values), fp32 [B, 7, C]; kp / k fp16 [T, C] or [B, T, C]."""
+        bl = self._heads(a)
+        n, Cc = q_pe.shape[1], q_pe.shape[2]
+        h, d = self.heads, bl["d"]
+        scale = 1.0 / math.sqrt(d)
+        kh = F.linear(q_pe, a.w["k"].float(), a.b["k"]).reshape(B, n, h, d)
+        vh = F.linear(q_val, a.w["v"].float(), a.b["v"]).reshape(B, n, h, d)
+        g2 = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_pe.device)
+        g2[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", kh, bl["wq"]).half()
+        cb = torch.full((B, h, 8), -1e30, dtype=torch.float32, device=q_pe.device)
+        cb[:, :, :n] = torch.einsum("bjhd,hd->bhj", kh, bl["bq"]) * scale
+        # vo[b, c, s] = Wo_h v_hj for the score column (h, j) = perm[s] that storage position s holds: gather the SMALL
+        # operands into that order ([B, 64, d] values, [C, 64, d] weights), one contraction writes the layout the kernel reads
+        vpad = torch.zeros((B, h, 8, d), dtype=torch.float32, device=q_pe.device)
+        vpad[:, :, :n] = vh.permute(0, 2, 1, 3)
+        perm = self._vo_perm()
+        v_s = vpad.reshape(B, 64, d)[:, perm]                              # [B, 64, d]
+        wo_s = bl["wo"][:, perm // 8]                                      # [C, 64, d]
+        vo = torch.einsum("bsd,csd->bcs", v_s, wo_s).half().contiguous()
+        return ops.sam_i2t(kp, k, key_pe, g2.reshape(B, 64, Cc), cb.reshape(B, 64), vo, a.bo, norm[0], norm[1], 1e-5, scale, B, want_kp)
+
+    def _vo_perm(self):
+        if not hasattr(self, "_perm"):
+            self._perm = ops.sam_vo_perm(self.device)
+        return self._perm
+
+    def predict_masks(self, image_tokens, emb_hw, sparse, multimask_output=True):
+        """image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
+        -> low-res mask logits fp32 [B, 3|1, 4h, 4w], iou predictions fp32 [B, 3|1].
+
+        segment_anything's MaskDecoder.predict_masks / TwoWayTransformer (third party).  The image side ([B, 4096, 256]
+        per block) is touched in as few passes as the arithmetic allows: the image -> token attention + residual + norm4
+        of a block is one fused kernel, the token -> image attention folds the key / value projections into the 7-token
+        side (no projection of the image tokens at all), and everything after the first transposed conv is one kernel."""
+        if sparse.shape[1] + self.out_tokens.shape[0] > 7:
+            return self.predict_masks_unfused(image_tokens, emb_hw, sparse, multimask_output)   # > 2 prompt tokens: 8 score columns per head
+        B, C = sparse.shape[0], self.C
+        h, w = emb_hw
+        T = h * w
+        key_pe = self.dense_pe(emb_hw)                                   # [T, C] fp16
+        point_emb = torch.cat([self.out_tokens[None].expand(B, -1, -1), sparse], dim=1)   # fp32 [B, n <= 7, C]
+        queries = point_emb
+        k, kp = image_tokens, (image_tokens.float() + key_pe.float()).half()               # shared by every prompt in block 0
+        for li, L in enumerate(self.layers):
+            a = L["self_attn"]
+            if li == 0:
+                q16 = queries.half()
+                queries = F.linear(a.core(a.proj("q", q16), a.proj("k", q16), a.proj("v", q16)).float(), a.wo.float(), a.bo)
+            else:
+                q16 = (queries + point_emb).half()
+                att = a.core(a.proj("q", q16), a.proj("k", q16), a.proj("v", queries.half()))
+                queries = queries + F.linear(att.float(), a.wo.float(), a.bo)
+            queries = self._ln(queries, L["norms"][0])
+            att = self._t2i_folded(L["t2i"], queries + point_emb, kp, k)
+            queries = self._ln(queries + att, L["norms"][1])
+            m = F.linear(F.relu(F.linear(queries, L["w1"].float(), L["b1"])), L["w2"].float(), L["b2"])
+            queries = self._ln(queries + m, L["norms"][2])
+            k, kp = self._i2t_fused(L["i2t"], queries + point_emb, queries, kp, k, key_pe, L["norms"][3], B, True)
+        att = self._t2i_folded(self.final, queries + point_emb, kp, k)
+        queries = self._ln(queries + att, self.norm_final)
+        iou_tok, mask_toks = queries[:, 0], queries[:, 1:1 + len(self.hyper)]
+        hyper = torch.stack([self._mlp3(self.hyper[i], mask_toks[:, i]) for i in range(len(self.hyper))], dim=1).contiguous()
+        nh = len(self.hyper)
+        m0, nm = (1, nh - 1) if multimask_output else (0, 1)             # MaskDecoder.forward's slice, written densely
+        masks = torch.empty((B, nm, 4 * h, 4 * w), dtype=torch.float32, device=k.device)
+        step = max(1, (1 << 30) // (T * C * 2))                          # operands of one launch stay under the 2-GiB buffer range
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            u0 = ops.gemm(k[b0:b1].reshape((b1 - b0) * T, C), self.up0_w, self.up0_b)              # [b*T, 4*c0]
+            ops.sam_upscale_tail(u0.reshape((b1 - b0) * T * 4, self.c0), self.up_ln[0], self.up_ln[1], 1e-6, self.up1_w, self.up1_b,
+                                 hyper[b0:b1].contiguous(), b1 - b0, h, w, m0, nm, out=masks[b0:b1])
+        iou = self._mlp3(self.iou_head, iou_tok)
+        return masks, iou[:, m0:m0 + nm]
 
     def image_tokens(self, embedding_nchw):
         """Encoder output [1, C, h, w] -> decoder image tokens (embedding + no-mask dense prompt) fp16 [h*w, C]."""
@@ -338,34 +452,40 @@ class SamAutomaticMaskGenerator:
         (H, W), (in_h, in_w) = st["orig"], st["inp"]
         pts_all = build_point_grid(c["points_per_side"]) * np.array([[W, H]])
         crop_box = [0, 0, W, H]
-        keep = dict(masks=[], iou=[], pts=[], stab=[], boxes=[])
+        # Two phases.  (1) Every prompt is decoded and its three candidates are filtered on numbers only: predicted IoU,
+        # then the stability score / box of the mask AT THE ORIGINAL RESOLUTION from a statistics-only post-processing
+        # pass (no mask is written: 3072 full-resolution masks per image were 0.8 GB of byte stores).  (2) After the box
+        # NMS the masks of the surviving records alone are written, from their kept low-resolution logits -- the same
+        # kernel, so the same pixels as a one-pass run.  `points_per_batch` is upstream's memory knob and does not change
+        # any result (prompts are independent): the decoder runs DECODE_BATCH prompts at a time whatever it says.
         scale = torch.tensor([in_w / W, in_h / H], device=dev)
-        for s in range(0, len(pts_all), c["points_per_batch"]):
-            p = torch.as_tensor(pts_all[s:s + c["points_per_batch"]], dtype=torch.float32, device=dev)
+        step = max(int(c["points_per_batch"]), DECODE_BATCH)
+        lows, ious, ptss = [], [], []
+        for s in range(0, len(pts_all), step):
+            p = torch.as_tensor(pts_all[s:s + step], dtype=torch.float32, device=dev)
             sparse = dec.embed_points((p * scale)[:, None, :], torch.ones(len(p), 1))
             low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, True)
-            low, iou = low.flatten(0, 1), iou.flatten(0, 1)
-            pp = p.repeat_interleave(3, dim=0)
-            # the predicted-IoU filter does not depend on the upsampled mask: apply it first, then post-process only
-            # the survivors -- resize to the original resolution, threshold, stability counts and box in one pass
-            k = iou > c["pred_iou_thresh"]
-            low, iou, pp = low[k], iou[k], pp[k]
-            if low.shape[0] == 0:
-                continue
-            mb, stats = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"])
-            stab = stats[:, 0] / stats[:, 1]
-            k = stab >= c["stability_score_thresh"]
-            mb, iou, pp, stab, stats = mb[k].bool(), iou[k], pp[k], stab[k], stats[k]
-            boxes = torch.where((stats[:, 4:5] < 0), torch.zeros_like(stats[:, 2:6]), stats[:, 2:6])
-            k = ~is_box_near_crop_edge(boxes, crop_box, [0, 0, W, H])
-            keep["masks"].append(mb[k]); keep["iou"].append(iou[k]); keep["pts"].append(pp[k])
-            keep["stab"].append(stab[k]); keep["boxes"].append(boxes[k])
-        if not keep["iou"]:
+            lows.append(low.flatten(0, 1)); ious.append(iou.flatten(0, 1)); ptss.append(p.repeat_interleave(3, dim=0))
+        low = lows[0] if len(lows) == 1 else torch.cat(lows)          # the candidates' logits stay where the decoder wrote them:
+        iou = ious[0] if len(ious) == 1 else torch.cat(ious)          # every filter below works on an index list
+        ppts = ptss[0] if len(ptss) == 1 else torch.cat(ptss)
+        idx = torch.nonzero(iou > c["pred_iou_thresh"]).reshape(-1)
+        if idx.numel() == 0:
             return []
-        masks = torch.cat(keep["masks"]); iou = torch.cat(keep["iou"]); ppts = torch.cat(keep["pts"])
-        stab = torch.cat(keep["stab"]); boxes = torch.cat(keep["boxes"])
+        _, stats = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"],
+                                            want_masks=False, index=idx.int())
+        stab = stats[:, 0] / stats[:, 1]
+        boxes = torch.where((stats[:, 4:5] < 0), torch.zeros_like(stats[:, 2:6]), stats[:, 2:6])
+        k = (stab >= c["stability_score_thresh"]) & ~is_box_near_crop_edge(boxes, crop_box, [0, 0, W, H])
+        idx, stab, boxes = idx[k], stab[k], boxes[k]
+        if idx.numel() == 0:
+            return []
+        iou, ppts = iou[idx], ppts[idx]
         order = nms(boxes, iou, c["box_nms_thresh"]).to(dev)
-        masks, iou, ppts, stab, boxes = masks[order], iou[order], ppts[order], stab[order], boxes[order]
+        idx, iou, ppts, stab, boxes = idx[order], iou[order], ppts[order], stab[order], boxes[order]
+        masks, _ = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"],
+                                            index=idx.int())
+        masks = masks.bool()
         areas = masks.flatten(1).sum(1).cpu().tolist()
         m_np, iou_l, pts_l, stab_l, box_l = masks.cpu().numpy(), iou.cpu().tolist(), ppts.cpu().tolist(), stab.cpu().tolist(), boxes.cpu().tolist()
         return [dict(segmentation=m_np[i], area=int(areas[i]), bbox=[box_l[i][0], box_l[i][1], box_l[i][2] - box_l[i][0],

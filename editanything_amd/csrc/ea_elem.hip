@@ -232,6 +232,7 @@ extern "C" int ea_gather_add_rows_f32(float* x, const void* src, const int* rows
 // resident) low-res logits and only the 1-byte mask is written.  Integer atomics -> deterministic.
 struct MaskPostParams {
   const float* low;
+  const int* index;      // optional: mask slot -> index into `low`
   unsigned char* mask;
   int* stats;   // [Nm][6]: inter, union, xmin, ymin, xmax, ymax (caller-initialised to 0, 0, W, H, -1, -1)
   int lh, lw, S, in_h, in_w, H, W;
@@ -269,13 +270,19 @@ __device__ __forceinline__ void ea_atomic_max_i(int* p, int v) {
 #endif
 }
 
+// One thread = one output pixel at a time (grid-stride over the mask): both bilinear resizes evaluated analytically from the
+// low-resolution logits, 16 taps that hit L1.  (Round 3 tried staging the four low-resolution rows of an output row in LDS --
+// two barriers per row for 512 pixels: 3x SLOWER than the scattered global reads it replaced; reverted.)  `index`
+// (optional) selects the masks to process out of the low-resolution tensor, `mask` may be NULL (statistics only): the
+// generator filters on the statistics and never copies logits or writes masks it will drop.
 __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
   EA_SMEM(smem);
   int* red = reinterpret_cast<int*>(smem);   // [256][6]
   const int tid = threadIdx.x;
-  const int m = blockIdx.y;
+  const int slot = blockIdx.y;
+  const int m = p.index ? p.index[slot] : slot;
   const float* low = p.low + (long long)m * p.lh * p.lw;
-  unsigned char* out = p.mask + (long long)m * p.H * p.W;
+  unsigned char* out = p.mask ? p.mask + (long long)slot * p.H * p.W : nullptr;
   const float s1y = (float)p.lh / (float)p.S, s1x = (float)p.lw / (float)p.S;
   const float s2y = (float)p.in_h / (float)p.H, s2x = (float)p.in_w / (float)p.W;
   int inter = 0, uni = 0, xmin = p.W, ymin = p.H, xmax = -1, ymax = -1;
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
     }
     const float v = (1.0f - ly) * ((1.0f - lx) * up[0][0] + lx * up[0][1]) + ly * ((1.0f - lx) * up[1][0] + lx * up[1][1]);
     const bool on = v > p.thr;
-    out[i] = on ? 1 : 0;
+    if (out) out[i] = on ? 1 : 0;
     inter += (v > p.thr + p.off) ? 1 : 0;
     uni += (v > p.thr - p.off) ? 1 : 0;
     if (on) {
@@ -325,21 +332,30 @@ __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
       else if (tid < 4) acc = v < acc ? v : acc;
       else acc = v > acc ? v : acc;
     }
-    int* dst = p.stats + m * 6 + tid;
+    int* dst = p.stats + slot * 6 + tid;
     if (tid < 2) ea_atomic_add_i(dst, acc);
     else if (tid < 4) ea_atomic_min_i(dst, acc);
     else ea_atomic_max_i(dst, acc);
   }
 }
 
+extern "C" int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
+                                               int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
+                                               int* stats, void* stream);
 extern "C" int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
                                        int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
                                        void* stream) {
-  if (!low_res || !mask || !stats) return EA_ERR_BAD_ARG;
+  return ea_sam_mask_postprocess_indexed(low_res, nullptr, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, offset, mask, stats, stream);
+}
+
+extern "C" int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
+                                               int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
+                                               int* stats, void* stream) {
+  if (!low_res || !stats) return EA_ERR_BAD_ARG;   // mask == NULL: statistics only (no mask is written)
   if (n_masks <= 0 || lh <= 0 || lw <= 0 || img_size <= 0 || in_h <= 0 || in_w <= 0 || H <= 0 || W <= 0) return EA_ERR_BAD_SHAPE;
-  if (in_h > img_size || in_w > img_size || (long long)H * W > 0x3fffffffLL) return EA_ERR_BAD_SHAPE;
+  if (in_h > img_size || in_w > img_size || (long long)H * W > 0x3fffffffLL || lw > 4096) return EA_ERR_BAD_SHAPE;
   MaskPostParams p;
-  p.low = low_res; p.mask = mask; p.stats = stats;
+  p.low = low_res; p.index = index; p.mask = mask; p.stats = stats;
   p.lh = lh; p.lw = lw; p.S = img_size; p.in_h = in_h; p.in_w = in_w; p.H = H; p.W = W;
   p.thr = threshold; p.off = offset;
   int bx = (H * W + 256 * 8 - 1) / (256 * 8);      // ~8 pixels per thread

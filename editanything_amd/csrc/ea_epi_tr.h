@@ -13,6 +13,7 @@
 // `scratch`: >= (waves) * 288 bytes of LDS no DMA targets (GroupNorm bins); SYNC = the caller needs a workgroup barrier
 // before that LDS is free.
 #pragma once
+#include "ea_gemm.h"
 #include "ea_prims.h"
 
 template <int MI, int NI, int TRX, bool SYNC>

@@ -2,7 +2,7 @@
 // MFMA, buffer descriptors + LDS-DMA (buffer_load ... lds), counted vmcnt waits, raw barriers, v_permlane16_swap and the
 // LDS row swizzle.  Under -DEA_EMU (CPU test-suite only) the same names execute on the host emulator.
 #pragma once
-#include "ea_gemm.h"
+#include "ea_platform.h"
 
 #define EA_OOB 0xFFFFFFF0u  // per-lane byte offset beyond any descriptor: the DMA writes zeros
 #define EA_BUF_BYTES 0x80000000u

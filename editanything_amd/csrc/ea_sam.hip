@@ -1,0 +1,318 @@
+// ea_sam.hip -- the image-token side of SAM's mask decoder as two fused gfx950 kernels (round 3).
+//
+// Reference call sites: `SamAutomaticMaskGenerator(sam).generate(image)` (sam2image.py:71,118; editany_lora.py:523) and
+// `SamPredictor.predict` (editany_lora.py:527-543); the decoder itself is segment_anything's MaskDecoder / TwoWayTransformer
+// (third party, un-vendored: SURVEY.md appendix C).  One image = 1024 point prompts x 4096 image tokens x 256 channels: the
+// image side of the decoder is a stream of [B, 4096, 256] fp16 tensors (2 MB per prompt), and what it costs is passes
+// over them.  Restated so that each pass does all the arithmetic that is local to a token:
+//
+//  * ea_sam_i2t_f16 -- one TwoWayAttentionBlock's "image -> token" cross attention + residual + LayerNorm (norm4):
+//        keys <- LN(keys + softmax_j((keys + pe) Wq k_j) v_j Wo + bo)           (7 tokens j, 8 heads)
+//    The 7-token side is folded into two small per-prompt matrices on the host side of the ABI: scores = (keys + pe) G2^T
+//    + c with G2[h*8 + j] = Wq_h^T k_hj (a row of 256), and the attention output = P VO with VO[h*8 + j] = Wo_h v_hj.
+//    Per token: a [256] x [256 x 64] product, eight 7-way softmaxes, a [64] x [64 x 256] product, residual, LayerNorm --
+//    all in registers; the tensor is read once (twice: keys + pe as the operand, keys as the residual) and written once
+//    (twice when the next block wants keys + pe too).  The unfused form runs a [B*4096 x 256 x 128] projection, an
+//    attention call, a [B*4096 x 128 x 256] projection and a LayerNorm pass over the same tensor.
+//  * ea_sam_upscale_tail_f16 -- output_upscaling's LayerNorm2d + GELU + second transposed conv + GELU + the product with
+//    the hypernetwork outputs: from the first transposed conv's [B*4096*4, 64] rows straight to the [B, 4, 256, 256] mask
+//    logits (three full passes and a batched product less).
+//
+// MFMA layout (ea_prims.h): operands swapped (D^T = W A^T), so a lane holds 4 consecutive output columns of one row; two
+// 16-column tiles pair up through v_permlane16_swap into 8 consecutive columns per lane.  In ea_sam_i2t the score columns
+// are laid out [head][8] (7 tokens + one pad column): after the pairing a lane holds exactly ONE head's scores, the softmax
+// is lane-local, and the packed probabilities ARE the A fragment of the second product (whose weight rows the host
+// stores in the matching order -- `ea_sam_vo_perm`).
+#include "ea_prims.h"
+#include "../../include/editanything_hip.h"
+
+namespace {
+
+struct SamI2tParams {
+  const f16* kp; long long kp_sb;     // [B][T][256] keys + pe (stride 0: shared by all prompts)
+  const f16* k; long long k_sb;       // [B][T][256] keys (residual)
+  const f16* pe;                      // [T][256] or null
+  const f16* g2;                      // [B][64][256]
+  const float* cbias;                 // [B][64]
+  const f16* vo;                      // [B][256][64] (k order: ea_sam_vo_perm)
+  const float* bo; const float* ln_g; const float* ln_b;   // [256]
+  float eps, scale;
+  f16* k_out; f16* kp_out;            // [B][T][256]
+  int B, T;
+};
+
+constexpr int SAM_C = 256;
+constexpr int I2T_TOK_PER_WG = 512;   // 4 waves x 16 tokens x 8 rounds
+
+// storage position s (0..31) of a 32-wide K step -> logical column inside the step, as the tile pairing leaves it in
+// the lanes: lane group q4 = s / 8 holds columns (q4 & 1) * 16 + (q4 >> 1) * 8 + 0..7
+__host__ __device__ inline int sam_perm32(int s) { return ((s >> 3) & 1) * 16 + (s >> 4) * 8 + (s & 7); }
+
+__global__ __launch_bounds__(256, 2) void ea_sam_i2t_kernel(SamI2tParams p) {
+  EA_SMEM(smem);
+  // LDS: G2 [64][512 B] (16-B chunks XOR-swizzled with row & 15), VO [256][128 B] (chunks XOR (row >> 1) & 7), bo / gamma / beta
+  char* s_g2 = smem;
+  char* s_vo = smem + 64 * 512;
+  float* s_vec = reinterpret_cast<float*>(smem + 64 * 512 + 256 * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int chunks_per_b = (p.T + I2T_TOK_PER_WG - 1) / I2T_TOK_PER_WG;
+  const int b = blockIdx.x / chunks_per_b, chunk = blockIdx.x - b * chunks_per_b;
+  {
+    const f16* g2 = p.g2 + (long long)b * 64 * SAM_C;
+    for (int i = tid; i < 64 * 32; i += 256) {       // 16-byte pieces
+      const int row = i >> 5, ch = i & 31;
+      *reinterpret_cast<f16x8*>(s_g2 + row * 512 + ((ch ^ (row & 15)) << 4)) = ea_ld8(g2 + row * SAM_C + ch * 8);
+    }
+    const f16* vo = p.vo + (long long)b * SAM_C * 64;
+    for (int i = tid; i < 256 * 8; i += 256) {
+      const int row = i >> 3, ch = i & 7;
+      *reinterpret_cast<f16x8*>(s_vo + row * 128 + ((ch ^ ea_swz(row)) << 4)) = ea_ld8(vo + row * 64 + ch * 8);
+    }
+    for (int i = tid; i < SAM_C; i += 256) { s_vec[i] = p.bo[i]; s_vec[SAM_C + i] = p.ln_g[i]; s_vec[2 * SAM_C + i] = p.ln_b[i]; }
+  }
+  __syncthreads();
+  // this lane's score-column bias: after the pairing it holds head (2*pr + (q4 & 1) * 2 + (q4 >> 1)) of pair pr -> columns
+  // base .. base + 7 with base = 32 * pr + sam_perm32(8 * q4)
+  float cb[2][8];
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cb[pr][e] = p.cbias[b * 64 + 32 * pr + sam_perm32(8 * q4) + e];
+
+  const f16* kp_b = p.kp + (long long)b * p.kp_sb;
+  const f16* k_b = p.k + (long long)b * p.k_sb;
+  f16* ko_b = p.k_out + (long long)b * p.T * SAM_C;
+  f16* kpo_b = p.kp_out ? p.kp_out + (long long)b * p.T * SAM_C : nullptr;
+
+  for (int round = 0; round < I2T_TOK_PER_WG / 64; ++round) {
+    const int t0 = chunk * I2T_TOK_PER_WG + round * 64 + wave * 16;
+    if (t0 >= p.T) break;                                   // (wave-uniform; no barrier below)
+    const int t = (t0 + c16 < p.T) ? t0 + c16 : p.T - 1;    // ragged tail: clamp the row, mask the stores
+    const bool row_ok = t0 + c16 < p.T;
+    // ---- product 1: scores[16 x 64] = (keys + pe)[16 x 256] G2^T
+    f16x8 fa[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) fa[s] = ea_ld8(kp_b + (long long)t * SAM_C + 32 * s + 8 * q4);
+    f32x4 sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 16 * j + c16, ch = 4 * s + q4;
+        const f16x8 fb = *reinterpret_cast<const f16x8*>(s_g2 + row * 512 + ((ch ^ (row & 15)) << 4));
+        sc[j] = ea_mfma_16x16x32(fb, fa[s], sc[j]);
+      }
+    // ---- pair the tiles: 8 consecutive columns = one head per lane; lane-local 7-way softmax (the pad column carries -1e30)
+    f16x8 prob[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      f32x4 a = sc[2 * pr], bq = sc[2 * pr + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float x = a[r], y = bq[r]; ea_swap16(x, y); a[r] = x; bq[r] = y; }
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = a[r] * p.scale + cb[pr][r]; v[4 + r] = bq[r] * p.scale + cb[pr][4 + r]; }
+      float mx = v[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) mx = fmaxf(mx, v[e]);
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[e] = ea_expf(v[e] - mx); sum += v[e]; }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) prob[pr][e] = (f16)(v[e] * inv);
+    }
+    // ---- product 2: out[16 x 256] = P[16 x 64] VO^T (the lanes' probability vectors are the A fragments of the two K steps)
+    f32x4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = 16 * j + c16, ch = 4 * ks + q4;
+        const f16x8 fb = *reinterpret_cast<const f16x8*>(s_vo + row * 128 + ((ch ^ ea_swz(row)) << 4));
+        acc[j] = ea_mfma_16x16x32(fb, prob[ks], acc[j]);
+      }
+    // ---- + bo + residual, LayerNorm over the 256 columns of the row, outputs.  Paired layout: vector pr2 of lane group q4
+    // covers columns 32 * pr2 + sam_perm32(8 * q4) .. + 7 of row c16.
+    float x[8][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int pr2 = 0; pr2 < 8; ++pr2) {
+      f32x4 a = acc[2 * pr2], bq = acc[2 * pr2 + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { float u = a[r], w = bq[r]; ea_swap16(u, w); a[r] = u; bq[r] = w; }
+      const int col = 32 * pr2 + sam_perm32(8 * q4);
+      const f16x8 res = ea_ld8(k_b + (long long)t * SAM_C + col);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[pr2][r] = a[r] + s_vec[col + r] + (float)res[r];
+        x[pr2][4 + r] = bq[r] + s_vec[col + 4 + r] + (float)res[4 + r];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1 += x[pr2][e]; s2 += x[pr2][e] * x[pr2][e]; }
+    }
+    s1 += ea_shfl_xor(s1, 16); s2 += ea_shfl_xor(s2, 16);
+    s1 += ea_shfl_xor(s1, 32); s2 += ea_shfl_xor(s2, 32);
+    const float mean = s1 * (1.0f / SAM_C);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / SAM_C) - mean * mean, 0.f) + p.eps);
+#pragma unroll
+    for (int pr2 = 0; pr2 < 8; ++pr2) {
+      const int col = 32 * pr2 + sam_perm32(8 * q4);
+      f16x8 h;
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { y[e] = (x[pr2][e] - mean) * rstd * s_vec[SAM_C + col + e] + s_vec[2 * SAM_C + col + e]; h[e] = (f16)y[e]; }
+      if (row_ok) ea_st8(ko_b + (long long)t * SAM_C + col, h);
+      if (kpo_b) {
+        // keys + pe of the NEXT block, from the rounded keys (what a separate add over the stored fp16 tensor would give)
+        const f16x8 pv = ea_ld8(p.pe + (long long)t * SAM_C + col);
+        f16x8 h2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h2[e] = (f16)((float)h[e] + (float)pv[e]);
+        if (row_ok) ea_st8(kpo_b + (long long)t * SAM_C + col, h2);
+      }
+    }
+  }
+}
+
+struct SamTailParams {
+  const f16* u0;                      // [B*T*4][64]
+  const float* ln_g; const float* ln_b; float eps;   // [64]
+  const f16* w1; const float* b1;     // [128][64], [128]: N = (ddy * 2 + ddx) * 32 + c
+  const float* hyper;                 // [B][4][32]
+  float* masks;                       // [B][nm][4h][4w]: hypernetwork outputs m0 .. m0 + nm - 1
+  int B, h, w, m0, nm;
+};
+
+__global__ __launch_bounds__(256, 2) void ea_sam_upscale_tail_kernel(SamTailParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int T = p.h * p.w;
+  const long long rows_per_b = (long long)T * 4;
+  // weight fragments and the per-K-position LayerNorm affine terms: loop invariant, in registers
+  f16x8 fw[8][2];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fw[j][ks] = ea_ld8(p.w1 + (16 * j + c16) * 64 + 32 * ks + 8 * q4);
+  float lg[2][8], lb[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { lg[ks][e] = p.ln_g[32 * ks + 8 * q4 + e]; lb[ks][e] = p.ln_b[32 * ks + 8 * q4 + e]; }
+  float bias[8][4];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[j][r] = p.b1[16 * j + 4 * q4 + r];
+  const long long ntiles = (long long)p.B * rows_per_b / 16;
+  for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+    const long long row0 = tile * 16;
+    const int b = (int)(row0 / rows_per_b);
+    const long long row = row0 + c16;
+    // ---- LayerNorm2d over the 64 channels of the row (fp32, eps 1e-6) + exact GELU -> A fragments
+    f16x8 in0 = ea_ld8(p.u0 + row * 64 + 8 * q4), in1 = ea_ld8(p.u0 + row * 64 + 32 + 8 * q4);
+    float v[2][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[0][e] = (float)in0[e]; v[1][e] = (float)in1[e]; s1 += v[0][e] + v[1][e]; s2 += v[0][e] * v[0][e] + v[1][e] * v[1][e]; }
+    s1 += ea_shfl_xor(s1, 16); s2 += ea_shfl_xor(s2, 16);
+    s1 += ea_shfl_xor(s1, 32); s2 += ea_shfl_xor(s2, 32);
+    const float mean = s1 * (1.0f / 64.0f);
+    const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / 64.0f) - mean * mean, 0.f) + p.eps);
+    f16x8 fa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[ks][e] = (f16)ea_gelu_erf((v[ks][e] - mean) * rstd * lg[ks][e] + lb[ks][e]);
+    // ---- second transposed conv as a [16 x 64] x [64 x 128] product, + bias, GELU
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc[j] = ea_mfma_16x16x32(fw[j][ks], fa[ks], acc[j]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[j][r] = ea_gelu_erf(acc[j][r] + bias[j][r]);
+    }
+    // ---- product with the hypernetwork outputs: logits[mask m][sub-pixel s] = sum_c u1[s * 32 + c] * hyper[b][m][c];
+    // this lane holds c in {4 q4 + r, 16 + 4 q4 + r}: partial sums, then a butterfly over the four lane groups
+    const float* hy = p.hyper + (long long)b * 4 * 32;
+    float out[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      float h8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h8[r] = hy[m * 32 + 4 * q4 + r]; h8[4 + r] = hy[m * 32 + 16 + 4 * q4 + r]; }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float a = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a += acc[2 * s][r] * h8[r] + acc[2 * s + 1][r] * h8[4 + r];
+        a += ea_shfl_xor(a, 16);
+        a += ea_shfl_xor(a, 32);
+        out[m][s] = a;
+      }
+    }
+    // lane group q4 writes mask q4: row -> (token (y, x), first up-sampling sub-pixel (dy, dx)); s = (ddy, ddx)
+    const long long rb = row - (long long)b * rows_per_b;
+    const int tok = (int)(rb >> 2), sub = (int)(rb & 3);
+    const int y = tok / p.w, xx = tok - y * p.w;
+    const int Y = 4 * y + 2 * (sub >> 1), X = 4 * xx + 2 * (sub & 1);
+    const int W4 = 4 * p.w;
+    float o[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = q4 == 0 ? out[0][s] : q4 == 1 ? out[1][s] : q4 == 2 ? out[2][s] : out[3][s];
+    const int mo = q4 - p.m0;           // multimask output keeps hypernetworks 1..3, single-mask output 0 (MaskDecoder.forward)
+    if (mo >= 0 && mo < p.nm) {
+      float* dst = p.masks + (((long long)b * p.nm + mo) * (4 * p.h) + Y) * W4 + X;
+      *reinterpret_cast<f32x2*>(dst) = f32x2{o[0], o[1]};
+      *reinterpret_cast<f32x2*>(dst + W4) = f32x2{o[2], o[3]};
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ea_sam_vo_perm(int s) { return (s & ~31) + sam_perm32(s & 31); }
+
+extern "C" int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_sb, const void* pe, const void* g2,
+                              const float* cbias, const void* vo, const float* bo, const float* ln_g, const float* ln_b, float eps,
+                              float scale, void* k_out, void* kp_out, int B, int T, int C, void* stream) {
+  if (!kp || !k || !g2 || !cbias || !vo || !bo || !ln_g || !ln_b || !k_out) return EA_ERR_BAD_ARG;
+  if (kp_out && !pe) return EA_ERR_BAD_ARG;
+  if (C != SAM_C) return EA_ERR_UNSUPPORTED;
+  if (B <= 0 || T <= 0 || (kp_sb & 7) || (k_sb & 7)) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)kp | (uintptr_t)k | (uintptr_t)pe | (uintptr_t)g2 | (uintptr_t)vo | (uintptr_t)k_out | (uintptr_t)kp_out) & 15) return EA_ERR_BAD_ARG;
+  SamI2tParams p;
+  p.kp = (const f16*)kp; p.kp_sb = kp_sb; p.k = (const f16*)k; p.k_sb = k_sb; p.pe = (const f16*)pe;
+  p.g2 = (const f16*)g2; p.cbias = cbias; p.vo = (const f16*)vo; p.bo = bo; p.ln_g = ln_g; p.ln_b = ln_b;
+  p.eps = eps; p.scale = scale; p.k_out = (f16*)k_out; p.kp_out = (f16*)kp_out; p.B = B; p.T = T;
+  const int chunks = (T + I2T_TOK_PER_WG - 1) / I2T_TOK_PER_WG;
+  const int smem = 64 * 512 + 256 * 128 + 3 * SAM_C * 4;
+  auto kfn = ea_sam_i2t_kernel;
+  ea_allow_big_lds(kfn, smem);
+  EA_LAUNCH(kfn, dim3((unsigned)(B * chunks)), dim3(256), smem, stream, p);
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_upscale_tail_f16(const void* u0, const float* ln_g, const float* ln_b, float eps, const void* w1, const float* b1,
+                                       const float* hyper, float* masks, int B, int h, int w, int m0, int nm, void* stream) {
+  if (!u0 || !ln_g || !ln_b || !w1 || !b1 || !hyper || !masks) return EA_ERR_BAD_ARG;
+  if (B <= 0 || h <= 0 || w <= 0 || ((long long)h * w * 4) % 16 || m0 < 0 || nm <= 0 || m0 + nm > 4) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)u0 | (uintptr_t)w1) & 15 || ((uintptr_t)masks & 7)) return EA_ERR_BAD_ARG;
+  SamTailParams p;
+  p.u0 = (const f16*)u0; p.ln_g = ln_g; p.ln_b = ln_b; p.eps = eps; p.w1 = (const f16*)w1; p.b1 = b1; p.hyper = hyper;
+  p.masks = masks; p.B = B; p.h = h; p.w = w; p.m0 = m0; p.nm = nm;
+  const long long ntiles = (long long)B * h * w * 4 / 16;
+  long long nb = (ntiles + 3) / 4;
+  if (nb > 8192) nb = 8192;
+  auto kfn = ea_sam_upscale_tail_kernel;
+  EA_LAUNCH(kfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  return ea_launch_status();
+}

@@ -420,20 +420,57 @@ def relpos_tables(q, heads, dim_head, S, rel_h, rel_w):
     return bh, bw
 
 
-def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, offset):
-    """low fp32 [n, lh, lw] -> (mask uint8 [n, H, W], stats int32 [n, 6] = inter, union, xmin, ymin, xmax, ymax)."""
+def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, offset, want_masks=True, index=None):
+    """low fp32 [n, lh, lw] -> (mask uint8 [k, H, W] or None, stats int32 [k, 6] = inter, union, xmin, ymin, xmax, ymax);
+    k = n, or len(index) when `index` (int32 device tensor) selects the masks to process."""
     _check_dev(low)
-    low = low.contiguous()
+    _dense(low, index)
     n, lh, lw = low.shape
+    k = n if index is None else int(index.shape[0])
     H, W = original_size
-    mask = torch.empty((n, H, W), dtype=torch.uint8, device=low.device)
-    stats = torch.tensor([0, 0, W, H, -1, -1], dtype=torch.int32, device=low.device).repeat(n, 1).contiguous()
+    mask = torch.empty((k, H, W), dtype=torch.uint8, device=low.device) if want_masks else None
+    stats = torch.tensor([0, 0, W, H, -1, -1], dtype=torch.int32, device=low.device).repeat(k, 1).contiguous()
+    if k == 0:
+        return mask, stats
     ev = _prof_begin()
-    st = _lib().ea_sam_mask_postprocess(_p(low), n, lh, lw, img_size, input_size[0], input_size[1], H, W, float(threshold),
-                                        float(offset), _p(mask), _p(stats), _stream())
-    _prof_end(ev, 0.0, f"sam-mask-post n{n} {H}x{W}")
+    st = _lib().ea_sam_mask_postprocess_indexed(_p(low), _p(index), k, lh, lw, img_size, input_size[0], input_size[1], H, W,
+                                                float(threshold), float(offset), _p(mask), _p(stats), _stream())
+    _prof_end(ev, 0.0, f"sam-mask-post n{k} {H}x{W}")
     L.check(st, "ea_sam_mask_postprocess")
     return mask, stats
+
+
+def sam_vo_perm(device):
+    """Storage order of ea_sam_i2t_f16's `vo` columns: position s holds score column perm[s]."""
+    return torch.tensor([_lib().ea_sam_vo_perm(s) for s in range(64)], dtype=torch.long, device=device)
+
+
+def sam_i2t(kp, k, pe, g2, cbias, vo, bo, ln_g, ln_b, eps, scale, B, want_kp=True):
+    """Image -> token cross attention + residual + LayerNorm of one TwoWayAttentionBlock, fused per token
+    (ea_sam_i2t_f16).  kp / k: fp16 [T, C] (shared by all prompts) or [B, T, C]; -> (k_out, kp_out) fp16 [B, T, C]."""
+    _check_dev(kp, k, g2, vo)
+    _dense(kp, k, pe, g2, cbias, vo)
+    T, Cc = k.shape[-2], k.shape[-1]
+    sb = 0 if k.dim() == 2 else T * Cc
+    k_out = torch.empty((B, T, Cc), dtype=torch.float16, device=k.device)
+    kp_out = torch.empty_like(k_out) if want_kp else None
+    st = _lib().ea_sam_i2t_f16(_p(kp), sb, _p(k), sb, _p(pe), _p(g2), _p(cbias), _p(vo), _p(bo), _p(ln_g), _p(ln_b), float(eps),
+                               float(scale), _p(k_out), _p(kp_out), B, T, Cc, _stream())
+    L.check(st, "ea_sam_i2t_f16")
+    return k_out, kp_out
+
+
+def sam_upscale_tail(u0, ln_g, ln_b, eps, w1, b1, hyper, B, h, w, m0=0, nm=4, out=None):
+    """MaskDecoder.output_upscaling[1:] + hypernetwork product (ea_sam_upscale_tail_f16): u0 fp16 [B*h*w*4, 64] ->
+    mask logits fp32 [B, nm, 4h, 4w] of hypernetworks m0 .. m0 + nm - 1."""
+    _check_dev(u0, w1, hyper)
+    _dense(u0, w1, hyper)
+    masks = out if out is not None else torch.empty((B, nm, 4 * h, 4 * w), dtype=torch.float32, device=u0.device)
+    _dense(masks)
+    st = _lib().ea_sam_upscale_tail_f16(_p(u0), _p(ln_g), _p(ln_b), float(eps), _p(w1), _p(b1), _p(hyper), _p(masks), B, h, w, m0, nm,
+                                        _stream())
+    L.check(st, "ea_sam_upscale_tail_f16")
+    return masks
 
 
 def softmax_rows(x, scale):

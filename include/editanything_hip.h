@@ -24,6 +24,9 @@
  *   ea_layernorm_f16, ea_gemm_f16, ea_ln_gemm_f16
  *                             <- BasicTransformerBlock / GEGLU / SpatialTransformer Linears
  *                                ldm/modules/attention.py:49-76,152-160,263-275,316-339
+ *   ea_sam_i2t_f16, ea_sam_upscale_tail_f16
+ *                             <- segment_anything TwoWayAttentionBlock (image -> token attention + norm4) and
+ *                                MaskDecoder.output_upscaling + hypernetwork product (3rd party), fused per token
  *   ea_cfg_ddim_step          <- DDIMSampler.p_sample_ddim, cldm/ddim_hacked.py:187-231
  *   ea_lincomb_f32            <- UniPCMultistepScheduler.step (diffusers, 3rd party; set at sam2image.py:42) and the
  *                                alpha-weighted latent blends of ...inpaint.py:2039-2051
@@ -236,9 +239,38 @@ int ea_lincomb_f32(const float* s0, const float* s1, const float* s2, const floa
  * segment_anything, third party): low_res fp32 [n][lh][lw] logits -> mask uint8 [n][H][W] (logit > threshold at the
  * original resolution, through the img_size^2 intermediate cropped to in_h x in_w, both resizes bilinear
  * align_corners=False) and stats int32 [n][6] = {#(> thr+off), #(> thr-off), xmin, ymin, xmax, ymax}.
- * `stats` must be initialised by the caller to {0, 0, W, H, -1, -1} per mask (accumulated with integer atomics). */
+ * `stats` must be initialised by the caller to {0, 0, W, H, -1, -1} per mask (accumulated with integer atomics).
+ * `mask` may be NULL: statistics only -- the automatic mask generator filters its 3 x 1024 candidates on the statistics
+ * and writes masks for the survivors of the NMS alone (a second call), instead of 3072 full-resolution masks. */
 int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
                             int H, int W, float threshold, float offset, unsigned char* mask, int* stats, void* stream);
+/* The same over a SELECTION of the masks in `low_res`: slot i (of n_masks) processes low_res[index[i]] and writes
+ * mask[i] / stats[i] (index: device int32 [n_masks]; NULL = identity).  lw <= 4096. */
+int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
+                                    int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
+                                    int* stats, void* stream);
+
+/* SAM mask decoder, image-token side (segment_anything TwoWayAttentionBlock / MaskDecoder, third party; reference call
+ * sites sam2image.py:71,118, editany_lora.py:523-543), fused per token (csrc/ea_sam.hip).
+ *
+ * ea_sam_i2t_f16: one block's image -> token cross attention + residual + LayerNorm:
+ *     k_out[b][t] = LN(k[b][t] + softmax_heads(scale * kp[b][t] . g2[b]^T + cbias[b]) . vo[b]^T + bo)
+ * kp = keys + positional encoding and k = keys, fp16 [B][T][256] (batch strides kp_sb / k_sb in elements, 0 = one tensor
+ * shared by every prompt); g2 fp16 [B][64][256] and cbias fp32 [B][64]: one score column per (head h, token j) at index
+ * h * 8 + j (j < 7; column h * 8 + 7 is padding: cbias = -1e30 there); vo fp16 [B][256][64]: vo[b][n][s] multiplies score
+ * column ea_sam_vo_perm(s) (the order the MFMA tile pairing leaves the probabilities in).  kp_out (optional, needs pe
+ * fp16 [T][256]) = k_out + pe for the next block.  C must be 256. */
+int ea_sam_vo_perm(int s);
+int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_sb, const void* pe, const void* g2,
+                   const float* cbias, const void* vo, const float* bo, const float* ln_g, const float* ln_b, float eps,
+                   float scale, void* k_out, void* kp_out, int B, int T, int C, void* stream);
+/* ea_sam_upscale_tail_f16: MaskDecoder.output_upscaling from the first transposed conv's output on (u0 fp16 [B*h*w*4][64],
+ * rows ordered (b, y, x, dy, dx)): LayerNorm2d(64, eps) + GELU, ConvTranspose2d(64 -> 32, k 2, s 2) as a per-row product
+ * with w1 fp16 [128][64] (row (ddy * 2 + ddx) * 32 + c) + b1, GELU, and the product with the hypernetwork outputs
+ * hyper fp32 [B][4][32] -> masks fp32 [B][nm][4h][4w], the outputs of hypernetworks m0 .. m0 + nm - 1 (MaskDecoder.forward
+ * keeps 1..3 for multimask output, 0 otherwise). */
+int ea_sam_upscale_tail_f16(const void* u0, const float* ln_g, const float* ln_b, float eps, const void* w1, const float* b1,
+                            const float* hyper, float* masks, int B, int h, int w, int m0, int nm, void* stream);
 
 /* Layout plumbing on device: NCHW fp32 -> NHWC fp16 with channel padding, and back. */
 int ea_nchw_f32_to_nhwc_f16(const float* x, void* out, int B, int C, int H, int W, int Cpad, float mul,

@@ -147,6 +147,32 @@ def test_device_decoder_full_grid_vs_oracle(device_decoder):
     assert float(agree) > 0.99, f"mask sign agreement {float(agree):.4f}"
 
 
+@gpu
+def test_fused_decoder_path_equals_the_unfused_formulation(device_decoder):
+    """`predict_masks` (image -> token attention + norm4 fused per token, token -> image attention with the key / value
+    projections folded into the 7-token side, fused upscaling tail) against `predict_masks_unfused` (projections,
+    attention calls, LayerNorm passes as separate launches) on the same fp16 weights: the same function, different
+    rounding points -- and both against the fp32 oracle, to the same tolerance."""
+    sd, dec = decoder_sd(), device_decoder
+    emb, _ = _seeded_case()
+    pts = torch.from_numpy(np.random.default_rng(11).uniform(0, 1024, size=(24, 1, 2)).astype(np.float32))
+    with torch.no_grad():
+        sparse = dec.embed_points(pts, torch.ones(24, 1))
+        tok = dec.image_tokens(emb)
+        low_f, iou_f = dec.predict_masks(tok, (64, 64), sparse, True)
+        low_u, iou_u = dec.predict_masks_unfused(tok, (64, 64), sparse, True)
+        ref_low, ref_iou = AO.mask_decoder(sd, emb, AO.dense_pe(sd, (64, 64)), AO.embed_points(sd, pts, torch.ones(24, 1)), True)
+    assert rel_l2(low_f, low_u) < 1e-2
+    assert rel_l2(low_f, ref_low) < 1e-2 and rel_l2(low_u, ref_low) < 1e-2
+    assert float((iou_f - iou_u).abs().max()) < 5e-3
+    assert float((iou_f.cpu() - ref_iou).abs().max()) < 2e-3 + 1e-2 * float(ref_iou.abs().max())
+    # single-mask output and a two-point prompt take the same path
+    with torch.no_grad():
+        low1, _ = dec.predict_masks(tok, (64, 64), sparse, False)
+        low1u, _ = dec.predict_masks_unfused(tok, (64, 64), sparse, False)
+    assert rel_l2(low1, low1u) < 1e-2
+
+
 def _iou(a, b):
     u = np.logical_or(a, b).sum()
     return np.logical_and(a, b).sum() / u if u else 1.0

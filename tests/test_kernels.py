@@ -1217,3 +1217,75 @@ def test_groupnorm_statistics_query_matches_the_launch(kb, B, H):
     else:
         e = epilogue(y, bias=bias, rowvec=rv, rows_per_group=HW)
         assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ea_sam.hip: the image-token side of SAM's mask decoder, fused per token
+def _vo_perm(kb):
+    return np.array([kb.lib.ea_sam_vo_perm(s) for s in range(64)])
+
+
+@pytest.mark.parametrize("B,T,shared", [(2, 96, False), (3, 40, True)])
+def test_sam_i2t_fused(kb, B, T, shared):
+    """ea_sam_i2t_f16 == LN(k + softmax_per_head(scale * kp g2^T + c) vo^T + bo) (segment_anything TwoWayAttentionBlock
+    cross_attn_image_to_token + norm4 with the token side folded into g2 / c / vo), ragged T, shared or per-prompt keys."""
+    Cc, heads = 256, 8
+    nb = 1 if shared else B
+    k = f16(nb, T, Cc)
+    pe = f16(T, Cc, scale=0.5)
+    kp = (k.astype(np.float32) + pe.astype(np.float32)[None]).astype(np.float16)
+    g2 = np.zeros((B, 64, Cc), np.float16)
+    cb = np.full((B, 64), -1e30, np.float32)
+    vo = np.zeros((B, Cc, 64), np.float32)
+    for h in range(heads):
+        g2[:, h * 8:h * 8 + 7] = f16(B, 7, Cc, scale=0.2)
+        cb[:, h * 8:h * 8 + 7] = f32(B, 7)
+        vo[:, :, h * 8:h * 8 + 7] = f32(B, Cc, 7, scale=0.3)
+    vo16 = vo.astype(np.float16)
+    perm = _vo_perm(kb)
+    assert sorted(perm.tolist()) == list(range(64))
+    vo_dev = np.ascontiguousarray(vo16[:, :, perm])          # storage position s <- logical score column perm[s]
+    bo, g, bt = f32(Cc, scale=0.1), (1.0 + 0.1 * RNG.standard_normal(Cc)).astype(np.float32), f32(Cc, scale=0.1)
+    k_out, kp_out = kb.zeros((B, T, Cc), np.float16), kb.zeros((B, T, Cc), np.float16)
+    sb = 0 if shared else T * Cc
+    st = kb.lib.ea_sam_i2t_f16(ptr(kp), sb, ptr(k), sb, ptr(pe), ptr(g2), ptr(cb), ptr(vo_dev), ptr(bo), ptr(g), ptr(bt), 1e-5, 0.25,
+                               ptr(k_out), ptr(kp_out), B, T, Cc, kb.stream)
+    assert st == 0
+    kk, kkp = t(k).expand(B, T, Cc), t(kp).expand(B, T, Cc)
+    s = torch.einsum("btc,bnc->btn", kkp, t(g2)) * 0.25 + t(cb)[:, None]
+    pr = torch.softmax(s.reshape(B, T, heads, 8), dim=-1).reshape(B, T, 64)
+    assert float(pr.reshape(B, T, heads, 8)[..., 7].abs().max()) == 0.0
+    out = torch.einsum("btn,bcn->btc", pr.half().float(), t(vo16)) + t(bo) + kk
+    ref = F.layer_norm(out, (Cc,), t(g), t(bt), 1e-5)
+    got = kb.down(k_out)
+    assert relerr(got, ref.numpy()) < 3e-3
+    got_kp = kb.down(kp_out).astype(np.float32)
+    assert np.abs(got_kp - (got.astype(np.float32) + pe.astype(np.float32)[None])).max() <= 2e-2
+
+
+def test_sam_upscale_tail_fused(kb):
+    """ea_sam_upscale_tail_f16 == LayerNorm2d + GELU + ConvTranspose2d(64 -> 32, 2, 2) + GELU + hypernetwork product of
+    segment_anything's MaskDecoder (output_upscaling[1:] and `hyper_in @ upscaled_embedding`), pixel placement included."""
+    B, h, w = 2, 4, 8
+    c0, c1 = 64, 32
+    u0 = f16(B * h * w * 4, c0)                                   # rows (b, y, x, dy, dx)
+    g, bt = (1.0 + 0.1 * RNG.standard_normal(c0)).astype(np.float32), f32(c0, scale=0.1)
+    wt = f16(c0, c1, 2, 2, scale=0.3)                             # ConvTranspose2d weight [cin, cout, 2, 2]
+    b1 = f32(c1, scale=0.1)
+    hyper = f32(B, 4, c1)
+    w1 = np.ascontiguousarray(np.transpose(wt, (2, 3, 1, 0)).reshape(4 * c1, c0))
+    masks = kb.zeros((B, 4, 4 * h, 4 * w), np.float32)
+    st = kb.lib.ea_sam_upscale_tail_f16(ptr(u0), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(np.tile(b1, 4)), ptr(hyper), ptr(masks), B, h, w,
+                                        0, 4, kb.stream)
+    assert st == 0
+    m3 = kb.zeros((B, 3, 4 * h, 4 * w), np.float32)     # multimask output: hypernetworks 1..3 only, densely packed
+    assert kb.lib.ea_sam_upscale_tail_f16(ptr(u0), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(np.tile(b1, 4)), ptr(hyper), ptr(m3), B, h, w, 1, 3,
+                                          kb.stream) == 0
+    assert np.array_equal(kb.down(m3), kb.down(masks)[:, 1:])
+    x = t(u0).reshape(B, h, w, 2, 2, c0).permute(0, 5, 1, 3, 2, 4).reshape(B, c0, 2 * h, 2 * w)      # NCHW after the first upscaling
+    mu, var = x.mean(1, keepdim=True), x.var(1, keepdim=True, unbiased=False)
+    x = (x - mu) / torch.sqrt(var + 1e-6) * t(g)[None, :, None, None] + t(bt)[None, :, None, None]
+    x = F.gelu(x).half().float()
+    x = F.gelu(F.conv_transpose2d(x, t(wt), t(b1), stride=2))
+    ref = torch.einsum("bmc,bchw->bmhw", t(hyper), x)
+    assert relerr(kb.down(masks), ref.numpy()) < 3e-3
