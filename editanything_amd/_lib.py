@@ -58,6 +58,7 @@ SIGNATURES = {
     "ea_tools_build": (_i, []),
     "ea_sam_vo_perm": (_i, [_i]),
     "ea_sam_i2t_f16": (_i, [_vp, _ll, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _i, _i, _i, _vp]),
+    "ea_sam_t2i_f16": (_i, [_vp, _ll, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "ea_sam_upscale_tail_f16": (_i, [_vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ea_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_row_stats_parts": (_i, [_i]),

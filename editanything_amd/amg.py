@@ -232,7 +232,7 @@ class SamPromptDecoder:
                              bv=a.b["v"].reshape(h, d), wo=a.wo.float().reshape(-1, h, d))
         return a._blocks
 
-    def _t2i_folded(self, a, q_in, kp, k):
+    def _t2i_folded(self, a, q_in, kp, k, key_pe):
         """Token -> image cross attention with PER-PROMPT keys, without projecting the image side: scores = G (keys + pe)^T
         with G[h, j] = Wk_h^T q_hj (the key bias is constant over the image tokens and drops out of their softmax), output
         = Wv_h (P keys) + bv_h.  kp / k fp16 [B, T, C]; q_in fp32 [B, 7, C] -> fp32 [B, 7, C] (before the residual)."""
@@ -242,14 +242,20 @@ class SamPromptDecoder:
         qh = (F.linear(q_in, a.w["q"].float(), a.b["q"])).reshape(B, n, h, d)
         G = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_in.device)
         G[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", qh, bl["wk"]).half()
-        if k.dim() == 2:
+        if T % 64 == 0:
+            # one pass over the image tokens per prompt: scores, online softmax and P keys fused (ops.sam_t2i)
+            ctx = ops.sam_t2i(k, key_pe, G.reshape(B, 64, Cc), 1.0 / math.sqrt(d), B).reshape(B, h, 8, Cc)[:, :, :n]
+        elif k.dim() == 2:
             # block 0: ONE image-token tensor for every prompt -- two plain contractions over all B * 64 score rows
             S = ops.gemm(G.reshape(B * 64, Cc), kp, out_dtype=torch.float32).reshape(B, 64, T)
             P = ops.softmax_rows(S, 1.0 / math.sqrt(d))
             ctx = ops.gemm(P.reshape(B * 64, T), k.t().contiguous()).float().reshape(B, h, 8, Cc)[:, :, :n]
         else:
+            # per-prompt keys: G (keys + pe)^T = G keys^T + G pe^T -- the second product has ONE weight for all prompts (a plain
+            # contraction) and enters the batched one as its fp32 residual, so no keys + pe tensor is ever stored
+            S_pe = ops.gemm(G.reshape(B * 64, Cc), key_pe, out_dtype=torch.float32)
             S = torch.empty((B, 64, T), dtype=torch.float32, device=q_in.device)
-            ops.gemm_batched(G, kp, S, 64, T, Cc, B, 64 * Cc, T * Cc, 64 * T)
+            ops.gemm_batched(G, k, S, 64, T, Cc, B, 64 * Cc, T * Cc, 64 * T, residual=S_pe, stride_r=64 * T)
             P = ops.softmax_rows(S, 1.0 / math.sqrt(d))                               # fp16 [B, 64, T]
             ctx = torch.bmm(P, k).float().reshape(B, h, 8, Cc)[:, :, :n]              # [B, h, 7, C]
         o = torch.einsum("bhjc,hdc->bjhd", ctx, bl["wv"]) + bl["bv"]
@@ -310,12 +316,13 @@ class SamPromptDecoder:
                 att = a.core(a.proj("q", q16), a.proj("k", q16), a.proj("v", queries.half()))
                 queries = queries + F.linear(att.float(), a.wo.float(), a.bo)
             queries = self._ln(queries, L["norms"][0])
-            att = self._t2i_folded(L["t2i"], queries + point_emb, kp, k)
+            att = self._t2i_folded(L["t2i"], queries + point_emb, kp, k, key_pe)
             queries = self._ln(queries + att, L["norms"][1])
             m = F.linear(F.relu(F.linear(queries, L["w1"].float(), L["b1"])), L["w2"].float(), L["b2"])
             queries = self._ln(queries + m, L["norms"][2])
-            k, kp = self._i2t_fused(L["i2t"], queries + point_emb, queries, kp, k, key_pe, L["norms"][3], B, True)
-        att = self._t2i_folded(self.final, queries + point_emb, kp, k)
+            k, _ = self._i2t_fused(L["i2t"], queries + point_emb, queries, kp if k.dim() == 2 else None, k, key_pe, L["norms"][3], B,
+                                   False)
+        att = self._t2i_folded(self.final, queries + point_emb, None, k, key_pe)
         queries = self._ln(queries + att, self.norm_final)
         iou_tok, mask_toks = queries[:, 0], queries[:, 1:1 + len(self.hyper)]
         hyper = torch.stack([self._mlp3(self.hyper[i], mask_toks[:, i]) for i in range(len(self.hyper))], dim=1).contiguous()

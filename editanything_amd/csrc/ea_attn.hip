@@ -21,7 +21,7 @@
 //  * online softmax in fp32 (exp2 domain), fp16 P for the PV MFMA, fp32 O.
 // q/k/v are read in place from the [B, N, H*D] projection outputs (arbitrary
 // row/batch strides, e.g. a fused QKV buffer); no head split/merge copies.
-#include "ea_platform.h"
+#include "ea_prims.h"
 #include "../../include/editanything_hip.h"
 #include <string.h>
 #include <type_traits>
@@ -48,50 +48,6 @@ constexpr int ATT_BK = 64;   // keys per tile
 // accumulate in fp32 -- the result differs from the always-rescale form only by fp32 rounding.
 constexpr float ATT_DEFER = 8.0f;
 
-// ds_read_b64_tr_b16: within each 16-lane group the 16 x 8-byte pieces form a [4][16] fp16 block (row r = lanes
-// 4r..4r+3, each supplying 4 consecutive columns); lane i receives column i = (M[0][i], M[1][i], M[2][i], M[3][i]).
-// (Mapping measured on gfx950 with tools/probe_tr.hip.)  Lets V stay row-major [key][d] in LDS -- written with plain
-// 16-byte stores -- and still be consumed as the V^T operand of O^T = V^T P^T.
-template <int OFF>
-__device__ __forceinline__ f16x4 ea_lds_read_tr16(const char* ptr0) {
-  const char* ptr = ptr0 + OFF;
-#ifdef EA_EMU
-  char* sc = ea_emu::wave_scratch();
-  const int l = ea_emu::lane_id();
-  memcpy(sc + l * 64, ptr, 8);
-  ea_emu::wave_sync();
-  const int g = l & ~15, i = l & 15;
-  f16x4 r;
-  for (int rr = 0; rr < 4; ++rr) {
-    f16 v;
-    memcpy(&v, sc + (g + 4 * rr + (i >> 2)) * 64 + (i & 3) * 2, 2);
-    r[rr] = v;
-  }
-  ea_emu::wave_sync();
-  return r;
-#else
-  f16x4 r;
-  (void)ptr;
-  const unsigned addr = (unsigned)(uintptr_t)ptr0;   // one address VGPR per tile, the rest is the 16-bit immediate
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF) : "memory");
-  return r;
-#endif
-}
-// the asm read above is invisible to the compiler's lgkmcnt bookkeeping: wait for it explicitly before the first use,
-// and keep the consumers behind the wait (guide section 5.4 rule 18)
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void ea_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    ea_static_for<N, I + 1>(f);
-  }
-}
-__device__ __forceinline__ void ea_lds_tr_wait() {
-#ifndef EA_EMU
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
 // LDS hand-off between the lanes of one wave (the LDS pipeline is in order per wave)
 __device__ __forceinline__ void ea_wave_lds_sync_() {
 #ifdef EA_EMU

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void ea_sam_i2t_kernel(SamI2tParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) cb[pr][e] = p.cbias[b * 64 + 32 * pr + sam_perm32(8 * q4) + e];
 
-  const f16* kp_b = p.kp + (long long)b * p.kp_sb;
+  const f16* kp_b = p.kp ? p.kp + (long long)b * p.kp_sb : nullptr;
   const f16* k_b = p.k + (long long)b * p.k_sb;
   f16* ko_b = p.k_out + (long long)b * p.T * SAM_C;
   f16* kpo_b = p.kp_out ? p.kp_out + (long long)b * p.T * SAM_C : nullptr;
@@ -92,8 +92,18 @@ __global__ __launch_bounds__(256, 2) void ea_sam_i2t_kernel(SamI2tParams p) {
     const bool row_ok = t0 + c16 < p.T;
     // ---- product 1: scores[16 x 64] = (keys + pe)[16 x 256] G2^T
     f16x8 fa[8];
+    if (p.kp) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) fa[s] = ea_ld8(kp_b + (long long)t * SAM_C + 32 * s + 8 * q4);
+      for (int s = 0; s < 8; ++s) fa[s] = ea_ld8(kp_b + (long long)t * SAM_C + 32 * s + 8 * q4);
+    } else {
+      // no stored keys + pe tensor: the operand is formed here, rounded to fp16 exactly like a stored sum would be
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const f16x8 kv = ea_ld8(k_b + (long long)t * SAM_C + 32 * s + 8 * q4), pv = ea_ld8(p.pe + (long long)t * SAM_C + 32 * s + 8 * q4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[s][e] = (f16)((float)kv[e] + (float)pv[e]);
+      }
+    }
     f32x4 sc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -277,6 +287,140 @@ __global__ __launch_bounds__(256, 2) void ea_sam_upscale_tail_kernel(SamTailPara
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ token -> image
+//  ctx[b] = softmax_rows(scale * g[b] (k[b] + pe)^T) k[b]          g [64 x 256] (one row per (head, token)), k [T x 256]
+// The token -> image cross attention of a TwoWayAttentionBlock with the key / value projections folded into the 7-token
+// side (amg.py `_t2i_folded`): a 64-query attention over T keys with head dimension 256 whose keys are (k + pe) and whose
+// values are k itself.  One workgroup per prompt walks the image tokens 64 at a time: the tile is loaded into registers one
+// tile ahead (k and pe, 16-byte loads), stored to LDS twice -- k + pe row-major for the score product, k row-major for the
+// value product, which reads it TRANSPOSED with ds_read_b64_tr_b16 -- flash-style online softmax in registers (each of the 4
+// waves owns 16 of the 64 score rows), probabilities paired into A fragments exactly like ea_sam_i2t.  Replaces, per
+// block: a [B*64 x T x 256] score contraction with a 1-GB fp32 output, a row-softmax pass over it, and a batched
+// [64 x T] x [T x 256] product (rocBLAS) -- three passes over 1-2 GB each -- with ONE pass over the 2 MB of k per prompt.
+struct SamT2iParams {
+  const f16* k; long long k_sb;       // [B][T][256] (stride 0: shared)
+  const f16* pe;                      // [T][256]
+  const f16* g;                       // [B][64][256]
+  float* ctx;                         // [B][64][256]
+  float scale;
+  int B, T;
+};
+
+constexpr int T2I_TILE = 64;
+constexpr int T2I_PITCH = 512 + 32;   // bytes per LDS row: 8 consecutive rows land on 8 different 32-byte bank groups (tr reads)
+
+__global__ __launch_bounds__(256, 2) void ea_sam_t2i_kernel(SamT2iParams p) {
+  EA_SMEM(smem);
+  char* s_kp = smem;                                   // [64][PITCH] k + pe
+  char* s_k = smem + T2I_TILE * T2I_PITCH;             // [64][PITCH] k
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int b = blockIdx.x;
+  const f16* kb = p.k + (long long)b * p.k_sb;
+  // this wave's 16 score rows of g as A fragments (loop invariant)
+  f16x8 ga[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) ga[s] = ea_ld8(p.g + ((long long)b * 64 + wave * 16 + c16) * SAM_C + 32 * s + 8 * q4);
+  // staging: thread t moves 16-byte pieces t, t + 256, ... of the [64 x 256] tile (32 pieces per row)
+  f16x8 rk[8], rp[8];
+  auto load_tile = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+      rk[i] = ea_ld8(kb + (long long)(t0 + row) * SAM_C + ch * 8);
+      rp[i] = ea_ld8(p.pe + (long long)(t0 + row) * SAM_C + ch * 8);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = tid + 256 * i, row = c >> 5, ch = c & 31;
+      f16x8 kp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) kp[e] = (f16)((float)rk[i][e] + (float)rp[i][e]);
+      *reinterpret_cast<f16x8*>(s_k + row * T2I_PITCH + ch * 16) = rk[i];
+      *reinterpret_cast<f16x8*>(s_kp + row * T2I_PITCH + ch * 16) = kp;
+    }
+  };
+  f32x4 acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  // per-lane part of the V^T fragment address (ea_prims.h ea_lds_read_tr16): 16-lane group q4 supplies the 8 tokens
+  // sam_perm32(8 * q4) .. + 7 of a 32-token K step (the order the paired probabilities are in), lane j of the group the
+  // token row j >> 2 (+ 4 for the second read) and channels 4 * (j & 3) .. + 3 of the 16-channel tile
+  const int vt_off = (sam_perm32(8 * q4) + (c16 >> 2)) * T2I_PITCH + 8 * (c16 & 3);
+  const int ntile = p.T / T2I_TILE;
+  load_tile(0);
+  for (int tl = 0; tl < ntile; ++tl) {
+    __syncthreads();                       // the previous tile's readers are done
+    store_tile();
+    __syncthreads();
+    if (tl + 1 < ntile) load_tile((tl + 1) * T2I_TILE);
+    // ---- scores of this wave's 16 rows against the 64 tokens of the tile
+    f32x4 sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f16x8 fb = *reinterpret_cast<const f16x8*>(s_kp + (16 * j + c16) * T2I_PITCH + (4 * s + q4) * 16);
+        sc[j] = ea_mfma_16x16x32(fb, ga[s], sc[j]);
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { sc[j][r] *= p.scale; mx = fmaxf(mx, sc[j][r]); }
+    mx = fmaxf(mx, ea_shfl_xor(mx, 16));
+    mx = fmaxf(mx, ea_shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = ea_expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+    m_run = m_new;
+    l_run *= alpha;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] *= alpha;
+    // ---- probabilities, paired into the A fragments of the two 32-token K steps
+    f16x8 prob[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      f32x4 a = sc[2 * pr], bq = sc[2 * pr + 1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = ea_expf(a[r] - m_new); bq[r] = ea_expf(bq[r] - m_new);
+        l_run += a[r] + bq[r];
+        float x = a[r], y = bq[r];
+        ea_swap16(x, y);
+        prob[pr][r] = (f16)x; prob[pr][4 + r] = (f16)y;
+      }
+    }
+    // ---- ctx += P k: the value operand is the k tile read transposed
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* vbase = s_k + 32 * ks * T2I_PITCH + vt_off;
+      ea_static_for<16>([&](auto jn_) {
+        constexpr int jn = decltype(jn_)::value;
+        const f16x4 lo = ea_lds_read_tr16<32 * jn>(vbase);
+        const f16x4 hi = ea_lds_read_tr16<32 * jn + 4 * T2I_PITCH>(vbase);
+        ea_lds_tr_wait();
+        f16x8 fb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fb[e] = lo[e]; fb[4 + e] = hi[e]; }
+        acc[jn] = ea_mfma_16x16x32(fb, prob[ks], acc[jn]);
+      });
+    }
+  }
+  // ---- normalise and write: lane (c16, q4) holds row wave * 16 + c16, columns 16 j + 4 q4 .. + 3
+  l_run += ea_shfl_xor(l_run, 16);
+  l_run += ea_shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_run;
+  float* dst = p.ctx + ((long long)b * 64 + wave * 16 + c16) * SAM_C + 4 * q4;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x4*>(dst + 16 * j) = acc[j] * inv;
+}
+
 }  // namespace
 
 extern "C" int ea_sam_vo_perm(int s) { return (s & ~31) + sam_perm32(s & 31); }
@@ -284,8 +428,8 @@ extern "C" int ea_sam_vo_perm(int s) { return (s & ~31) + sam_perm32(s & 31); }
 extern "C" int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_sb, const void* pe, const void* g2,
                               const float* cbias, const void* vo, const float* bo, const float* ln_g, const float* ln_b, float eps,
                               float scale, void* k_out, void* kp_out, int B, int T, int C, void* stream) {
-  if (!kp || !k || !g2 || !cbias || !vo || !bo || !ln_g || !ln_b || !k_out) return EA_ERR_BAD_ARG;
-  if (kp_out && !pe) return EA_ERR_BAD_ARG;
+  if (!k || !g2 || !cbias || !vo || !bo || !ln_g || !ln_b || !k_out) return EA_ERR_BAD_ARG;
+  if ((kp_out || !kp) && !pe) return EA_ERR_BAD_ARG;   // kp == NULL: the operand keys + pe is formed in the kernel
   if (C != SAM_C) return EA_ERR_UNSUPPORTED;
   if (B <= 0 || T <= 0 || (kp_sb & 7) || (k_sb & 7)) return EA_ERR_BAD_SHAPE;
   if (((uintptr_t)kp | (uintptr_t)k | (uintptr_t)pe | (uintptr_t)g2 | (uintptr_t)vo | (uintptr_t)k_out | (uintptr_t)kp_out) & 15) return EA_ERR_BAD_ARG;
@@ -314,5 +458,20 @@ extern "C" int ea_sam_upscale_tail_f16(const void* u0, const float* ln_g, const 
   if (nb > 8192) nb = 8192;
   auto kfn = ea_sam_upscale_tail_kernel;
   EA_LAUNCH(kfn, dim3((unsigned)nb), dim3(256), 0, stream, p);
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_t2i_f16(const void* k, long long k_sb, const void* pe, const void* g, float scale, float* ctx, int B, int T, int C,
+                              void* stream) {
+  if (!k || !pe || !g || !ctx) return EA_ERR_BAD_ARG;
+  if (C != SAM_C) return EA_ERR_UNSUPPORTED;
+  if (B <= 0 || T <= 0 || (T % T2I_TILE) || (k_sb & 7)) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)k | (uintptr_t)pe | (uintptr_t)g | (uintptr_t)ctx) & 15) return EA_ERR_BAD_ARG;
+  SamT2iParams p;
+  p.k = (const f16*)k; p.k_sb = k_sb; p.pe = (const f16*)pe; p.g = (const f16*)g; p.ctx = ctx; p.scale = scale; p.B = B; p.T = T;
+  const int smem = 2 * T2I_TILE * T2I_PITCH;
+  auto kfn = ea_sam_t2i_kernel;
+  ea_allow_big_lds(kfn, smem);
+  EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p);
   return ea_launch_status();
 }

@@ -181,11 +181,11 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
 
 
 def gemm_batched(a, w, out, M, N, K, batch, stride_a, stride_w, stride_c, lda=None, ldw=None, bias=None,
-                 bias_per_row=False, scale=1.0):
-    """Strided-batched GEMM on raw buffers (VAE single-head attention path)."""
+                 bias_per_row=False, scale=1.0, residual=None, stride_r=0):
+    """Strided-batched GEMM on raw buffers (VAE single-head attention path; SAM decoder scores, with an fp32 residual)."""
     ws = workspace(a.device)
-    e = _epilogue(out, N, bias, ACT_NONE, scale, None, None, 1, None, bias_per_row)
-    st = _lib().ea_gemm_f16(_p(a), lda or K, _p(w), ldw or K, M, N, K, batch, stride_a, stride_w, stride_c, 0, C.byref(e),
+    e = _epilogue(out, N, bias, ACT_NONE, scale, residual, None, 1, None, bias_per_row)
+    st = _lib().ea_gemm_f16(_p(a), lda or K, _p(w), ldw or K, M, N, K, batch, stride_a, stride_w, stride_c, stride_r, C.byref(e),
                             _p(ws), ws.numel(), _stream())
     L.check(st, "ea_gemm_f16(batched)")
     return out
@@ -448,7 +448,7 @@ def sam_vo_perm(device):
 def sam_i2t(kp, k, pe, g2, cbias, vo, bo, ln_g, ln_b, eps, scale, B, want_kp=True):
     """Image -> token cross attention + residual + LayerNorm of one TwoWayAttentionBlock, fused per token
     (ea_sam_i2t_f16).  kp / k: fp16 [T, C] (shared by all prompts) or [B, T, C]; -> (k_out, kp_out) fp16 [B, T, C]."""
-    _check_dev(kp, k, g2, vo)
+    _check_dev(k, g2, vo)
     _dense(kp, k, pe, g2, cbias, vo)
     T, Cc = k.shape[-2], k.shape[-1]
     sb = 0 if k.dim() == 2 else T * Cc
@@ -458,6 +458,18 @@ def sam_i2t(kp, k, pe, g2, cbias, vo, bo, ln_g, ln_b, eps, scale, B, want_kp=Tru
                                float(scale), _p(k_out), _p(kp_out), B, T, Cc, _stream())
     L.check(st, "ea_sam_i2t_f16")
     return k_out, kp_out
+
+
+def sam_t2i(k, pe, g, scale, B):
+    """softmax_rows(scale * g (k + pe)^T) k per prompt (ea_sam_t2i_f16): k fp16 [T, C] (shared) or [B, T, C], pe fp16 [T, C],
+    g fp16 [B, 64, C] -> fp32 [B, 64, C]."""
+    _check_dev(k, pe, g)
+    _dense(k, pe, g)
+    T, Cc = k.shape[-2], k.shape[-1]
+    ctx = torch.empty((B, 64, Cc), dtype=torch.float32, device=k.device)
+    st = _lib().ea_sam_t2i_f16(_p(k), 0 if k.dim() == 2 else T * Cc, _p(pe), _p(g), float(scale), _p(ctx), B, T, Cc, _stream())
+    L.check(st, "ea_sam_t2i_f16")
+    return ctx
 
 
 def sam_upscale_tail(u0, ln_g, ln_b, eps, w1, b1, hyper, B, h, w, m0=0, nm=4, out=None):

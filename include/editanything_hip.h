@@ -258,12 +258,18 @@ int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int 
  * kp = keys + positional encoding and k = keys, fp16 [B][T][256] (batch strides kp_sb / k_sb in elements, 0 = one tensor
  * shared by every prompt); g2 fp16 [B][64][256] and cbias fp32 [B][64]: one score column per (head h, token j) at index
  * h * 8 + j (j < 7; column h * 8 + 7 is padding: cbias = -1e30 there); vo fp16 [B][256][64]: vo[b][n][s] multiplies score
- * column ea_sam_vo_perm(s) (the order the MFMA tile pairing leaves the probabilities in).  kp_out (optional, needs pe
- * fp16 [T][256]) = k_out + pe for the next block.  C must be 256. */
+ * column ea_sam_vo_perm(s) (the order the MFMA tile pairing leaves the probabilities in).  kp may be NULL: the operand is
+ * then fp16(k + pe), formed in the kernel (pe fp16 [T][256]; no keys + pe tensor ever stored).  kp_out (optional, needs pe)
+ * = k_out + pe.  C must be 256. */
 int ea_sam_vo_perm(int s);
 int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_sb, const void* pe, const void* g2,
                    const float* cbias, const void* vo, const float* bo, const float* ln_g, const float* ln_b, float eps,
                    float scale, void* k_out, void* kp_out, int B, int T, int C, void* stream);
+/* ea_sam_t2i_f16: the token -> image cross attention of a block with its key / value projections folded into the token
+ * side: ctx[b] = softmax_rows(scale * g[b] (k[b] + pe)^T) k[b], g fp16 [B][64][256] (one row per (head, token), padding rows
+ * arbitrary), k fp16 [B][T][256] (k_sb = 0: shared), pe fp16 [T][256], ctx fp32 [B][64][256].  T % 64 == 0, C = 256. */
+int ea_sam_t2i_f16(const void* k, long long k_sb, const void* pe, const void* g, float scale, float* ctx, int B, int T, int C,
+                   void* stream);
 /* ea_sam_upscale_tail_f16: MaskDecoder.output_upscaling from the first transposed conv's output on (u0 fp16 [B*h*w*4][64],
  * rows ordered (b, y, x, dy, dx)): LayerNorm2d(64, eps) + GELU, ConvTranspose2d(64 -> 32, k 2, s 2) as a per-row product
  * with w1 fp16 [128][64] (row (ddy * 2 + ddx) * 32 + c) + b1, GELU, and the product with the hypernetwork outputs

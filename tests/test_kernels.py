@@ -568,10 +568,13 @@ def test_sam_global_attention_bias_rows(kb):
     assert relerr(kb.down(out), attn_ref(q, k, v, scale, bias).numpy()) < 3e-3
 
 
-def test_softmax_rows(kb):
-    x = f32(5, 300, scale=3.0)
-    out = kb.zeros((5, 300), np.float16)
-    assert kb.lib.ea_softmax_rows_f32_f16(ptr(x), ptr(out), 5, 300, 0.5, kb.stream) == 0
+@pytest.mark.parametrize("rows,cols", [(5, 300), (3, 1000), (4, 4096), (2, 5000), (2, 8192), (2, 8196), (3, 6)])
+def test_softmax_rows(kb, rows, cols):
+    """Register-resident rows (<= 8192 columns, a multiple of 4: 1 / 4 / 8 vectors per thread, ragged last vector) and the
+    generic three-pass loop."""
+    x = f32(rows, cols, scale=3.0)
+    out = kb.zeros((rows, cols), np.float16)
+    assert kb.lib.ea_softmax_rows_f32_f16(ptr(x), ptr(out), rows, cols, 0.5, kb.stream) == 0
     assert relerr(kb.down(out), (t(x) * 0.5).softmax(-1).numpy()) < 2e-3
 
 
@@ -1261,6 +1264,12 @@ def test_sam_i2t_fused(kb, B, T, shared):
     assert relerr(got, ref.numpy()) < 3e-3
     got_kp = kb.down(kp_out).astype(np.float32)
     assert np.abs(got_kp - (got.astype(np.float32) + pe.astype(np.float32)[None])).max() <= 2e-2
+    # kp == NULL: the operand fp16(k + pe) is formed in the kernel -- the same bits as the stored sum
+    k_out2 = kb.zeros((B, T, Cc), np.float16)
+    st = kb.lib.ea_sam_i2t_f16(None, sb, ptr(k), sb, ptr(pe), ptr(g2), ptr(cb), ptr(vo_dev), ptr(bo), ptr(g), ptr(bt), 1e-5, 0.25,
+                               ptr(k_out2), None, B, T, Cc, kb.stream)
+    assert st == 0
+    assert np.array_equal(kb.down(k_out2), got)
 
 
 def test_sam_upscale_tail_fused(kb):
@@ -1289,3 +1298,24 @@ def test_sam_upscale_tail_fused(kb):
     x = F.gelu(F.conv_transpose2d(x, t(wt), t(b1), stride=2))
     ref = torch.einsum("bmc,bchw->bmhw", t(hyper), x)
     assert relerr(kb.down(masks), ref.numpy()) < 3e-3
+
+
+@pytest.mark.parametrize("B,T,shared", [(2, 128, False), (2, 192, True)])
+def test_sam_t2i_fused(kb, B, T, shared):
+    """ea_sam_t2i_f16 == softmax_rows(scale * g (k + pe)^T) k: online softmax over several 64-token tiles, the value operand
+    read transposed (ds_read_b64_tr_b16), probabilities paired into MFMA fragments; a spiked score forces a large rescale."""
+    Cc = 256
+    nb = 1 if shared else B
+    k = f16(nb, T, Cc)
+    pe = f16(T, Cc, scale=0.5)
+    g = f16(B, 64, Cc, scale=0.15)
+    g[0, 5] = (k[0, 100].astype(np.float32) * 0.5).astype(np.float16)      # row 5 of prompt 0 lines up with token 100: max jumps in tile 1
+    ctx = kb.zeros((B, 64, Cc), np.float32)
+    st = kb.lib.ea_sam_t2i_f16(ptr(k), 0 if shared else T * Cc, ptr(pe), ptr(g), 0.25, ptr(ctx), B, T, Cc, kb.stream)
+    assert st == 0
+    kk = t(k).expand(B, T, Cc)
+    kp = (kk + t(pe)[None]).half().float()
+    P = torch.softmax(torch.einsum("bqc,btc->bqt", t(g), kp) * 0.25, dim=-1)
+    ref = torch.einsum("bqt,btc->bqc", P, kk)
+    assert relerr(kb.down(ctx), ref.numpy()) < 3e-3
+    assert kb.lib.ea_sam_t2i_f16(ptr(k), 0, ptr(pe), ptr(g), 0.25, ptr(ctx), B, 100, Cc, kb.stream) != 0     # T % 64
