@@ -42,6 +42,9 @@ def parse():
                     help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
                          "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the two extra single-GPU measurements (process() end-to-end WITH automatic mask generation; "
+                         "the fp32-accurate SAM encoder) that are reported beside the headline")
     return ap.parse_args()
 
 
@@ -92,8 +95,8 @@ def dry_run(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
     shapes = {"w%d" % i: (64, 16 + i) for i in range(5)}
-    sd = synth.synth_state_dict_torch(shapes, args.seed) if rank == 0 else {k: torch.empty(v) for k, v in shapes.items()}
-    sd = eadist.broadcast_state_dict(sd, 0)
+    shapes["n.weight"], shapes["n.bias"] = (48, 32), (48,)                 # one fp16-packed matrix, one fp32 vector
+    sd = eadist.broadcast_packed(synth.synth_state_dict_torch(shapes, args.seed) if rank == 0 else None, shapes, 0)
     checksum = float(sum(v.double().sum() for v in sd.values()))
     units = eadist.shard_indices(args.batch * world, rank, world)          # weak scaling: `batch` images per rank
 
@@ -141,13 +144,12 @@ def main():
                   vae=arch.vae_param_shapes(arch.VAE_KL_F8), sam=arch.sam_encoder_param_shapes(models.SAM_CONFIGS[args.sam]))
     seeds = dict(unet=args.seed + 1, cn=args.seed, vae=args.seed + 2, sam=args.seed + 3)
     sds = {}
+    # rank 0 synthesises the fp32 state dicts; with more than one rank every network is built from views into ONE packed
+    # blob per network that is broadcast device-to-device (dist.broadcast_packed: fp16 matrices, fp32 vectors)
     for name, sh in shapes.items():
-        if rank == 0:
-            sds[name] = synth.synth_state_dict_torch(sh, seeds[name])
-        else:
-            sds[name] = {k: torch.empty(tuple(s), dtype=torch.float32) for k, s in sh.items()}
+        sds[name] = synth.synth_state_dict_torch(sh, seeds[name]) if rank == 0 else None
         if world > 1:
-            sds[name] = {k: v.cpu() for k, v in eadist.broadcast_state_dict(sds[name], 0, device=dev).items()}
+            sds[name] = eadist.broadcast_packed(sds[name], sh, 0, device=dev)
     t_weights = time.time() - t0
     pipe = models.build_pipeline("sd21", sds["unet"], sds["cn"], sds["vae"], dev, inpaint=True, use_graph=not args.no_graph)
     sam = models.ImageEncoderViT(models.SAM_CONFIGS[args.sam], sds["sam"], dev)
@@ -218,6 +220,8 @@ def main():
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
                    "weights_setup_s": round(t_weights, 1), "phase_ms": phases},
     }
+    if world == 1 and not args.no_extras:
+        result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases))
     if rank == 0:
         result["roofline"] = roofline_leg(one_step, pipe, args)
         result["cpu_baseline"] = None
@@ -226,6 +230,96 @@ def main():
         print(json.dumps(result), flush=True)
     pipe.decode_latents = orig_decode
     eadist.barrier()
+
+
+def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, s_per_step, phases):
+    """Two more measurements of the SAME batch on the same GPU, reported beside the headline (which SURVEY 8d defines without
+    the mask decoder):
+
+    `with_amg`  one step = what sam2image.process() does per image (sam2image.py:117-120,154-177) for the whole batch:
+        SAM ViT-H encode -> SamAutomaticMaskGenerator at the reference's settings (32 x 32 point grid = 1024 prompts, 3
+        candidates each, upstream's filters + box NMS) -> show_anns id map (on the device) -> control tensor -> VAE encode ->
+        20 steps ControlNet + UNet -> VAE decode.  With random weights the predicted-IoU / stability numbers are noise, so
+        the two thresholds are set from the scores themselves to let ~300 of the 3072 candidates reach the NMS (a real
+        image: a few hundred); everything else is upstream's default.  `amg_ms_per_image` = decoder + post-processing +
+        NMS + id map per image (the encoder is in `sam_encode`), from device events.
+    `fp32_sam`  the headline step with the fp32-accurate SAM encoder (sam_exact.py: split-operand fp16 MFMA GEMMs, fp32
+        accuracy -- what the reference computes, it never halves SAM) in place of the fp16 one."""
+    from editanything_amd import amg as eamg, arch, models, synth
+    from editanything_amd.sam_exact import ImageEncoderViTExact
+    out = {}
+    B = args.batch
+    imgs_np = inp["images_u8"].cpu().numpy()
+
+    def encode(enc, graph):
+        x = torch.nn.functional.interpolate(inp["images_u8"].permute(0, 3, 1, 2).float(), size=(1024, 1024), mode="bilinear",
+                                            align_corners=False)
+        x = (x - enc.mean) / enc.std
+        return enc.forward_graph(x) if graph else enc.forward(x)
+
+    def denoise(control, seed):
+        gen = torch.Generator("cpu").manual_seed(seed)
+        return pipe(prompt_embeds=embeds_b, negative_prompt_embeds=neg_b, image=init_image, mask_image=mask_b,
+                    controlnet_conditioning_image=control, height=512, width=512, num_inference_steps=args.ddim_steps,
+                    guidance_scale=7.5, num_images_per_prompt=1, generator=gen, output_type="np_device")
+
+    def timed(fn, steps):
+        fn(args.seed + 9000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(args.seed + 9001 + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    # ---- process() end-to-end with automatic mask generation
+    dec = eamg.SamPromptDecoder(synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), args.seed + 12), dev)
+    open_cfg = dict(pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
+    emb = encode(sam, not args.no_graph)
+    sc = np.sort([r["stability_score"] for r in eamg.SamAutomaticMaskGenerator(sam, dec, **open_cfg).generate(imgs_np[0], image_embedding=emb[:1])])
+    thr = float(sc[-300]) if len(sc) >= 300 else -1.0
+    gen = eamg.SamAutomaticMaskGenerator(sam, dec, pred_iou_thresh=-1e9, stability_score_thresh=thr)
+    amg_ms, n_rec = [], []
+
+    def amg_step(seed):
+        emb = encode(sam, not args.no_graph)
+        control = torch.zeros((B, 3, 512, 512), dtype=torch.float32, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for b in range(B):
+            idm, n = gen.generate_id_map(imgs_np[b], image_embedding=emb[b:b + 1])
+            control[b, 0], control[b, 1] = idm % 256, idm // 256           # show_anns' encoding (sam2image.py:110-113)
+            n_rec.append(n)
+        e1.record()
+        res = denoise(control, seed)
+        amg_ms.append((e0, e1))
+        return res
+    t_amg = timed(amg_step, args.steps)
+    per_image = [a.elapsed_time(b) / B for a, b in amg_ms[1:]]
+    out["amg_ms_per_image"] = round(float(np.mean(per_image)), 2)
+    out["with_amg"] = {"metric": "512^2 images/s, process() end-to-end: SAM encode + automatic mask generation + 20-step ControlNet-SD inpaint",
+                       "value": round(B / t_amg, 4), "unit": "images/s", "ms_per_step": round(t_amg * 1e3, 2),
+                       "amg_ms_per_image": out["amg_ms_per_image"], "records_per_image": round(float(np.mean(n_rec)), 1),
+                       "settings": "SamAutomaticMaskGenerator defaults (points_per_side 32 -> 1024 prompts x 3 candidates, box_nms 0.7); "
+                                   "random weights: pred_iou filter open, stability threshold set so ~300 candidates reach the NMS",
+                       "headline_ratio": round((B / t_amg) / (B / s_per_step), 4)}
+    # ---- the fp32-accurate SAM encoder in the headline step
+    enc32 = ImageEncoderViTExact(models.SAM_CONFIGS[args.sam], sds["sam"], dev)
+
+    def exact_step(seed):
+        emb = encode(enc32, False)
+        return emb, denoise(inp["control"], seed)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t32 = timed(exact_step, max(1, min(args.steps, 2)))
+    e0.record(); encode(enc32, False); e1.record()
+    torch.cuda.synchronize()
+    out["fp32_sam"] = {"metric": "512^2 images/s end-to-end with the fp32-accurate SAM encoder", "value": round(B / t32, 4),
+                       "unit": "images/s", "ms_per_step": round(t32 * 1e3, 2), "sam_encode_ms": round(e0.elapsed_time(e1), 2),
+                       "fp16_sam_encode_ms": phases.get("sam_encode(+resize)")}
+    del enc32
+    print(json.dumps(dict(out["with_amg"], n_gpus=1, steps=args.steps, higher_is_better=True, data="synthetic", dtype="f16")),
+          file=sys.stderr, flush=True)
+    return out
 
 
 def roofline_leg(one_step, pipe, args):
@@ -256,7 +350,12 @@ def roofline_leg(one_step, pipe, args):
     other_t = sum(r[1].elapsed_time(r[2]) for r in recs if not r[3].startswith(("gemm", "conv"))) * 1e-3
     n = len(mm)
     achieved = tot_f / tot_t / 1e12
-    traffic, traffic_note = pmc_traffic()
+    classes = {}
+    for r in mm:
+        c = classes.setdefault(r[3], [0, 0.0])
+        c[0] += 1
+        c[1] += r[1].elapsed_time(r[2]) * 1e3
+    traffic, traffic_note = pmc_traffic(classes)
     return {"bound": "mfma", "kernel": "ea_gemm2_kernel / ea_gemm_kernel (MFMA implicit-GEMM conv3x3/1x1 + linear)",
             "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
@@ -265,41 +364,37 @@ def roofline_leg(one_step, pipe, args):
             "contraction_ms_per_step": round(tot_t * 1e3, 2), "attention_norm_ms_per_step": round(other_t * 1e3, 2)}
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel, from the PMC passes of THIS round's shipped kernels
-    (profiles/r02_pmc_traffic_tap_major.json: `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` in separate
-    passes over tools/gemm_bench, tools/gpu_pmc2.sh; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes on gfx950).  Counters cannot be read inside this process, so the figure is the
-    TIME-WEIGHTED mean over the launch classes of one evaluation (weight = launches per evaluation x microseconds per
-    launch, profiles/r02_epilogue_register_direct.jsonl); the per-class table with the algorithmic bytes is in DESIGN.md
-    section 8c.  null when the files are absent."""
+def pmc_traffic(classes):
+    """HBM-side bytes per launch of the dominant kernel.  Counters cannot be read inside this process, so the figure joins
+    two measurements: `classes` = {launch class: (launches, total microseconds)} of THIS run's step (the roofline leg's
+    events), and the PMC passes over the same shipped kernels, one launch class at a time (profiles/r03_pmc_traffic.json:
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` in separate passes over tools/gemm_bench, tools/gpu_visit.sh
+    `pmc:tools/pmc_cases.txt`; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes on gfx950).  -> the TIME-WEIGHTED mean over the classes of the step that have a PMC record, and how much of
+    the contraction time those classes cover.  null when the file is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic_tap_major.json")) as f:
-            cases = json.load(f)["cases"]
-        with open(os.path.join(ROOT, "profiles", "r01_eval_breakdown_v3.json")) as f:
-            calls = {r["op"]: r["calls"] for r in json.load(f)[0]["rows"]}
-        us = {}
-        with open(os.path.join(ROOT, "profiles", "r02_epilogue_register_direct.jsonl")) as f:
-            for line in f:
-                r = json.loads(line)
-                if r.get("debug") == "0" and "us" in r:
-                    us[r["case"]] = r["us"]
-    except (OSError, ValueError, KeyError, IndexError):
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
+            cases = {k.split(" [variant")[0]: v for k, v in json.load(f)["cases"].items() if "hbm_bytes" in v}
+    except (OSError, ValueError, KeyError):
         return None, "no PMC summary under profiles/"
     num = den = 0.0
     n = 0
-    for name, c in cases.items():
-        w = calls.get(name, 0) * us.get(name, 0.0)
-        if w > 0 and "hbm_bytes" in c:
-            num += w * c["hbm_bytes"]
-            den += w
+    total = sum(us for _, us in classes.values())
+    for label, (cnt, us) in classes.items():
+        c = cases.get(label)
+        if c is None:      # ResBlock forms ("... emb" / "... res") of the same convolution: the plain launch's record
+            c = next((v for k, v in cases.items() if k.startswith(label + " ")), None)
+        if c is not None:
+            num += us * c.get("hbm_bytes_with_reduce", c["hbm_bytes"])
+            den += us
             n += 1
     if den == 0:
-        return None, "no weighted classes"
-    return round(num / den), ("bytes per launch of ea_gemm2_kernel, time-weighted mean over %d launch classes of one evaluation "
-                             "(separate --pmc passes on the shipped kernels, profiles/r02_pmc_traffic_tap_major.json; "
-                             "2*FETCH_SIZE + WRITE_SIZE, L2 fabric side: every XCD's L2 fetches the weights once, so "
-                             "weight-heavy classes sit at 2-3x the algorithmic bytes by construction; per class: DESIGN.md 8c)" % n)
+        return None, "no launch class of this step has a PMC record"
+    return round(num / den), ("bytes per contraction launch (split-K reduce included where a class uses one), time-weighted mean over "
+                             "the %d launch classes of this step with a PMC record = %.0f %% of its contraction time (separate --pmc "
+                             "passes on the shipped kernels, profiles/r03_pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, L2 fabric "
+                             "side: every XCD's L2 fetches the weights once, so weight-heavy classes sit above the algorithmic bytes "
+                             "by construction; per class: DESIGN.md 8c)" % (n, 100.0 * den / total))
 
 
 def cpu_baseline(sds, args):

@@ -446,7 +446,10 @@ class SamAutomaticMaskGenerator:
         return self._state
 
     @torch.no_grad()
-    def generate(self, image, image_embedding=None):
+    def _select(self, image, image_embedding=None):
+        """Decode every grid prompt and run upstream's filters on numbers only.  -> None (nothing survives) or a dict with the
+        candidates' low-resolution logits `low`, the surviving candidates' indices into it in NMS order `idx`, their
+        `iou`, `points`, `stability`, `boxes` (device tensors) and the geometry."""
         c = self.cfg
         dec, dev = self.decoder, self.decoder.device
         S = self.encoder.cfg["img_size"] if self.encoder is not None else dec.img_size
@@ -478,7 +481,8 @@ class SamAutomaticMaskGenerator:
         ppts = ptss[0] if len(ptss) == 1 else torch.cat(ptss)
         idx = torch.nonzero(iou > c["pred_iou_thresh"]).reshape(-1)
         if idx.numel() == 0:
-            return []
+            return None
+        geom = ((in_h, in_w), (H, W), S)
         _, stats = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"],
                                             want_masks=False, index=idx.int())
         stab = stats[:, 0] / stats[:, 1]
@@ -486,19 +490,53 @@ class SamAutomaticMaskGenerator:
         k = (stab >= c["stability_score_thresh"]) & ~is_box_near_crop_edge(boxes, crop_box, [0, 0, W, H])
         idx, stab, boxes = idx[k], stab[k], boxes[k]
         if idx.numel() == 0:
-            return []
+            return None
         iou, ppts = iou[idx], ppts[idx]
         order = nms(boxes, iou, c["box_nms_thresh"]).to(dev)
-        idx, iou, ppts, stab, boxes = idx[order], iou[order], ppts[order], stab[order], boxes[order]
-        masks, _ = ops.sam_mask_postprocess(low, (in_h, in_w), (H, W), S, c["mask_threshold"], c["stability_score_offset"],
-                                            index=idx.int())
-        masks = masks.bool()
+        return dict(low=low, idx=idx[order], iou=iou[order], points=ppts[order], stability=stab[order], boxes=boxes[order], geom=geom)
+
+    def _masks(self, sel, lo, hi):
+        """uint8 masks [hi - lo, H, W] of the selected records lo .. hi - 1 (device)."""
+        c = self.cfg
+        (inp, orig, S) = sel["geom"]
+        masks, _ = ops.sam_mask_postprocess(sel["low"], inp, orig, S, c["mask_threshold"], c["stability_score_offset"],
+                                            index=sel["idx"][lo:hi].int())
+        return masks
+
+    @torch.no_grad()
+    def generate(self, image, image_embedding=None):
+        sel = self._select(image, image_embedding)
+        if sel is None:
+            return []
+        H, W = sel["geom"][1]
+        masks = self._masks(sel, 0, len(sel["idx"])).bool()
         areas = masks.flatten(1).sum(1).cpu().tolist()
-        m_np, iou_l, pts_l, stab_l, box_l = masks.cpu().numpy(), iou.cpu().tolist(), ppts.cpu().tolist(), stab.cpu().tolist(), boxes.cpu().tolist()
+        m_np = masks.cpu().numpy()
+        iou_l, pts_l, stab_l, box_l = (sel[k].cpu().tolist() for k in ("iou", "points", "stability", "boxes"))
         return [dict(segmentation=m_np[i], area=int(areas[i]), bbox=[box_l[i][0], box_l[i][1], box_l[i][2] - box_l[i][0],
                                                                       box_l[i][3] - box_l[i][1]],
                      predicted_iou=float(iou_l[i]), point_coords=[pts_l[i]], stability_score=float(stab_l[i]),
                      crop_box=[0, 0, W, H]) for i in range(len(iou_l))]
+
+    @torch.no_grad()
+    def generate_id_map(self, image, image_embedding=None):
+        """What the hot path consumes from `generate` (sam2image.py:117-120: `show_anns(mask_generator.generate(image))`):
+        the id map -- record i paints i + 1 over its mask in list order, later records over earlier ones, i.e. the
+        LARGEST record number covering a pixel -- built on the device from the same mask bytes `generate` returns, without
+        the records' full-size masks ever crossing to the host.  -> (int32 [H, W] device tensor, number of records);
+        `host.show_anns_from_id_map` turns it into show_anns' return value."""
+        sel = self._select(image, image_embedding)
+        H, W = np.asarray(image).shape[:2]
+        idm = torch.zeros((H, W), dtype=torch.int16, device=self.decoder.device)
+        if sel is None:
+            return idm.int(), 0
+        n = len(sel["idx"])
+        for lo in range(0, n, 512):
+            hi = min(n, lo + 512)
+            m = self._masks(sel, lo, hi).ne(0)
+            ids = torch.arange(lo + 1, hi + 1, dtype=torch.int16, device=idm.device)
+            idm = torch.maximum(idm, (m * ids[:, None, None]).amax(0))
+        return idm.int(), n
 
 
 def remove_small_regions(mask, area_thresh, mode):

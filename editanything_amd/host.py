@@ -70,6 +70,24 @@ def show_anns(anns, rng=None):
     return Image.fromarray(np.uint8(full * 255)), res
 
 
+def show_anns_from_id_map(idmap, n, rng=None):
+    """show_anns' return value from the id map itself (amg.generate_id_map): the preview colours are drawn once per
+    record in list order -- the same `n` draws from the same stream as show_anns -- and looked up through the map (the
+    last painter of a pixel is the largest record number, which is what the map holds)."""
+    if n == 0:
+        return None
+    idmap = np.asarray(idmap).astype(np.uint16)
+    rng = rng if rng is not None else np.random
+    colours = np.zeros((n + 1, 3))
+    for i in range(n):
+        colours[i + 1] = rng.random((1, 3)).tolist()[0]
+    full = colours[idmap]
+    res = np.zeros(idmap.shape + (3,))
+    res[:, :, 0] = idmap % 256
+    res[:, :, 1] = idmap // 256
+    return Image.fromarray(np.uint8(full * 255)), res
+
+
 def make_control(detected_map, H, W, num_samples, device):
     """sam2image.py:154-161: uint8 truncation, HWC3, (bilinear) resize to (W, H), float 0..255, b c h w."""
     det = HWC3(detected_map.astype(np.uint8))

@@ -71,6 +71,10 @@ class Demo:
                 im = host.resize_longest_side(im, S)
             emb = self.sam_encoder.encode_image(im)
             self.last_embedding = emb
+        if hasattr(self.mask_generator, "generate_id_map"):
+            # device generator: show_anns' id map is built where the masks are (no full-size masks cross to the host)
+            idmap, n = self.mask_generator.generate_id_map(image, image_embedding=emb)
+            return host.show_anns_from_id_map(idmap.cpu().numpy(), n)
         try:
             masks = self.mask_generator.generate(image, image_embedding=emb)
         except TypeError:

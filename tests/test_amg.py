@@ -239,6 +239,28 @@ def test_process_runs_sam_encoder_decoder_amg_end_to_end():
 
 
 @gpu
+def test_device_id_map_equals_show_anns_of_the_records(device_decoder):
+    """generate_id_map (what process() consumes: no full-size mask crosses to the host) == show_anns(generate(...))'s map,
+    bit for bit, with overlapping masks and more records than one 512-record chunk."""
+    from editanything_amd import host
+    from editanything_amd.amg import SamAutomaticMaskGenerator
+    dec = device_decoder
+    emb = torch.randn(1, 256, 16, 16, generator=torch.Generator().manual_seed(4)).cuda()
+    img = np.zeros((96, 128, 3), np.uint8)
+    gen = SamAutomaticMaskGenerator(None, dec, points_per_side=16, pred_iou_thresh=-1e9, stability_score_thresh=-1.0,
+                                    stability_score_offset=0.002, box_nms_thresh=1.1)
+    recs = gen.generate(img, image_embedding=emb)
+    idm, n = gen.generate_id_map(img, image_embedding=emb)
+    assert n == len(recs) and n > 512
+    res = host.show_anns(recs)[1]
+    assert np.array_equal(idm.cpu().numpy(), (res[..., 0] + 256 * res[..., 1]).astype(np.int32))
+    assert np.array_equal(host.show_anns_from_id_map(idm.cpu().numpy(), n)[1], res)
+    gen0 = SamAutomaticMaskGenerator(None, dec, points_per_side=4, pred_iou_thresh=1e9)
+    idm0, n0 = gen0.generate_id_map(img, image_embedding=emb)
+    assert n0 == 0 and int(idm0.abs().sum()) == 0
+
+
+@gpu
 def test_process_outputs_vs_oracle_chain():
     """`sam2image.process()` (sam2image.py:122-180) against the oracle chained the same way, same seed:
       stage A  image -> SAM encoder -> prompt / mask decoder -> AMG records: every oracle record has a device record from

@@ -84,6 +84,77 @@ def test_weight_broadcast_and_sharding_world2_gloo():
     assert res[0]["mx"] == 2.0 and res[1]["mx"] == 2.0          # bench.py's max-over-ranks timing
 
 
+PACKED_WORKER = textwrap.dedent("""
+    import os, sys, json, hashlib
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch
+    from editanything_amd import arch, dist as eadist, synth
+    rank, world, local = eadist.init_from_env(backend="gloo")
+    shapes = arch.unet_param_shapes(arch.TINY_CONTROLNET, True)
+    sd = synth.synth_state_dict_torch(shapes, 5) if rank == 0 else None          # non-source ranks hold NOTHING but the blob
+    out = eadist.broadcast_packed(sd, shapes, 0, bucket_bytes=64 << 10)          # small buckets -> many slices of the blob
+    ref = synth.synth_state_dict_torch(shapes, 5)
+    lay, total = eadist.packed_layout(shapes)
+    ok = True
+    for k, v in ref.items():
+        half = k.endswith("weight") and v.dim() >= 2
+        ok &= out[k].dtype == (torch.float16 if half else torch.float32) and tuple(out[k].shape) == tuple(v.shape)
+        ok &= torch.equal(out[k], v.half() if half else v)
+    base = min(v.data_ptr() for v in out.values())
+    one_blob = all(0 <= v.data_ptr() - base < total for v in out.values())     # views of ONE allocation
+    h = hashlib.sha1(b"".join(out[k].numpy().tobytes() for k in sorted(ref))).hexdigest()
+    eadist.barrier()
+    print("RESULT " + json.dumps(dict(rank=rank, ok=bool(ok), one_blob=bool(one_blob), sha=h, total=total)), flush=True)
+""")
+
+
+def test_packed_weight_broadcast_world2_gloo():
+    """dist.broadcast_packed (one packed blob, fp16 matrices + fp32 vectors, sent as slices of itself): both ranks
+    end with bit-identical views of one allocation; matrices are the fp16 rounding of the source, vectors exact."""
+    import json
+    res = {}
+    for rc, o in _spawn(2, PACKED_WORKER.format(root=ROOT)):
+        assert rc == 0, o
+        d = json.loads([l for l in o.splitlines() if l.startswith("RESULT ")][-1][7:])
+        res[d["rank"]] = d
+    assert res[0]["ok"] and res[1]["ok"] and res[0]["one_blob"] and res[1]["one_blob"]
+    assert res[0]["sha"] == res[1]["sha"]
+
+
+@pytest.mark.gpu
+def test_networks_built_from_the_packed_blob_compute_the_same_thing():
+    """The packing rule (fp16 for `*.weight` with >= 2 dimensions) only halves what the networks halve themselves: a
+    ControlNet + UNet evaluation, a VAE decode and a SAM encoding from the blob's views equal the ones from the fp32 state
+    dicts bit for bit."""
+    import torch
+    from editanything_amd import arch, dist as eadist, synth
+    from editanything_amd.sam import ImageEncoderViT
+    from editanything_amd.unet import ControlledUnetModel, ControlNet
+    from editanything_amd.vae import AutoencoderKL
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+
+    def pair(shapes, seed):
+        sd = synth.synth_state_dict_torch(shapes, seed)
+        return sd, eadist.broadcast_packed(sd, shapes, 0, device=dev)
+    x, t = torch.randn(2, 4, 16, 16, generator=g).to(dev), torch.tensor([500, 20], device=dev)
+    ctx, hint = torch.randn(2, 77, arch.TINY_UNET["context_dim"], generator=g).to(dev), torch.rand(2, 3, 128, 128, generator=g).to(dev) * 255
+    outs = []
+    for which in (0, 1):
+        cn = ControlNet(arch.TINY_CONTROLNET, pair(arch.unet_param_shapes(arch.TINY_CONTROLNET, True), 5)[which], dev)
+        un = ControlledUnetModel(arch.TINY_UNET, pair(arch.unet_param_shapes(arch.TINY_UNET), 6)[which], dev)
+        vae = AutoencoderKL(arch.TINY_VAE, pair(arch.vae_param_shapes(arch.TINY_VAE), 7)[which], dev)
+        sam = ImageEncoderViT(arch.TINY_SAM, pair(arch.sam_encoder_param_shapes(arch.TINY_SAM), 8)[which], dev)
+        with torch.no_grad():
+            ctrl = cn.forward(x, hint, t, ctx)
+            eps = un.forward(x, t, ctx, control=ctrl)
+            img = vae.decode(x)
+            emb = sam.forward(torch.randn(1, 3, arch.TINY_SAM["img_size"], arch.TINY_SAM["img_size"], generator=torch.Generator().manual_seed(1)).to(dev))
+        outs.append((eps.float().cpu(), img.float().cpu(), emb.float().cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("n,world", [(0, 2), (1, 2), (32, 8), (7, 3)])
 def test_shard_indices_partition(n, world):
     from editanything_amd import dist as eadist

@@ -246,6 +246,21 @@ def test_product_show_anns_idmap_bit_exact_vs_reference_golden():
         assert np.array_equal(ref_fn2(anns)[1], res)
 
 
+def test_show_anns_from_id_map_is_show_anns():
+    """host.show_anns_from_id_map (the device generator's path: amg.generate_id_map) returns exactly what show_anns returns
+    for the records the map was painted from: id map and, with the same random stream, the preview."""
+    g = np.load(os.path.join(GOLD, "host_show_anns.npz"))
+    anns = [{"segmentation": s.astype(bool)} for s in g["segs"]]
+    idmap = np.zeros(g["segs"].shape[1:], np.int32)
+    for i, a in enumerate(anns):
+        idmap = np.maximum(idmap, (i + 1) * a["segmentation"])          # "later records paint over earlier ones" == the largest number
+    p0, r0 = host.show_anns(anns, rng=np.random.RandomState(7))
+    p1, r1 = host.show_anns_from_id_map(idmap, len(anns), rng=np.random.RandomState(7))
+    assert np.array_equal(r0, r1) and np.array_equal(r1, g["res"].astype(np.float64))
+    assert np.array_equal(np.asarray(p0), np.asarray(p1))
+    assert host.show_anns_from_id_map(idmap * 0, 0) is None
+
+
 def test_product_hwc3_and_make_control_vs_reference():
     """annotator/util.py:9-26 (HWC3) and sam2image.py:154-161 (uint8 truncation -> HWC3 -> float 0..255, b c h w)."""
     rng = np.random.default_rng(3)

@@ -203,7 +203,8 @@ int main(int argc, char** argv) {
   for (auto& c : all_cases()) {
     if (cases_sel == "all" && (c.flops > 3e11 || c.name.find("stride") != std::string::npos || c.name.find("l2fit") != std::string::npos)) continue;   // cubes / probes: by name only
     if (cases_sel != "all") {
-      if (cases_sel == "gemm" ? c.conv != 0 : cases_sel == "conv" ? c.conv != 1 : c.name.find(cases_sel) == std::string::npos) continue;
+      if (cases_sel[0] == '=' ? c.name != cases_sel.substr(1)          // "=<name>": exactly that case
+          : cases_sel == "gemm" ? c.conv != 0 : cases_sel == "conv" ? c.conv != 1 : c.name.find(cases_sel) == std::string::npos) continue;
     }
     // ---- operands
     int M, N, K;

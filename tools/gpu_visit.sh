@@ -49,7 +49,7 @@ for step in "$@"; do
         for pass in fetch write; do
           if [ $pass = fetch ]; then CNT="FETCH_SIZE"; else CNT="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; fi
           (cd /tmp && timeout 60 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$D/c${i}_$pass -o p --pmc $CNT -- \
-            $GRAFT_REPO_ROOT/tools/gemm_bench $GRAFT_REPO_ROOT/$LIB --cases "$c" --variants $var --geglu 32 --iters 3 --rounds 1 > /dev/null 2>> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc.err)
+            $GRAFT_REPO_ROOT/tools/gemm_bench $GRAFT_REPO_ROOT/$LIB --cases "=$c" --variants $var --geglu 32 --iters 3 --rounds 1 > /dev/null 2>> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc.err)
         done
         echo "$i|$var|$c" >> $D/cases.txt
       done < "$arg"
