@@ -95,7 +95,6 @@ def dry_run(args):
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}")
     shapes = {"w%d" % i: (64, 16 + i) for i in range(5)}
-    shapes["n.weight"], shapes["n.bias"] = (48, 32), (48,)                 # one fp16-packed matrix, one fp32 vector
     sd = eadist.broadcast_packed(synth.synth_state_dict_torch(shapes, args.seed) if rank == 0 else None, shapes, 0)
     checksum = float(sum(v.double().sum() for v in sd.values()))
     units = eadist.shard_indices(args.batch * world, rank, world)          # weak scaling: `batch` images per rank
@@ -145,7 +144,8 @@ def main():
     seeds = dict(unet=args.seed + 1, cn=args.seed, vae=args.seed + 2, sam=args.seed + 3)
     sds = {}
     # rank 0 synthesises the fp32 state dicts; with more than one rank every network is built from views into ONE packed
-    # blob per network that is broadcast device-to-device (dist.broadcast_packed: fp16 matrices, fp32 vectors)
+    # blob per network that is broadcast device-to-device (dist.broadcast_packed; fp32 masters: the networks fold scales into
+    # their matrices before rounding to fp16, so this is what keeps an N-GPU job bit-identical to a 1-GPU one)
     for name, sh in shapes.items():
         sds[name] = synth.synth_state_dict_torch(sh, seeds[name]) if rank == 0 else None
         if world > 1:
@@ -240,7 +240,7 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
         SAM ViT-H encode -> SamAutomaticMaskGenerator at the reference's settings (32 x 32 point grid = 1024 prompts, 3
         candidates each, upstream's filters + box NMS) -> show_anns id map (on the device) -> control tensor -> VAE encode ->
         20 steps ControlNet + UNet -> VAE decode.  With random weights the predicted-IoU / stability numbers are noise, so
-        the two thresholds are set from the scores themselves to let ~300 of the 3072 candidates reach the NMS (a real
+        the predicted-IoU threshold is set from the scores themselves to let ~300 of the 3072 candidates reach the NMS (a real
         image: a few hundred); everything else is upstream's default.  `amg_ms_per_image` = decoder + post-processing +
         NMS + id map per image (the encoder is in `sam_encode`), from device events.
     `fp32_sam`  the headline step with the fp32-accurate SAM encoder (sam_exact.py: split-operand fp16 MFMA GEMMs, fp32
@@ -276,9 +276,9 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
     dec = eamg.SamPromptDecoder(synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), args.seed + 12), dev)
     open_cfg = dict(pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
     emb = encode(sam, not args.no_graph)
-    sc = np.sort([r["stability_score"] for r in eamg.SamAutomaticMaskGenerator(sam, dec, **open_cfg).generate(imgs_np[0], image_embedding=emb[:1])])
-    thr = float(sc[-300]) if len(sc) >= 300 else -1.0
-    gen = eamg.SamAutomaticMaskGenerator(sam, dec, pred_iou_thresh=-1e9, stability_score_thresh=thr)
+    sc = np.sort([r["predicted_iou"] for r in eamg.SamAutomaticMaskGenerator(sam, dec, **open_cfg).generate(imgs_np[0], image_embedding=emb[:1])])
+    thr = float(sc[-300]) if len(sc) >= 300 else -1e9
+    gen = eamg.SamAutomaticMaskGenerator(sam, dec, pred_iou_thresh=thr, stability_score_thresh=-1.0)
     amg_ms, n_rec = [], []
 
     def amg_step(seed):
@@ -301,7 +301,7 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
                        "value": round(B / t_amg, 4), "unit": "images/s", "ms_per_step": round(t_amg * 1e3, 2),
                        "amg_ms_per_image": out["amg_ms_per_image"], "records_per_image": round(float(np.mean(n_rec)), 1),
                        "settings": "SamAutomaticMaskGenerator defaults (points_per_side 32 -> 1024 prompts x 3 candidates, box_nms 0.7); "
-                                   "random weights: pred_iou filter open, stability threshold set so ~300 candidates reach the NMS",
+                                   "random weights: stability filter open, predicted-IoU threshold set so ~300 candidates reach the NMS",
                        "headline_ratio": round((B / t_amg) / (B / s_per_step), 4)}
     # ---- the fp32-accurate SAM encoder in the headline step
     enc32 = ImageEncoderViTExact(models.SAM_CONFIGS[args.sam], sds["sam"], dev)

@@ -72,15 +72,18 @@ def broadcast_state_dict(sd, src=0, device=None, bucket_bytes=BUCKET_BYTES, grou
     return out
 
 
-def packed_layout(shapes, align=256):
-    """Byte layout of the packed weight blob, computed identically on every rank from {key: shape} alone.  Matrices and
-    convolution kernels (`*.weight` with >= 2 dimensions: the MFMA operands, consumed as fp16 everywhere on the serving
-    path) are stored as fp16; everything else (biases, norm scales, position tables -- consumed in fp32) stays fp32.
-    -> ({key: (byte offset, torch dtype, shape)}, total bytes)."""
+def packed_layout(shapes, half_matrices=False, align=256):
+    """Byte layout of the packed weight blob, computed identically on every rank from {key: shape} alone.
+    half_matrices=False (default): every tensor keeps fp32 -- the networks fold norm scales, attention scales and zero-conv
+    factors into their matrices in fp32 BEFORE rounding them to fp16 operands, so only the fp32 masters give every rank the
+    bits a single-GPU run computes (tests/test_dist.py asserts it).  half_matrices=True: matrices and convolution kernels
+    (`*.weight` with >= 2 dimensions) travel as fp16 -- half the bytes, for checkpoints that are fp16 to begin with (the
+    reference loads its diffusion weights with torch_dtype=float16) -- everything else (biases, norm scales, position
+    tables) stays fp32.  -> ({key: (byte offset, torch dtype, shape)}, total bytes)."""
     lay, off = {}, 0
     for k in sorted(shapes):
         shp = tuple(int(d) for d in shapes[k])
-        dt = torch.float16 if (k.endswith("weight") and len(shp) >= 2) else torch.float32
+        dt = torch.float16 if (half_matrices and k.endswith("weight") and len(shp) >= 2) else torch.float32
         n = 1
         for d in shp:
             n *= d
@@ -89,20 +92,19 @@ def packed_layout(shapes, align=256):
     return lay, off
 
 
-def broadcast_packed(sd, shapes, src=0, device=None, bucket_bytes=BUCKET_BYTES, group=None):
-    """The start-up weight broadcast of SURVEY 8e: ONE packed blob on the device (packed_layout: fp16 matrices, fp32
-    vectors), filled by `src` from its state dict `sd` (other ranks pass None and allocate nothing but the blob), sent in
+def broadcast_packed(sd, shapes, src=0, device=None, bucket_bytes=BUCKET_BYTES, group=None, half_matrices=False):
+    """The start-up weight broadcast of SURVEY 8e: ONE packed blob on the device (packed_layout), filled by `src` from its state dict `sd` (other ranks pass None and allocate nothing but the blob), sent in
     `bucket_bytes` slices of the blob itself -- no per-tensor messages, no concatenation copies, no host round trip --
     and handed back as {key: view into the blob}.  EVERY rank, `src` included, builds its networks from these views, so
     all ranks hold bit-identical weights.  World size 1: the same packing without the collective."""
-    lay, total = packed_layout(shapes)
+    lay, total = packed_layout(shapes, half_matrices)
     blob = torch.empty(total, dtype=torch.uint8, device=device)
     views = {k: blob[off:off + torch.empty((), dtype=dt).element_size() * _numel(shp)].view(dt).view(shp)
              for k, (off, dt, shp) in lay.items()}
     multi = dist.is_initialized() and dist.get_world_size(group) > 1
     if not multi or dist.get_rank(group) == src:
         for k, v in views.items():
-            v.copy_(sd[k])                       # H2D + the fp16 rounding of the matrices, once, on the source
+            v.copy_(sd[k])                       # host -> device (+ the fp16 rounding under half_matrices), once, on the source
     if multi:
         for lo in range(0, total, bucket_bytes):
             dist.broadcast(blob[lo:min(total, lo + bucket_bytes)], src=src, group=group)

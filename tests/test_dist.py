@@ -92,9 +92,9 @@ PACKED_WORKER = textwrap.dedent("""
     rank, world, local = eadist.init_from_env(backend="gloo")
     shapes = arch.unet_param_shapes(arch.TINY_CONTROLNET, True)
     sd = synth.synth_state_dict_torch(shapes, 5) if rank == 0 else None          # non-source ranks hold NOTHING but the blob
-    out = eadist.broadcast_packed(sd, shapes, 0, bucket_bytes=64 << 10)          # small buckets -> many slices of the blob
+    out = eadist.broadcast_packed(sd, shapes, 0, bucket_bytes=64 << 10, half_matrices=True)     # small buckets -> many slices
     ref = synth.synth_state_dict_torch(shapes, 5)
-    lay, total = eadist.packed_layout(shapes)
+    lay, total = eadist.packed_layout(shapes, True)
     ok = True
     for k, v in ref.items():
         half = k.endswith("weight") and v.dim() >= 2
@@ -109,7 +109,7 @@ PACKED_WORKER = textwrap.dedent("""
 
 
 def test_packed_weight_broadcast_world2_gloo():
-    """dist.broadcast_packed (one packed blob, fp16 matrices + fp32 vectors, sent as slices of itself): both ranks
+    """dist.broadcast_packed (one packed blob, here with fp16 matrices + fp32 vectors, sent as slices of itself): both ranks
     end with bit-identical views of one allocation; matrices are the fp16 rounding of the source, vectors exact."""
     import json
     res = {}
@@ -123,9 +123,9 @@ def test_packed_weight_broadcast_world2_gloo():
 
 @pytest.mark.gpu
 def test_networks_built_from_the_packed_blob_compute_the_same_thing():
-    """The packing rule (fp16 for `*.weight` with >= 2 dimensions) only halves what the networks halve themselves: a
-    ControlNet + UNet evaluation, a VAE decode and a SAM encoding from the blob's views equal the ones from the fp32 state
-    dicts bit for bit."""
+    """Networks built from device views of the packed fp32 blob (what every rank of a multi-GPU job does) compute, bit for
+    bit, what the ones built from the host state dicts compute (a single-GPU run): ControlNet + UNet evaluation, VAE
+    decode, SAM encoding."""
     import torch
     from editanything_amd import arch, dist as eadist, synth
     from editanything_amd.sam import ImageEncoderViT

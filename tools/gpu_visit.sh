@@ -11,6 +11,7 @@
 #   pmc:<file>       HBM-side traffic per launch class (separate --pmc FETCH_SIZE / WRITE_SIZE passes over gemm_bench);
 #                    <file> lists one "variant|case name" per line
 #   py:<script>[:<args>]   python <script> <args>  (tools/*.py helpers), output -> <tag>_<script>.log
+#   profpy:<script>[:<args>]   the same under rocprofv3 --kernel-trace --stats -> <tag>_<script>_kernel_stats.csv
 #   sh:<cmd>         anything else ("," -> " ")
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
@@ -57,6 +58,14 @@ for step in "$@"; do
     py)
       script=${arg%%:*}; a=""; [ "$script" != "$arg" ] && a=$(echo "${arg#*:}" | tr ',' ' ')
       timeout 900 python $script $a > gpurun_out/${TAG}_$(basename $script .py).log 2>&1; echo "py rc=$?"; tail -5 gpurun_out/${TAG}_$(basename $script .py).log;;
+    profpy)
+      # rocprofv3 kernel statistics of a python helper: profpy:<script>[:<args>] -> <tag>_<script>_kernel_stats.csv
+      script=${arg%%:*}; a=""; [ "$script" != "$arg" ] && a=$(echo "${arg#*:}" | tr ',' ' '); b=$(basename $script .py)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_$b -o p -- \
+         python $GRAFT_REPO_ROOT/$script $a > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_${b}_prof.log 2>&1)
+      echo "profpy rc=$?"
+      F=$(find gpurun_out/prof_${TAG}_$b -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp "$F" gpurun_out/${TAG}_${b}_kernel_stats.csv
+      rm -rf gpurun_out/prof_${TAG}_$b; head -25 gpurun_out/${TAG}_${b}_kernel_stats.csv | cut -c1-150;;
     sh)
       a=$(echo "$arg" | tr ',' ' '); timeout 900 bash -c "$a" 2>&1 | tail -20;;
     *) echo "unknown step $step";;
