@@ -240,7 +240,8 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
         SAM ViT-H encode -> SamAutomaticMaskGenerator at the reference's settings (32 x 32 point grid = 1024 prompts, 3
         candidates each, upstream's filters + box NMS) -> show_anns id map (on the device) -> control tensor -> VAE encode ->
         20 steps ControlNet + UNet -> VAE decode.  With random weights the predicted-IoU / stability numbers are noise, so
-        the predicted-IoU threshold is set from the scores themselves to let ~300 of the 3072 candidates reach the NMS (a real
+        the stability threshold is set from the scores themselves (the 300th best; ties at 1.0 let more through -- the number of
+        records per image is reported, and is several times what a real image yields) (a real
         image: a few hundred); everything else is upstream's default.  `amg_ms_per_image` = decoder + post-processing +
         NMS + id map per image (the encoder is in `sam_encode`), from device events.
     `fp32_sam`  the headline step with the fp32-accurate SAM encoder (sam_exact.py: split-operand fp16 MFMA GEMMs, fp32
@@ -276,9 +277,9 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
     dec = eamg.SamPromptDecoder(synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), args.seed + 12), dev)
     open_cfg = dict(pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
     emb = encode(sam, not args.no_graph)
-    sc = np.sort([r["predicted_iou"] for r in eamg.SamAutomaticMaskGenerator(sam, dec, **open_cfg).generate(imgs_np[0], image_embedding=emb[:1])])
-    thr = float(sc[-300]) if len(sc) >= 300 else -1e9
-    gen = eamg.SamAutomaticMaskGenerator(sam, dec, pred_iou_thresh=thr, stability_score_thresh=-1.0)
+    sc = np.sort([r["stability_score"] for r in eamg.SamAutomaticMaskGenerator(sam, dec, **open_cfg).generate(imgs_np[0], image_embedding=emb[:1])])
+    thr = float(sc[-300]) if len(sc) >= 300 else -1.0
+    gen = eamg.SamAutomaticMaskGenerator(sam, dec, pred_iou_thresh=-1e9, stability_score_thresh=thr)
     amg_ms, n_rec = [], []
 
     def amg_step(seed):
@@ -301,7 +302,7 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
                        "value": round(B / t_amg, 4), "unit": "images/s", "ms_per_step": round(t_amg * 1e3, 2),
                        "amg_ms_per_image": out["amg_ms_per_image"], "records_per_image": round(float(np.mean(n_rec)), 1),
                        "settings": "SamAutomaticMaskGenerator defaults (points_per_side 32 -> 1024 prompts x 3 candidates, box_nms 0.7); "
-                                   "random weights: stability filter open, predicted-IoU threshold set so ~300 candidates reach the NMS",
+                                   "random weights: predicted-IoU filter open, stability threshold = the 300th best score (ties let more through: see records_per_image)",
                        "headline_ratio": round((B / t_amg) / (B / s_per_step), 4)}
     # ---- the fp32-accurate SAM encoder in the headline step
     enc32 = ImageEncoderViTExact(models.SAM_CONFIGS[args.sam], sds["sam"], dev)

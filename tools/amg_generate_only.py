@@ -1,0 +1,28 @@
+"""Automatic mask generation of one 512 x 512 image from a given embedding (1024 grid prompts, random weights, the stability
+threshold at the 300th best score), id-map output, repeated: the launch list rocprofv3 sees is decoder + post-processing +
+NMS + id map (tools/gpu_visit.sh profpy:tools/amg_generate_only.py -> profiles/r03_amg_*)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from editanything_amd import amg, arch, ops, synth  # noqa: E402
+
+dev = torch.device("cuda:0")
+ops.workspace(dev)
+dec = amg.SamPromptDecoder(synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), 12), dev)
+emb = torch.randn(1, 256, 64, 64, generator=torch.Generator().manual_seed(0)).to(dev)
+img = np.zeros((512, 512, 3), np.uint8)
+g0 = amg.SamAutomaticMaskGenerator(None, dec, pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
+sc = np.sort([r["stability_score"] for r in g0.generate(img, image_embedding=emb)])
+gen = amg.SamAutomaticMaskGenerator(None, dec, pred_iou_thresh=-1e9, stability_score_thresh=float(sc[-300]))
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+gen.generate_id_map(img, image_embedding=emb)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(REPS):
+    idm, n = gen.generate_id_map(img, image_embedding=emb)
+torch.cuda.synchronize()
+print(f"generate_id_map: {(time.perf_counter() - t0) / REPS * 1e3:.2f} ms per image, {n} records")

@@ -32,14 +32,14 @@ def timed(fn, reps=3):
     return best * 1e3, out
 
 
-# predicted-IoU threshold (continuous: no ties, unlike the stability score of random-weight masks) that lets ~300 of the 3072 candidates through the filters (random weights: chosen from the scores themselves)
+# stability threshold (the 300th best score; ties at 1.0 let more through with random weights) that lets ~300 of the 3072 candidates through the filters (random weights: chosen from the scores themselves)
 g0 = SamAutomaticMaskGenerator(enc, dec, pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
-sc = np.sort([r["predicted_iou"] for r in g0.generate(img)])
-thr300 = float(sc[-300]) if len(sc) >= 300 else -1e9
+sc = np.sort([r["stability_score"] for r in g0.generate(img)])
+thr300 = float(sc[-300]) if len(sc) >= 300 else -1.0
 for name, kw in (("all 3072 candidates survive, no NMS (worst case: 3072 full-size masks to the host)",
                   dict(pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)),
-                 ("~300 candidates pass the filters, NMS at the default 0.7 (like a real image)",
-                  dict(pred_iou_thresh=thr300, stability_score_thresh=-1.0)),
+                 ("the 300 most stable candidates (and their ties) pass the filters, NMS at the default 0.7",
+                  dict(pred_iou_thresh=-1e9, stability_score_thresh=thr300)),
                  ("stability filter rejects nearly all", dict(pred_iou_thresh=-1e9, stability_score_thresh=0.9, stability_score_offset=0.002))):
     gen = SamAutomaticMaskGenerator(enc, dec, **kw)
     enc_ms, st = timed(lambda: gen.set_image(img))
