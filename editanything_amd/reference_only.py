@@ -70,6 +70,13 @@ def mix_norm_feature(x, sel, mean_acc, var_acc, do_cfg, style_fidelity, n_uc, ep
 class ReferenceOnly:
     """State of one `ref_image` call: which modules take part, the banks of the current step, the mode."""
 
+    TRACE = None      # tests only: a list collects (kind, tensor) at every bank / mix / AdaIN point, in execution order
+
+    def _trace(self, kind, t):
+        if ReferenceOnly.TRACE is not None:
+            ReferenceOnly.TRACE.append((kind, t.detach().float().cpu()))
+        return t
+
     def __init__(self, unet, controlnet, n_img, do_cfg, ref_mask, inpaint_mask, style_fidelity=0.5, ref_scale=1.0,
                  attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0, reference_attn=True, reference_adain=True):
         assert reference_attn or reference_adain, "`reference_attn` or `reference_adain` must be True."   # check_ref_input :281
@@ -192,7 +199,7 @@ class ReferenceOnly:
         return torch.cat([t, t], dim=0) if self.do_cfg else t
 
     def _mix_ref(self, feat, banked):
-        return add_freq_feature(self._dup(banked), feat, self.ref_scale)        # mix_ref_feature :109-133
+        return self._trace("mix", add_freq_feature(self._dup(banked), feat, self.ref_scale))        # mix_ref_feature :109-133
 
     # ------------------------------------------------------------------ self-attention (hacked_basic_transformer_inner_forward)
     def wants_attn(self, m):
@@ -212,7 +219,7 @@ class ReferenceOnly:
         mask, sel = self._mask_sel(self.ref_mask, H, W)
         if self.mode == "write":
             f = n1.view(B, H, W, Cc)
-            self.bank[id(m)] = ((f.float() * mask).to(n1.dtype), n1[:, sel].contiguous())   # fea_bank, bank (:355-380)
+            self.bank[id(m)] = (self._trace("save", (f.float() * mask).to(n1.dtype)), n1[:, sel].contiguous())   # fea_bank, bank (:355-380)
             return plain(n1)
         fea, tokens = self.bank.pop(id(m))
         mixed = self._mix_ref(n1.view(B, H, W, Cc), fea).reshape(B, N, Cc).contiguous()
@@ -239,7 +246,7 @@ class ReferenceOnly:
         if self.mode == "write":
             mask, sel = self._mask_sel(self.ref_mask, H, W)
             var, mean = masked_stats(h, sel)
-            self.bank[key] = ((h.float() * mask).to(h.dtype), self._dup(mean), self._dup(var))
+            self.bank[key] = (self._trace("save", (h.float() * mask).to(h.dtype)), self._dup(mean), self._dup(var))
             return h
         if key not in self.bank:
             return h
@@ -250,4 +257,4 @@ class ReferenceOnly:
             # `sum(bank) / len(bank)` averages over the batch rows (:698-701, :883-886 with :160-161)
             mean, var = mean.mean(0, keepdim=True), var.mean(0, keepdim=True)
         _, sel = self._mask_sel(self.inpaint_mask, H, W)
-        return mix_norm_feature(h, sel, mean, var, self.do_cfg, self.sf, self.n_img)
+        return self._trace("norm", mix_norm_feature(h, sel, mean, var, self.do_cfg, self.sf, self.n_img))

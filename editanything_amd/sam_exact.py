@@ -129,7 +129,7 @@ class ImageEncoderViTExact:
                        for i in range(cfg["depth"])]
         f = lambda k: sd[k].to(dev, torch.float32)
         self.neck0 = ExactLinear(sd["neck.0.weight"].reshape(sd["neck.0.weight"].shape[0], -1), None, dev)
-        self.neck2_w = f("neck.2.weight")
+        self.neck2 = ExactLinear(sd["neck.2.weight"].reshape(sd["neck.2.weight"].shape[0], -1), None, dev)
         self.ln1, self.ln2 = (f("neck.1.weight"), f("neck.1.bias")), (f("neck.3.weight"), f("neck.3.bias"))
         self.mean = torch.tensor(PIXEL_MEAN, device=dev).view(1, 3, 1, 1)
         self.std = torch.tensor(PIXEL_STD, device=dev).view(1, 3, 1, 1)
@@ -152,7 +152,10 @@ class ImageEncoderViTExact:
             h = blk.forward(h)
         n = self.neck0(h).permute(0, 3, 1, 2)                              # 1x1 conv, no bias
         n = _ln2d(n, *self.ln1)
-        n = F.conv2d(n, self.neck2_w, padding=1)                           # 3x3, 256 -> 256 (0.3 % of the encoder's FLOPs)
+        # 3x3, 256 -> 256 (0.3 % of the encoder's FLOPs) as im2col + the split-operand GEMM: an fp32 F.conv2d of this shape
+        # lands on MIOpen's naive kernel (25 ms per batch of 4, measured: profiles/r03 bench statistics)
+        cols = F.unfold(n, 3, padding=1).transpose(1, 2)                   # [B, g*g, 256 * 9], (c, ky, kx) order = the weight's
+        n = self.neck2(cols).view(B, g, g, -1).permute(0, 3, 1, 2)
         return _ln2d(n, *self.ln2)
 
     __call__ = forward

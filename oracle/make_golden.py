@@ -400,6 +400,61 @@ def refonly_case_kwargs(name, inp, rin):
     return kw
 
 
+def refonly_trace(rr, nets, inp, rin):
+    """PER-MODULE record of one reference-only step (case "full", ONE denoising step): every tensor the reference's helper
+    functions return, in execution order -- `save_ref_feature` (write pass: what each patched module banks),
+    `mix_ref_feature` (read pass: the frequency mix each module continues with), `mix_norm_feature` (read pass: the AdaIN
+    output) -- each as [n, h*w, c].  The same call is traced a second time with 2e-3 relative noise on every feature entering a
+    mix; `refonly_trace_sens[i]` is how far entry i moves under it (the reference's OWN conditioning at that module)."""
+    g_ns = rr.namespace()["StableDiffusionReferencePipeline"].redefine_ref_model.__globals__
+    clean = {k: g_ns[k] for k in ("save_ref_feature", "mix_ref_feature", "mix_norm_feature")}
+
+    def canon(t):
+        t = t.detach().float()
+        return t.permute(0, 2, 3, 1).reshape(t.shape[0], -1, t.shape[1]) if t.dim() == 4 else t
+
+    def traced(noise):
+        trace = []
+        gen = torch.Generator("cpu").manual_seed(1234)
+
+        def save(feature, mask):
+            r = clean["save_ref_feature"](feature, mask)
+            trace.append(("save", canon(r).clone()))
+            return r
+
+        def mix(feature, bank, cfg=True, ref_scale=0.0, dim3=False):
+            if noise:
+                feature = feature + noise * feature.float().pow(2).mean().sqrt() * torch.randn(feature.shape, generator=gen)
+            r = clean["mix_ref_feature"](feature, bank, cfg=cfg, ref_scale=ref_scale, dim3=dim3)
+            trace.append(("mix", canon(r).clone()))
+            return r
+
+        def norm(x, *a, **k):
+            r = clean["mix_norm_feature"](x, *a, **k)
+            trace.append(("norm", canon(r).clone()))
+            return r
+        g_ns.update(save_ref_feature=save, mix_ref_feature=mix, mix_norm_feature=norm)
+        try:
+            pipe = rr.inpaint_pipeline([nets["cn"], nets["cn2"]], nets["unet"], nets["vae"], rin["ref_embeds"])
+            kw = refonly_case_kwargs("full", inp, rin)
+            kw["num_inference_steps"] = 1
+            with torch.no_grad():
+                lat = pipe(ref_prompt="a photo", generator=torch.Generator("cpu").manual_seed(11), **kw).images
+        finally:
+            g_ns.update(clean)
+        return trace, lat
+    tr, lat = traced(0.0)
+    tr2, _ = traced(2e-3)
+    assert [k for k, _ in tr] == [k for k, _ in tr2]
+    out = {"refonly_trace_kinds": np.array([k for k, _ in tr]), "refonly_trace_latents": lat.numpy(),
+           "refonly_trace_sens": np.array([float((b - a).norm() / (a.norm() + 1e-12)) for (_, a), (_, b) in zip(tr, tr2)], np.float32)}
+    for i, (_, t) in enumerate(tr):
+        out[f"refonly_trace_{i}"] = t.numpy().astype(np.float16)
+    print("reference-only trace:", len(tr), "entries;", {k: sum(1 for x, _ in tr if x == k) for k in ("save", "mix", "norm")},
+          "max own sensitivity %.3f" % float(out["refonly_trace_sens"].max()))
+    return out
+
+
 def gen_reference_only():
     """Reference-only control goldens: the reference's inpaint `__call__` with `ref_image`, its
     StableDiffusionReferencePipeline base and every patched forward executed from source
@@ -436,6 +491,7 @@ def gen_reference_only():
         sens = float((lat2 - lat).norm() / lat.norm())
         out["refonly_sens_" + name] = np.float32(sens)
         print("reference-only", name, tuple(lat.shape), float(lat.abs().max()), "own sensitivity to 2e-3 feature noise: %.4f" % sens)
+    out.update(refonly_trace(rr, nets, inp, rin))
     # how far the branch moves the result (the plain call on the same inputs), so a test cannot pass by ignoring it
     pipe = rr.inpaint_pipeline([nets["cn"], nets["cn2"]], nets["unet"], nets["vae"], rin["ref_embeds"])
     kw = refonly_case_kwargs("full", inp, rin)

@@ -7,7 +7,7 @@
 #   pytest[:<k>]     python -m pytest tests -m gpu -x -q [-k <k>]
 #   smoke            __graft_entry__.smoke()
 #   bench[:<args>]   python bench.py <args>  -> <tag>_bench_line.json
-#   prof             rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1 --no-cpu-baseline` -> <tag>_bench_kernel_stats.csv
+#   prof             rocprofv3 --kernel-trace --stats of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras` -> <tag>_bench_kernel_stats.csv
 #   pmc:<file>       HBM-side traffic per launch class (separate --pmc FETCH_SIZE / WRITE_SIZE passes over gemm_bench);
 #                    <file> lists one "variant|case name" per line
 #   py:<script>[:<args>]   python <script> <args>  (tools/*.py helpers), output -> <tag>_<script>.log
@@ -39,7 +39,7 @@ for step in "$@"; do
       echo "bench rc=$?"; tail -c 1800 gpurun_out/${TAG}_bench_line${n}.json;;
     prof)
       (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o bench -- \
-         python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_line.json 2> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.err)
+         python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_line.json 2> $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof.err)
       echo "prof rc=$?"
       F=$(find gpurun_out/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && cp "$F" gpurun_out/${TAG}_bench_kernel_stats.csv
       rm -rf gpurun_out/prof_$TAG; head -12 gpurun_out/${TAG}_bench_kernel_stats.csv | cut -c1-170;;
