@@ -185,7 +185,16 @@ def test_reference_only_per_module_banks_and_mixes_vs_reference_trace(mg, tiny):
     kinds = [str(k) for k in g["refonly_trace_kinds"]]
     assert [k for k, _ in trace] == kinds, ([k for k, _ in trace], kinds)
     sens = g["refonly_trace_sens"]
-    worst = {}
+    # launch order: the reference runs [ControlNet, UNet encoder, UNet decoder]; the product issues the UNet encoder (which
+    # does not depend on the control) BEFORE the ControlNet.  Same modules, same tensors: the product's record is brought
+    # into the reference's order by swapping its two 6-point (write) / 8-point (read) encoder-side segments.
+    n_cn = sum(1 for k in kinds[:12] if k == "save") // 2
+    wr = [k for k in kinds if k == "save"]
+    rd0 = len(wr)
+    seg = next(j for j in range(rd0 + 1, len(kinds)) if g[f"refonly_trace_{j}"].shape == g[f"refonly_trace_{rd0}"].shape) - rd0
+    trace = trace[n_cn:2 * n_cn] + trace[:n_cn] + trace[2 * n_cn:rd0] + trace[rd0 + seg:rd0 + 2 * seg] + trace[rd0:rd0 + seg] + trace[rd0 + 2 * seg:]
+    assert [k for k, _ in trace] == kinds
+    worst, bad = {}, []
     for i, (kind, t) in enumerate(trace):
         ref = torch.from_numpy(g[f"refonly_trace_{i}"].astype(np.float32))
         got = t.reshape(t.shape[0], -1, t.shape[-1])
@@ -193,8 +202,10 @@ def test_reference_only_per_module_banks_and_mixes_vs_reference_trace(mg, tiny):
         assert got.shape[1:] == ref.shape[1:], (i, kind, tuple(got.shape), tuple(ref.shape))
         err = rel_l2(got[:n], ref[:n])
         tol = 1.5e-2 if kind == "save" else max(1.5e-2, 3.0 * float(sens[i]))
-        assert err <= tol, f"point {i} ({kind}, {tuple(ref.shape)}): rel-L2 {err:.3e} > {tol:.3e}"
+        if err > tol:
+            bad.append(f"point {i} ({kind}, {tuple(ref.shape)}): rel-L2 {err:.3e} > {tol:.3e}")
         worst[kind] = max(worst.get(kind, 0.0), err)
+    assert not bad, "\n".join(bad)
     print("reference-only per-module trace:", len(trace), "points, worst rel-L2 per kind", {k: round(v, 4) for k, v in worst.items()})
     assert rel_l2(out, g["refonly_trace_latents"]) <= max(1.5e-2, 3.0 * float(sens.max()))
 

@@ -28,7 +28,7 @@ for step in "$@"; do
       timeout 600 tools/gemm_bench $LIB $a --out gpurun_out/${TAG}_gemm${n}.jsonl > /dev/null 2> gpurun_out/${TAG}_gemm${n}.err
       echo "gemm${n} rc=$? lines=$(wc -l < gpurun_out/${TAG}_gemm${n}.jsonl 2>/dev/null)";;
     pytest)
-      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -x -q -m gpu -k "$arg" > gpurun_out/${TAG}_pytest.log 2>&1
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest tests -x -q -rP -m gpu -k "$arg" > gpurun_out/${TAG}_pytest.log 2>&1
       else timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest.log 2>&1; fi
       echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest.log; tail -3 gpurun_out/${TAG}_pytest.log;;
     smoke)
