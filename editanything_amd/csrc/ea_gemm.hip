@@ -431,9 +431,10 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 #define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
-  const bool tr_raw = t.splits > 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (p.N & 3) == 0 && p.debug != 9;
+  const bool tr_kind = t.kind == 1 || t.kind == 9 || (EA_TOOLS && t.kind == 24);
+  const bool tr_raw = t.splits > 1 && !g_no_tr && tr_kind && (p.N & 3) == 0 && p.debug != 9;
   const bool tr = tr_raw || p.epi_fast == 3 ||
-                  (p.epi_fast == 1 && !g_no_tr && (t.kind == 1 || t.kind == 9) && (((uintptr_t)p.epi.bias) & 15) == 0 &&
+                  (p.epi_fast == 1 && !g_no_tr && tr_kind && (((uintptr_t)p.epi.bias) & 15) == 0 &&
                    (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
   // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
   if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
@@ -449,6 +450,24 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   } while (0)
   if (tr) {
     const bool lnx = p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1);   // fold / statistics compiled in
+#if EA_TOOLS
+    // kind 24 (experiment): ONE 8-wave workgroup per CU on a 256-row tile -- the two co-resident 128-row workgroups merged,
+    // the weight panel fetched once for both halves; same wave tiles, same epilogue
+    if (t.kind == 24) {
+      if (lnx) return EA_ERR_UNSUPPORTED;
+      if (t.bn == 160) {
+        auto kfn = ea_gemm2_kernel<256, 160, 4, 2, 2, 16, 0, 0, 1>;
+        const int smem = 2 * (256 + 160) * 128;
+        ea_allow_big_lds(kfn, smem);
+        EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);
+      } else {
+        auto kfn = ea_gemm2_kernel<256, 128, 4, 2, 2, 16, 0, 0, 1>;
+        const int smem = 2 * (256 + 128) * 128;
+        ea_allow_big_lds(kfn, smem);
+        EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);
+      }
+    } else
+#endif
     if (t.kind == 1) {
       if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
       else { if (lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
@@ -480,6 +499,9 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
     case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
     case 13: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 2); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 2); break;   // ping-pong
+    // kind 25 (experiment): 128 x 80 WAVE tiles (256 x 160 per workgroup, 4 compute + 4 loader waves, 3-deep ring): 13 fragment
+    // reads per 40 MFMAs instead of 9 per 20 -- the LDS read rate per MFMA cycle drops from 29 to 21 bytes per wave
+    case 25: if (t.bn == 160) EA_LAUNCH_G2L(256, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(256, 128, 2, 2, 3, 16, 0, 1); break;
     case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
 #endif
     default: return EA_ERR_UNSUPPORTED;

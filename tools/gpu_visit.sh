@@ -16,7 +16,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=$1; shift
-LIB=editanything_amd/csrc/libeditanything_hip.so
+LIB=${EA_VISIT_LIB:-editanything_amd/csrc/libeditanything_hip.so}
 n=0
 for step in "$@"; do
   n=$((n+1))
