@@ -451,8 +451,10 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   if (tr) {
     const bool lnx = p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1);   // fold / statistics compiled in
 #if EA_TOOLS
-    // kind 24 (experiment): ONE 8-wave workgroup per CU on a 256-row tile -- the two co-resident 128-row workgroups merged,
-    // the weight panel fetched once for both halves; same wave tiles, same epilogue
+    // kind 24 (experiment, round 3): ONE 8-wave workgroup per CU on a 256-row tile -- the two co-resident 128-row workgroups
+    // merged, the weight panel fetched once for both halves (22 % fewer operand bytes from L2); same wave tiles, same
+    // epilogue.  Measured 3-10 % SLOWER than the two independent workgroups on every level-0 / SAM class
+    // (profiles/r03_kind24_merged_workgroups.jsonl): operand traffic is not what bounds the loop
     if (t.kind == 24) {
       if (lnx) return EA_ERR_UNSUPPORTED;
       if (t.bn == 160) {
@@ -499,9 +501,6 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     case 10: if (t.bn == 160) EA_LAUNCH_G2L(128, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(128, 128, 2, 2, 3, 16, 0, 1); break;
     case 12: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 2, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 2, 16, 0, 1); break;
     case 13: if (t.bn == 160) EA_LAUNCH_G2(256, 160, 4, 2, 3, 16, 2); else EA_LAUNCH_G2(256, 128, 4, 2, 3, 16, 2); break;   // ping-pong
-    // kind 25 (experiment): 128 x 80 WAVE tiles (256 x 160 per workgroup, 4 compute + 4 loader waves, 3-deep ring): 13 fragment
-    // reads per 40 MFMAs instead of 9 per 20 -- the LDS read rate per MFMA cycle drops from 29 to 21 bytes per wave
-    case 25: if (t.bn == 160) EA_LAUNCH_G2L(256, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(256, 128, 2, 2, 3, 16, 0, 1); break;
     case 11: if (t.bn == 160) EA_LAUNCH_G2L(64, 160, 2, 2, 3, 16, 0, 1); else EA_LAUNCH_G2L(64, 128, 2, 2, 3, 16, 0, 1); break;
 #endif
     default: return EA_ERR_UNSUPPORTED;

@@ -81,7 +81,7 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // LDS-slab epilogues cost 25 % of the contraction time of an evaluation (10-54 us per launch; the bare store stream of
 // the same bytes takes 5-15 us, tools/probe_misc).  Same products and the same fp32 summation order as TR = 0.
 template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
-__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (BM >= 256 ? 1 : STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
+__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
 void ea_gemm2_kernel(EaGemmParams p) {
   constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR);
   static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && STAGES == 2), "register-direct epilogue: the 2-stage 16x16x32 tiles");
