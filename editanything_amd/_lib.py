@@ -31,6 +31,7 @@ class Epilogue(C.Structure):
         ("out", _vp), ("ldc", C.c_int32), ("out_f32", C.c_int32), ("geglu_block", C.c_int32),
         ("ln_stats", _vp), ("ln_parts", C.c_int32), ("ln_colsum", _vp), ("ln_eps", C.c_float), ("row_stats_out", _vp),
         ("gn_stats_out", _vp), ("gn_rows_per_sample", C.c_int32), ("gn_cpg", C.c_int32),
+        ("gn_next_out", _vp), ("gn_next_gamma", _vp), ("gn_next_beta", _vp), ("gn_next_eps", C.c_float), ("gn_next_silu", C.c_int32),
     ]
 
 
@@ -64,6 +65,7 @@ SIGNATURES = {
     "ea_row_stats_parts": (_i, [_i]),
     "ea_gemm_ln_fold_ok": (_i, [_i, _i, _i]),
     "ea_gemm_gn_stats_chunk_rows": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ea_gemm_gn_next_ok": (_i, [_i, _i, _i, _i, _i, _i]),
     "ea_groupnorm_apply_f16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "ea_gemm_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, C.POINTER(Epilogue), _vp, _sz, _vp]),
     "ea_conv2d_f16": (_i, [C.POINTER(ConvSrc), _vp, _i, C.POINTER(Epilogue), _vp, _sz, _vp]),

@@ -61,6 +61,14 @@ static int fill_epilogue(EaEpilogue& e, const ea_epilogue* epi, int M, int N) {
   e.gn_stats_out = epi->gn_stats_out;
   e.gn_hw = epi->gn_rows_per_sample;
   e.gn_cpg = epi->gn_cpg;
+  e.gn_next_out = (f16*)epi->gn_next_out;
+  e.gn_next_gamma = epi->gn_next_gamma;
+  e.gn_next_beta = epi->gn_next_beta;
+  e.gn_next_eps = epi->gn_next_eps;
+  e.gn_next_silu = epi->gn_next_silu;
+  if (e.gn_next_out && (!e.gn_next_gamma || !e.gn_next_beta || e.gn_hw <= 0 || e.gn_cpg < 4 || (e.gn_cpg & 3) || e.gn_stats_out ||
+                        ((((uintptr_t)e.gn_next_out) | ((uintptr_t)e.gn_next_gamma) | ((uintptr_t)e.gn_next_beta)) & 15)))
+    return EA_ERR_BAD_ARG;
   if (e.gn_stats_out && (e.gn_hw <= 0 || e.gn_cpg < 8 || (((uintptr_t)e.gn_stats_out) & 7) || epi->act == EA_ACT_GEGLU)) return EA_ERR_BAD_ARG;
   if (e.ln_stats && (!e.ln_colsum || e.ln_parts <= 0)) return EA_ERR_BAD_ARG;
   if ((((uintptr_t)e.ln_stats) & 7) || (((uintptr_t)e.ln_colsum) & 15) || (((uintptr_t)e.row_stats_out) & 7)) return EA_ERR_BAD_ARG;
@@ -222,6 +230,29 @@ static int launch_reduce(EaGemmParams& p, void* stream) {
   return ea_launch_status();
 }
 
+// ---- split-K reduction that also applies the consuming GroupNorm (ea_gemm.h ea_splitk_reduce_gn_kernel)
+// shape side of the decision (ea_gemm_gn_next_ok + the launch): whole samples, 4-channel pieces, a slab one workgroup holds
+static bool gn_next_shape_ok(int M, int N, int hw, int cpg) {
+  if (hw <= 0 || cpg < 4 || (cpg & 3) || (N % cpg) || (M % hw) || (N & 3)) return false;
+  return (long long)hw * (cpg >> 2) <= 256ll * EA_RGN_MAXQ;
+}
+static bool gn_next_epi_ok(const EaGemmParams& p) {
+  const EaEpilogue& e = p.epi;
+  return p.batch == 1 && !e.out_f32 && !e.bias_per_row && !e.row_scale && !e.residual32 && !e.row_stats_out && !e.ln_stats &&
+         (e.act == EA_ACT_NONE || e.act == EA_ACT_SILU) && (e.ldc & 3) == 0 && (!e.residual || (e.ldr & 3) == 0) &&
+         (!e.rowvec || (e.rowvec_ld & 3) == 0) &&
+         ((((uintptr_t)e.out) | ((uintptr_t)e.residual)) & 7) == 0 && ((((uintptr_t)e.bias) | ((uintptr_t)e.rowvec)) & 15) == 0;
+}
+static int launch_reduce_gn(EaGemmParams& p, void* stream) {
+  const EaEpilogue& e = p.epi;
+  const long long nq = (long long)e.gn_hw * (e.gn_cpg >> 2);
+  dim3 grid((unsigned)(p.N / e.gn_cpg), (unsigned)(p.M / e.gn_hw), 1);
+  if (nq <= 256 * 4) { auto k = ea_splitk_reduce_gn_kernel<4>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
+  else if (nq <= 256 * 12) { auto k = ea_splitk_reduce_gn_kernel<12>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
+  else { auto k = ea_splitk_reduce_gn_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
+  return ea_launch_status();
+}
+
 // fallback producer of the output row statistics (launches whose epilogue could not write them)
 static int launch_row_stats(EaGemmParams& p, void* stream) {
   const EaEpilogue& e = p.epi;
@@ -338,6 +369,7 @@ static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t
     p.partial = (float*)workspace;
   }
   if ((p.epi.ln_stats || p.epi.gn_stats_out) && t.splits > 1) return EA_ERR_UNSUPPORTED;
+  if (p.epi.gn_next_out) return EA_ERR_UNSUPPORTED;
   const int items = ((p.M + 127) / 128) * ((p.N + t.bn - 1) / t.bn) * t.splits;
   const int ncu = cu_count();
   dim3 grid(items < ncu ? items : ncu, 1, 1);
@@ -438,6 +470,8 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
                    (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
   // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
   if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
+  // the consuming GroupNorm rides on the split-K reduction of the raw register-direct dump only (callers ask ea_gemm_gn_next_ok)
+  if (p.epi.gn_next_out && (!tr_raw || !gn_next_shape_ok(p.M, p.N, p.epi.gn_hw, p.epi.gn_cpg) || !gn_next_epi_ok(p))) return EA_ERR_UNSUPPORTED;
   // ... and so do the GroupNorm partials (callers ask ea_gemm_gn_stats_chunk_rows first)
   if (p.epi.gn_stats_out && (!tr || t.splits > 1 || p.epi_fast != 1 || p.batch != 1 || !gn_stats_rows(t, p.M, p.N, p.epi.gn_hw, p.epi.gn_cpg)))
     return EA_ERR_UNSUPPORTED;
@@ -479,7 +513,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     }
     int st_tr = ea_launch_status();
     if (st_tr == EA_OK && t.splits > 1) {
-      st_tr = launch_reduce(p, stream);
+      st_tr = p.epi.gn_next_out ? launch_reduce_gn(p, stream) : launch_reduce(p, stream);
       if (st_tr == EA_OK) st_tr = launch_row_stats(p, stream);
     }
     return st_tr;                  // (unsplit launches: row statistics, if asked for, were written by the epilogue)
@@ -518,7 +552,7 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   read_env();
   if (!g_force_generic && fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
   if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
-  if (p.epi.ln_stats || p.epi.gn_stats_out) return EA_ERR_UNSUPPORTED;
+  if (p.epi.ln_stats || p.epi.gn_stats_out || p.epi.gn_next_out) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
   TilePlan t = plan_tiles(p.M, p.N, p.K, p.batch, allow_split);
   p.splits = t.splits;
@@ -586,6 +620,15 @@ extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   }
   Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
   return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
+}
+
+extern "C" int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
+  if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+  read_env();
+  if (g_force_generic || g_no_tr || (g_variant != 0 && g_variant != 1 && g_variant != 9)) return 0;
+  if (!gn_next_shape_ok(M, N, rows_per_sample, cpg)) return 0;
+  const Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
+  return (t.splits > 1 && (t.kind == 1 || t.kind == 9)) ? 1 : 0;
 }
 
 extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {

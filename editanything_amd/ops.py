@@ -218,6 +218,22 @@ def _rows_per_group(rowvec, s):
 GN_EPILOGUE = os.environ.get("EA_GN_EPILOGUE", "1") != "0"      # A/B switch (tools/): 0 keeps the statistics passes
 
 
+class Normed:
+    """A GroupNorm that the PRODUCING launch already applied (split-K reduction + the consuming norm in one kernel,
+    `ea_epilogue.gn_next_out`): handed to `groupnorm(..., stats=)` in place of statistics, which then returns `t` as is."""
+
+    def __init__(self, t, gamma, eps, silu):
+        self.t, self.gamma_ptr, self.eps, self.silu = t, gamma.data_ptr(), float(eps), bool(silu)
+
+
+def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
+    """True when a contraction of this shape is split along K and its reduction can apply the GroupNorm that consumes the
+    output (`ea_epilogue.gn_next_out`)."""
+    if not GN_EPILOGUE or PROFILE is not None or N % groups:
+        return False
+    return bool(_lib().ea_gemm_gn_next_ok(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
+
+
 def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
     """Rows per GroupNorm-statistics chunk when a contraction of this shape can leave the partials of its OUTPUT behind
     for the GroupNorm that reads it (`ea_epilogue.gn_stats_out`), else 0."""
@@ -228,11 +244,13 @@ def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
 
 def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
            residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None,
-           gn_groups=0):
+           gn_groups=0, gn_next=None):
     """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin).
 
     gn_groups > 0: the caller's next op is a GroupNorm over this output -- returns (out, stats) with stats =
-    (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them."""
+    (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them.
+    gn_next = (gamma, beta, eps, silu) of that GroupNorm, when the caller knows it: where the launch is split along K its
+    reduction applies the norm itself and stats is a `Normed` (the normalised tensor)."""
     _check_dev(x1, w)
     _dense(x1, x2, x2_add, w, residual, out)
     s = _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout)
@@ -245,7 +263,15 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
     if gn_groups:
         hw = s.Hout * s.Wout
         rows = gn_stats_plan(s.B * hw, cout, w.shape[1], 1, hw, gn_groups) if out.dtype == torch.float16 else 0
-        if rows:
+        if (gn_next is not None and not rows and out.dtype == torch.float16 and act in (ACT_NONE, ACT_SILU) and row_scale is None
+                and gn_next_plan(s.B * hw, cout, w.shape[1], 1, hw, gn_groups)):
+            gamma, beta, eps, silu = gn_next
+            normed = torch.empty_like(out)
+            e.gn_next_out, e.gn_next_gamma, e.gn_next_beta = _p(normed), _p(gamma), _p(beta)
+            e.gn_next_eps, e.gn_next_silu = float(eps), int(bool(silu))
+            e.gn_rows_per_sample, e.gn_cpg = hw, cout // gn_groups
+            stats = Normed(normed, gamma, eps, silu)
+        elif rows:
             part = torch.empty((s.B, hw // rows, gn_groups, 2), dtype=torch.float32, device=x1.device)
             e.gn_stats_out, e.gn_rows_per_sample, e.gn_cpg = _p(part), hw, cout // gn_groups
             stats = (part, hw // rows)
@@ -266,6 +292,10 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
     c1 = x1.shape[-1]
     c2 = x2.shape[-1] if x2 is not None else 0
     HW = x1.numel() // (B * c1)
+    if isinstance(stats, Normed):
+        assert x2 is None and out is None and stats.gamma_ptr == gamma.data_ptr() and stats.silu == bool(silu) and \
+            abs(stats.eps - eps) < 1e-12, "the producing launch applied a different GroupNorm"
+        return stats.t.view(x1.shape)
     if out is None:
         out = torch.empty(x1.shape[:-1] + (c1 + c2,), dtype=torch.float16, device=x1.device)
     if stats is not None:
@@ -286,7 +316,7 @@ def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=N
 
 def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=None, x2_add=None, stride=1, pad=1,
                            ups=False, residual=None, rowvec=None, scale=1.0, out_dtype=torch.float16, gn_in=None,
-                           gn_out_groups=0):
+                           gn_out_groups=0, gn_next=None):
     """ResBlock half (openaimodel.py:254-274): GroupNorm32 -> SiLU -> conv3x3 (+ embedding row vector / + skip).
 
     gn_in: this GroupNorm's statistics, left behind by the launch that produced x1 (then the norm is the streaming
@@ -297,7 +327,7 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
     if gn_in is not None or gn_out_groups:
         n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add, stats=gn_in)
         return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype,
-                      gn_groups=gn_out_groups)
+                      gn_groups=gn_out_groups, gn_next=gn_next)
     if PROFILE is not None:     # roofline leg: same kernels, launched separately so events bracket only the MFMA kernel
         n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add)
         return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype)

@@ -82,20 +82,23 @@ class _Res:
             self.skip_w = pack_conv(sd[p + "skip_connection.weight"], device)
             self.skip_b = _f32(sd[p + "skip_connection.bias"], device)
 
-    def forward(self, x1, x2, emb_all, gn_in=None, gn_out=False):
+    def forward(self, x1, x2, emb_all, gn_in=None, gn_out=False, gn_next=None):
         """gn_in: statistics of x1 for in_layers' GroupNorm, left by the launch that produced x1 (single-source input
         only).  gn_out: the caller's next op is a 32-group GroupNorm over the result (a SpatialTransformer's norm / the
         next ResBlock's in_layers) -- returns (h, stats-or-None).  The out_layers GroupNorm always takes its statistics
-        from the in_layers conv's epilogue where that launch can emit them (ops.gn_stats_plan)."""
+        from the in_layers conv's epilogue where that launch can emit them (ops.gn_stats_plan) -- or, where that conv is
+        split along K, is applied by its reduction kernel outright (ops.gn_next_plan); gn_next = (gamma, beta, eps, silu) of
+        the caller's norm lets the out_layers conv do the same for it."""
         rowvec = emb_all[:, self.emb_off:self.emb_off + self.cout]
         h, st2 = ops.groupnorm_silu_conv3x3(x1, self.g1w, self.g1b, self.w1, self.b1, x2=x2, rowvec=rowvec,
-                                            gn_in=gn_in if x2 is None else None, gn_out_groups=32)
+                                            gn_in=gn_in if x2 is None else None, gn_out_groups=32,
+                                            gn_next=(self.g2w, self.g2b, 1e-5, True))
         if self.skip_w is not None:
             res = ops.conv2d(x1, self.skip_w, self.skip_b, ksize=1, pad=0, x2=x2)
         else:
             res = x1
         out = ops.groupnorm_silu_conv3x3(h, self.g2w, self.g2b, self.w2, self.b2, residual=res, gn_in=st2,
-                                         gn_out_groups=32 if gn_out else 0)
+                                         gn_out_groups=32 if gn_out else 0, gn_next=gn_next if gn_out else None)
         if gn_out:
             return out
         return out[0] if isinstance(out, tuple) else out
@@ -273,7 +276,8 @@ class _UNetBase:
                 if ref is not None:
                     h = ref.after_res(m, m.forward(h, x2, emb_all))      # AdaIN point of the attention-free levels
                 elif feeds_norm:
-                    h, stats = m.forward(h, x2, emb_all, gn_out=True)
+                    nxt = mods[k + 1][1]
+                    h, stats = m.forward(h, x2, emb_all, gn_out=True, gn_next=(nxt.nw, nxt.nb, 1e-6, False))
                 else:
                     h = m.forward(h, x2, emb_all)
                 x2 = None

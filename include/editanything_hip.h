@@ -97,7 +97,20 @@ typedef struct ea_epilogue {
    * (EA_ERR_UNSUPPORTED otherwise).  NULL = off. */
   float* gn_stats_out;
   int32_t gn_rows_per_sample;   /* output rows (pixels) per sample: M = B * gn_rows_per_sample */
-  int32_t gn_cpg;               /* channels per group (>= 8) */
+  int32_t gn_cpg;               /* channels per group (>= 8; gn_next_out: a multiple of 4) */
+  /* The GroupNorm (+ SiLU) that CONSUMES this launch's fp16 output, applied by the split-K reduction itself (ResBlock
+   * in_layers conv -> out_layers GroupNorm -> SiLU, out_layers conv + skip -> the next block's norm, at the 16 x 16 / 8 x 8
+   * levels where the contraction is split along K: openaimodel.py:254-274, attention.py:308-311).  The reduction kernel is
+   * laid out one workgroup per (sample, group): it sums the fp32 slices, applies bias / row vector / residual, writes the
+   * fp16 output `out`, takes the group's statistics from those ROUNDED values while they are still in registers and writes
+   * gn_next_out[m][n] = act((out[m][n] - mean) * rstd * gamma[n] + beta[n]) -- no statistics pass, no normalise pass.
+   * Uses gn_rows_per_sample / gn_cpg above.  Only launches for which ea_gemm_gn_next_ok() returns 1 accept it
+   * (EA_ERR_UNSUPPORTED otherwise).  gn_next_out NULL = off. */
+  void* gn_next_out;            /* fp16 [M][ldc] */
+  const float* gn_next_gamma;   /* [N] */
+  const float* gn_next_beta;    /* [N] */
+  float gn_next_eps;
+  int32_t gn_next_silu;
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and
@@ -145,6 +158,10 @@ int ea_gemm_ln_fold_ok(int M, int N, int K);
 /* Rows per GroupNorm-statistics chunk (the wave tile height of the instantiation the planner picks) when a launch of
  * this shape can emit `gn_stats_out` from its epilogue, else 0: unsplit register-direct launches whose wave tiles hold
  * whole groups and whole-sample row ranges.  conv: 1 for ea_conv2d_f16 launches (M = B * Hout * Wout, K = ks*ks*Cin). */
+/* 1 if a launch of this shape (conv != 0: implicit-GEMM convolution) is split along K and its reduction can apply the
+ * consuming GroupNorm (ea_epilogue.gn_next_out): whole samples of rows_per_sample rows, groups of cpg channels (cpg % 4 == 0),
+ * one (sample, group) slab small enough for one workgroup's registers. */
+int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sample, int cpg);
 int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg);
 
 /* C[b] = epilogue(A[b] (MxK, lda) * W[b]^T (NxK, ldw)), b < batch. */

@@ -78,7 +78,7 @@ def _is_f32(a):
 
 def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual32=None, ldr=None, rowvec=None,
              rows_per_group=1, row_scale=None, bias_per_row=0, geglu_block=0, ln_stats=None, ln_parts=0, ln_colsum=None,
-             ln_eps=1e-5, row_stats_out=None, gn_stats_out=None, gn_rows_per_sample=0, gn_cpg=0):
+             ln_eps=1e-5, row_stats_out=None, gn_stats_out=None, gn_rows_per_sample=0, gn_cpg=0, gn_next=None):
     e = L.Epilogue()
     e.bias = ptr(bias)
     e.bias_per_row = bias_per_row
@@ -104,6 +104,9 @@ def epilogue(out, ldc=None, bias=None, act=0, scale=1.0, residual=None, residual
     e.gn_stats_out = ptr(gn_stats_out)
     e.gn_rows_per_sample = gn_rows_per_sample
     e.gn_cpg = gn_cpg
+    if gn_next is not None:          # (normalised output, gamma, beta, eps, silu)
+        e.gn_next_out, e.gn_next_gamma, e.gn_next_beta = ptr(gn_next[0]), ptr(gn_next[1]), ptr(gn_next[2])
+        e.gn_next_eps, e.gn_next_silu = gn_next[3], int(gn_next[4])
     return e
 
 

@@ -953,6 +953,73 @@ def test_groupnorm_statistics_from_the_producing_conv(kb, B, H, cin, cout, group
     assert np.abs(kb.down(out).astype(np.float32) - kb.down(out2).astype(np.float32)).max() <= 4e-3 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("B,H,cin,cout,emb,res,silu,splits", [
+    (2, 8, 128, 1280, True, False, True, 3),     # in_layers conv at the 8 x 8 level -> out_layers GroupNorm + SiLU; cpg 40, 640 pieces
+    (2, 16, 64, 1280, False, True, False, 2),    # out_layers conv + skip -> SpatialTransformer norm (no SiLU); 2560 pieces (12 per thread)
+    (1, 32, 64, 640, True, True, True, 4),       # cpg 20: 5 pieces per row, 5120 pieces (the 24-per-thread instantiation)
+    (3, 8, 64, 320, False, False, True, 2),      # cpg 10 -> not a multiple of 4: refused
+])
+def test_split_k_reduction_applies_the_consuming_groupnorm(kb, B, H, cin, cout, emb, res, silu, splits):
+    """`gn_next_out`: the split-K reduction (one workgroup per (sample, group)) writes the output AND its GroupNorm (+ SiLU):
+    the output is bit-identical to the plain split-K launch's, the normalised tensor equals ea_groupnorm_f16 of that output
+    (same statistics definition: the ROUNDED fp16 values) and torch's GroupNorm (openaimodel.py:254-274, attention.py:308-311)."""
+    groups = 32
+    HW, M, K = H * H, B * H * H, 9 * cin
+    cpg = cout // groups
+    tune(kb, splits=splits)
+    x = f16(B, H, H, cin)
+    W = f16(cout, K, scale=0.05)
+    bias = f32(cout)
+    rv = f32(B, cout) if emb else None
+    R = f16(M, cout) if res else None
+    gamma, beta = f32(cout), f32(cout)
+    eps = 1e-5 if silu else 1e-6
+    ws = workspace(kb, max(kb.lib.ea_gemm_workspace_bytes(M, cout, K, 1), 4 * splits * M * cout))
+    src = conv_src(x)
+    y0 = kb.zeros((M, cout), np.float16)
+    e0 = epilogue(y0, bias=bias, rowvec=rv, rows_per_group=HW, residual=R)
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e0), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    y = kb.zeros((M, cout), np.float16)
+    n = kb.zeros((M, cout), np.float16)
+    e = epilogue(y, bias=bias, rowvec=rv, rows_per_group=HW, residual=R, gn_rows_per_sample=HW, gn_cpg=cpg,
+                 gn_next=(n, gamma, beta, eps, silu))
+    ok = kb.lib.ea_gemm_gn_next_ok(M, cout, K, 1, HW, cpg)
+    st = kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream)
+    if cpg % 4:
+        assert ok == 0 and st != 0
+        return
+    assert st == 0
+    assert np.array_equal(kb.down(y), kb.down(y0))
+    out2 = kb.zeros((B, HW, cout), np.float16)
+    ws2 = workspace(kb, kb.lib.ea_groupnorm_workspace_bytes(B, HW, cout, groups))
+    assert kb.lib.ea_groupnorm_f16(ptr(y0), cout, None, 0, None, ptr(gamma), ptr(beta), ptr(out2), B, HW, groups, eps, int(silu),
+                                   ptr(ws2), ws_nbytes(ws2), kb.stream) == 0
+    yt = t(kb.down(y0)).reshape(B, HW, cout)
+    want = F.group_norm(yt.permute(0, 2, 1), groups, t(gamma), t(beta), eps)
+    want = (F.silu(want) if silu else want).permute(0, 2, 1).numpy()
+    got = kb.down(n).reshape(B, HW, cout)
+    assert relerr(got, want) < 3e-3
+    assert np.abs(got.astype(np.float32) - kb.down(out2).astype(np.float32)).max() <= 4e-3 * np.abs(want).max()
+
+
+def test_split_k_groupnorm_refused_where_it_cannot_run(kb):
+    """Unsplit plans, fp32 outputs and the generic kernel refuse `gn_next_out` (query 0 / EA_ERR_UNSUPPORTED), they never
+    silently skip the norm."""
+    tune(kb, splits=1)
+    assert kb.lib.ea_gemm_gn_next_ok(512, 1280, 1152, 1, 64, 40) == 0            # forced unsplit
+    x, W = f16(2, 16, 16, 64), f16(320, 576, scale=0.05)
+    y, n = kb.zeros((512, 320), np.float16), kb.zeros((512, 320), np.float16)
+    gamma, beta = f32(320), f32(320)
+    e = epilogue(y, gn_rows_per_sample=256, gn_cpg=20, gn_next=(n, gamma, beta, 1e-5, True))
+    ws = workspace(kb, 1 << 22)
+    src = conv_src(x)
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), 320, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) != 0
+    tune(kb, splits=2)
+    y32 = kb.zeros((512, 320), np.float32)
+    e = epilogue(y32, gn_rows_per_sample=256, gn_cpg=20, gn_next=(n, gamma, beta, 1e-5, True))
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W), 320, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) != 0
+
+
 def test_groupnorm_statistics_refused_where_they_cannot_be_emitted(kb):
     """Shapes whose wave tiles do not hold whole groups / whole-sample row ranges, split-K plans and the generic kernel
     say so up front (0 from the query, EA_ERR_UNSUPPORTED from the launch)."""
