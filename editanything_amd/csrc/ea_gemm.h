@@ -527,95 +527,110 @@ __global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
 // ROUNDED fp16 values the output holds), its statistics are reduced over the workgroup, and both the output and its
 // normalised form are written.  Replaces reduce + statistics pass + normalise pass (3 launches, 2 extra trips over the
 // tensor) at the levels where the contraction is split.  Same order of operations per element as ea_epilogue_store8.
-constexpr int EA_RGN_MAXQ = 24;
+// Footprint: a workgroup must not need a whole CU -- the ControlNet trunk and the UNet encoder run on two streams and their
+// launches share CUs (that overlap is worth 19 % of the denoising loop); a 1024-thread x 128-register instantiation, which only
+// fits an EMPTY CU, sent one graph replay in three into a 10 % slower mode (same kernel times, idle gaps).  Both forms take
+// half a CU's registers: 1024 x 1 piece (<= 64 registers) and 512 x 5 pieces (<= 128).
+constexpr int EA_RGN_MAXQ = 5;
 template <int MAXQ>
-__global__ __launch_bounds__(256) void ea_splitk_reduce_gn_kernel(EaGemmParams p) {
+__global__ __launch_bounds__(MAXQ == 1 ? 1024 : 512) void ea_splitk_reduce_gn_kernel(EaGemmParams p) {
+  constexpr int EA_RGN_THREADS = MAXQ == 1 ? 1024 : 512;
   EA_SMEM(smem);
-  float (*red)[4] = reinterpret_cast<float (*)[4]>(smem);    // [2][4]
+  float (*red)[16] = reinterpret_cast<float (*)[16]>(smem);    // [2][16]
   const EaEpilogue& e = p.epi;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = blockIdx.x, b = blockIdx.y;
   const int hw = e.gn_hw, cpg = e.gn_cpg, qpr = cpg >> 2;
   const int nq = hw * qpr;
   const long long slab = (long long)p.M * p.N;
+  // ONE round: every load of the thread (its <= MAXQ pieces x all slices, bias, row vector, residual) is issued before the
+  // first use -- a workgroup is on its own CU with nothing to overlap a second round trip with
+  f32x4 acc[MAXQ], bv[MAXQ], rv[MAXQ];
+  f16x4 res[MAXQ];
+  int mrow[MAXQ], col[MAXQ];
+  bool ok[MAXQ];
+#pragma unroll
+  for (int u = 0; u < MAXQ; ++u) {
+    const int q = tid + EA_RGN_THREADS * u;
+    ok[u] = q < nq;
+    const int qq = ok[u] ? q : 0;
+    const int row = qq / qpr;
+    mrow[u] = b * hw + row;
+    col[u] = g * cpg + (qq - row * qpr) * 4;
+    acc[u] = *reinterpret_cast<const f32x4*>(p.partial + (long long)mrow[u] * p.N + col[u]);
+    bv[u] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + col[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rv[u] = e.rowvec ? *reinterpret_cast<const f32x4*>(e.rowvec + (long long)(mrow[u] / e.rows_per_group) * e.rowvec_ld + col[u])
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (e.residual) res[u] = *reinterpret_cast<const f16x4*>(e.residual + (long long)mrow[u] * e.ldr + col[u]);
+  }
+  // the other slices, SCH at a time, all of a chunk's loads in flight together (the adds keep slice order)
+  constexpr int SCH = MAXQ == 1 ? 7 : 2;
+  for (int s0 = 1; s0 < p.splits; s0 += SCH) {
+    f32x4 t[SCH][MAXQ];
+#pragma unroll
+    for (int c = 0; c < SCH; ++c)
+#pragma unroll
+      for (int u = 0; u < MAXQ; ++u)
+        t[c][u] = (s0 + c < p.splits) ? *reinterpret_cast<const f32x4*>(p.partial + (s0 + c) * slab + (long long)mrow[u] * p.N + col[u])
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < SCH; ++c)
+      if (s0 + c < p.splits) {
+#pragma unroll
+        for (int u = 0; u < MAXQ; ++u) acc[u] += t[c][u];
+      }
+  }
+  // the consuming norm's scale / shift: requested now, used after the workgroup reduction
+  f32x4 ga[MAXQ], be[MAXQ];
+#pragma unroll
+  for (int u = 0; u < MAXQ; ++u) {
+    ga[u] = *reinterpret_cast<const f32x4*>(e.gn_next_gamma + col[u]);
+    be[u] = *reinterpret_cast<const f32x4*>(e.gn_next_beta + col[u]);
+  }
   float v[MAXQ][4];
   float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-  for (int i0 = 0; i0 < MAXQ; i0 += 4) {
-    // four pieces per round: every load of the round (slices, bias, row vector, residual) is issued before the first use
-    f32x4 acc[4], bv[4], rv[4];
-    f16x4 res[4];
-    int mrow[4], col[4];
-    bool ok[4];
+  for (int u = 0; u < MAXQ; ++u) {
+    f16x4 h;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = tid + 256 * (i0 + u);
-      ok[u] = q < nq;
-      const int qq = ok[u] ? q : 0;
-      const int row = qq / qpr;
-      mrow[u] = b * hw + row;
-      col[u] = g * cpg + (qq - row * qpr) * 4;
-      const float* src = p.partial + (long long)mrow[u] * p.N + col[u];
-      acc[u] = *reinterpret_cast<const f32x4*>(src);
-      bv[u] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + col[u]) : f32x4{0.f, 0.f, 0.f, 0.f};
-      rv[u] = e.rowvec ? *reinterpret_cast<const f32x4*>(e.rowvec + (long long)(mrow[u] / e.rows_per_group) * e.rowvec_ld + col[u])
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e.residual) res[u] = *reinterpret_cast<const f16x4*>(e.residual + (long long)mrow[u] * e.ldr + col[u]);
+    for (int j = 0; j < 4; ++j) {
+      float x = acc[u][j] + bv[u][j];
+      x += rv[u][j];
+      if (e.act == EA_ACT_SILU) x = ea_silu(x);
+      x *= e.scale;
+      if (e.residual) x += (float)res[u][j];
+      h[j] = (f16)x;
+      const float r = ok[u] ? (float)h[j] : 0.0f;
+      v[u][j] = r;
+      s1 += r;
+      s2 += r * r;
     }
-    for (int s = 1; s < p.splits; ++s) {
-      f32x4 t[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const f32x4*>(p.partial + s * slab + (long long)mrow[u] * p.N + col[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc[u] += t[u];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      f16x4 h;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float x = acc[u][j] + bv[u][j];
-        x += rv[u][j];
-        if (e.act == EA_ACT_SILU) x = ea_silu(x);
-        x *= e.scale;
-        if (e.residual) x += (float)res[u][j];
-        h[j] = (f16)x;
-        const float r = ok[u] ? (float)h[j] : 0.0f;
-        v[i0 + u][j] = r;
-        s1 += r;
-        s2 += r * r;
-      }
-      if (ok[u]) *reinterpret_cast<f16x4*>((f16*)e.out + (long long)mrow[u] * e.ldc + col[u]) = h;
-    }
+    if (ok[u]) *reinterpret_cast<f16x4*>((f16*)e.out + (long long)mrow[u] * e.ldc + col[u]) = h;
   }
   s1 = ea_wave_sum(s1);
   s2 = ea_wave_sum(s2);
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   __syncthreads();
-  s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  s1 = 0.0f; s2 = 0.0f;
+#pragma unroll
+  for (int w = 0; w < EA_RGN_THREADS / 64; ++w) { s1 += red[0][w]; s2 += red[1][w]; }
   const float inv_n = 1.0f / ((float)hw * (float)cpg);
   const float mean = s1 * inv_n;
   float var = s2 * inv_n - mean * mean;
   var = var > 0.0f ? var : 0.0f;
   const float rstd = 1.0f / sqrtf(var + e.gn_next_eps);
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i) {
-    const int q = tid + 256 * i;
-    if (q < nq) {
-      const int row = q / qpr;
-      const int c = g * cpg + (q - row * qpr) * 4;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(e.gn_next_gamma + c);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(e.gn_next_beta + c);
+  for (int u = 0; u < MAXQ; ++u) {
+    if (ok[u]) {
       f16x4 y;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float a = rstd * ga[j];                    // the normalise pass's form (ea_norm.hip gn_finish): x * a + sh
-        float f = v[i][j] * a + (be[j] - mean * a);
+        const float a = rstd * ga[u][j];                 // the normalise pass's form (ea_norm.hip gn_finish): x * a + sh
+        float f = v[u][j] * a + (be[u][j] - mean * a);
         if (e.gn_next_silu) f = ea_silu(f);
         y[j] = (f16)f;
       }
-      *reinterpret_cast<f16x4*>(e.gn_next_out + (long long)(b * hw + row) * e.ldc + c) = y;
+      *reinterpret_cast<f16x4*>(e.gn_next_out + (long long)mrow[u] * e.ldc + col[u]) = y;
     }
   }
 }

@@ -234,7 +234,7 @@ static int launch_reduce(EaGemmParams& p, void* stream) {
 // shape side of the decision (ea_gemm_gn_next_ok + the launch): whole samples, 4-channel pieces, a slab one workgroup holds
 static bool gn_next_shape_ok(int M, int N, int hw, int cpg) {
   if (hw <= 0 || cpg < 4 || (cpg & 3) || (N % cpg) || (M % hw) || (N & 3)) return false;
-  return (long long)hw * (cpg >> 2) <= 256ll * EA_RGN_MAXQ;
+  return (long long)hw * (cpg >> 2) <= 512ll * EA_RGN_MAXQ;
 }
 static bool gn_next_epi_ok(const EaGemmParams& p) {
   const EaEpilogue& e = p.epi;
@@ -247,9 +247,8 @@ static int launch_reduce_gn(EaGemmParams& p, void* stream) {
   const EaEpilogue& e = p.epi;
   const long long nq = (long long)e.gn_hw * (e.gn_cpg >> 2);
   dim3 grid((unsigned)(p.N / e.gn_cpg), (unsigned)(p.M / e.gn_hw), 1);
-  if (nq <= 256 * 4) { auto k = ea_splitk_reduce_gn_kernel<4>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
-  else if (nq <= 256 * 12) { auto k = ea_splitk_reduce_gn_kernel<12>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
-  else { auto k = ea_splitk_reduce_gn_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(256), 32, stream, p); }
+  if (nq <= 1024) { auto k = ea_splitk_reduce_gn_kernel<1>; EA_LAUNCH(k, grid, dim3(1024), 128, stream, p); }
+  else { auto k = ea_splitk_reduce_gn_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(512), 128, stream, p); }
   return ea_launch_status();
 }
 

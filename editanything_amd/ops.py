@@ -216,6 +216,7 @@ def _rows_per_group(rowvec, s):
 
 
 GN_EPILOGUE = os.environ.get("EA_GN_EPILOGUE", "1") != "0"      # A/B switch (tools/): 0 keeps the statistics passes
+GN_NEXT = os.environ.get("EA_GN_NEXT", "1") != "0"              # A/B switch (tools/): 0 keeps reduce + statistics + normalise apart
 
 
 class Normed:
@@ -229,7 +230,7 @@ class Normed:
 def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
     """True when a contraction of this shape is split along K and its reduction can apply the GroupNorm that consumes the
     output (`ea_epilogue.gn_next_out`)."""
-    if not GN_EPILOGUE or PROFILE is not None or N % groups:
+    if not GN_EPILOGUE or not GN_NEXT or PROFILE is not None or N % groups:
         return False
     return bool(_lib().ea_gemm_gn_next_ok(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 

@@ -430,7 +430,7 @@ class ControlledDenoiser:
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
         self.only_mid_control = False
-        self.overlap = True       # concurrent streams: batch row groups x (UNet encoder | ControlNet trunk)
+        self.overlap = os.environ.get("EA_OVERLAP", "1") != "0"   # concurrent streams: batch row groups x (UNet encoder | ControlNet trunk); env: A/B switch (tools/)
         self.cn_overlap = True
         # row groups of one evaluation run as independent stream sets (2 = the uncond / cond halves of a CFG batch).
         # Measured at C2 (network batch 8): 2 groups 357 ms vs 1 group 336 ms per 20 evaluations -- halving M costs the
