@@ -216,7 +216,12 @@ def _rows_per_group(rowvec, s):
 
 
 GN_EPILOGUE = os.environ.get("EA_GN_EPILOGUE", "1") != "0"      # A/B switch (tools/): 0 keeps the statistics passes
-GN_NEXT = os.environ.get("EA_GN_NEXT", "1") != "0"              # A/B switch (tools/): 0 keeps reduce + statistics + normalise apart
+# The split-K reduction can apply the consuming GroupNorm itself (ea_epilogue.gn_next_out; one launch instead of three at the
+# 16 x 16 / 8 x 8 levels).  Measured on the MI355X (profiles/r03_fused_reduce_groupnorm_ab.jsonl): -6 us per site, 29 sites per
+# evaluation, -0.8 % on the denoising loop -- but one graph replay in ten runs 7 % SLOWER with identical kernel times: the
+# (sample, group) workgroups take half a CU each and, when they land beside the other stream's contraction launch, the two
+# streams stop packing into each other (that overlap is worth 19 %).  Net zero, with a tail: OFF unless EA_GN_NEXT=1.
+GN_NEXT = os.environ.get("EA_GN_NEXT", "0") == "1"
 
 
 class Normed:
