@@ -369,8 +369,8 @@ def test_sam_vit_h_blocks_vs_frozen_oracle():
 def test_sam_vit_h_full_depth_vs_frozen_oracle():
     """The bench's encoder at FULL depth (SAM ViT-H: 32 blocks, 4 global) on a 1024^2 image against the fp32 oracle's frozen
     result (oracle/make_golden_vith.py): the serving fp16 path -- eager, graph replay, and as image 2 of a batch of four (the
-    timed shape) -- within 2e-2 rel-L2 of the embedding, with depth-resolved checkpoints of the token stream after each global
-    block; the fp32-accurate encoder (sam_exact.py) within 1e-4."""
+    timed shape) -- within 5e-3 rel-L2 of the embedding (measured 1.0e-3), with depth-resolved checkpoints of the token stream
+    after each global block (7e-4 .. 8e-4); the fp32-accurate encoder (sam_exact.py) within 1e-5 (measured 1.1e-6)."""
     from editanything_amd import ops
     from editanything_amd.sam import ImageEncoderViT
     from editanything_amd.sam_exact import ImageEncoderViTExact
@@ -403,12 +403,12 @@ def test_sam_vit_h_full_depth_vs_frozen_oracle():
         enc.forward_graph(enc.preprocess(batch[::-1].copy()))            # replay with other contents, then again
         e3 = rel_l2(enc.forward_graph(enc.preprocess(batch))[2:3], ref)
     print(f"ViT-H full depth: fp16 eager {e1:.3e}, in a batch of 4 by graph replay {e2:.3e} / {e3:.3e}; tokens after global blocks {errs}")
-    assert e1 <= 2e-2 and e2 <= 2e-2 and e3 <= 2e-2, (e1, e2, e3)
-    assert all(v <= 2e-2 for v in errs.values()), errs
+    assert e1 <= 5e-3 and e2 <= 5e-3 and e3 <= 5e-3, (e1, e2, e3)
+    assert all(v <= 5e-3 for v in errs.values()), errs
     del enc
     torch.cuda.empty_cache()
     with torch.no_grad():
         ex = ImageEncoderViTExact(cfg, sd, DEV)
         e4 = rel_l2(ex.encode_image(img), ref)
     print(f"ViT-H full depth: fp32-accurate encoder {e4:.3e}")
-    assert e4 <= 1e-4, e4
+    assert e4 <= 1e-5, e4
