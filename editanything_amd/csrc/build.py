@@ -68,7 +68,7 @@ def build_emu(force=False, verbose=True):
         [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if not force and not _newer(EMU_LIB, deps):
         return EMU_LIB
-    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-DEA_TOOLS=1", "-I", EMU_DIR, "-I", HERE,
+    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-DEA_TOOLS=1", "-DEA_ATTN_EXP=2", "-I", EMU_DIR, "-I", HERE,
            "-Wno-unknown-attributes", "-Wno-unused-value", "-o", EMU_LIB]
     for s in srcs:
         cmd += ["-x", "c++", s]

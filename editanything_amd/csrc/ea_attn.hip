@@ -47,6 +47,14 @@ constexpr int ATT_BK = 64;   // keys per tile
 // exceeds it by more than this many log2 units; until then P = exp2(s - m_run) <= 2^8, exact in fp16's range, l and O
 // accumulate in fp32 -- the result differs from the always-rescale form only by fp32 rounding.
 constexpr float ATT_DEFER = 8.0f;
+#ifndef EA_ATTN_EXP
+#define EA_ATTN_EXP 0
+#endif
+#ifdef EA_EMU
+constexpr long long ATT_G2_MIN_WG = 2;      // host emulation: small test shapes must reach the two-group kernel
+#else
+constexpr long long ATT_G2_MIN_WG = 256;    // CUs of an MI355X
+#endif
 
 // LDS hand-off between the lanes of one wave (the LDS pipeline is in order per wave)
 __device__ __forceinline__ void ea_wave_lds_sync_() {
@@ -499,8 +507,14 @@ __device__ __forceinline__ void attn_barrier() {
 #endif
 constexpr unsigned ATT_OOB = 0x80000000u;     // a byte offset past every buffer's num_records: the lane gets zeros
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
+// G = 2 (round 3, EXPERIMENT -- slower, see launch_attn): a wave owns TWO 32-row query groups.  Every K / V fragment read from LDS feeds two MFMAs (the loop at G = 1
+// asks the LDS for 32 bytes per MFMA cycle per wave: 128 B/clk/CU, all it has), the staging per query row halves, and -- the
+// point -- the wave carries two independent softmax chains: group 0's exponentials issue under group 1's matrix work and the
+// other way round, in ONE instruction stream.  (A SIMD overlaps a wave's VALU with that wave's own MFMAs, not with another
+// wave's: tools/probe_overlap2, profiles/r02_attention_counters.md -- two waves per SIMD add their VALU and MFMA times.)
+// One workgroup per CU, one wave per SIMD, ~330 registers.  Same arithmetic per row as G = 1: bit-identical results.
+template <int NW, int G>
+__global__ __launch_bounds__(64 * NW, G == 1 ? 2 : 1) void ea_attn_dma_kernel(AttnParams p) {
   constexpr int D = 64, NKS = D / 16, NDT = D / 32;
   constexpr int ROWB = 128;                          // LDS bytes per K / V row (unpadded: the DMA writes lane-linear)
   constexpr int STAGE = ATT_BK * ROWB;               // 8 KiB per tile and operand
@@ -522,23 +536,33 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
   int qblk, bh;
   ea_attn_block(qblk, bh);
   const int b = bh / p.H, h = bh % p.H;
-  const int q_row = qblk * (32 * NW) + wave * 32 + l31;
-  const bool q_ok = q_row < p.Nq;
-  const int q_ld = q_ok ? q_row : p.Nq - 1;
+  int q_row[G];
+  bool q_ok[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    q_row[g] = qblk * (32 * NW * G) + (wave * G + g) * 32 + l31;
+    q_ok[g] = q_row[g] < p.Nq;
+  }
   const f16* qp = p.q + b * p.q_sb + (long long)h * D;
   const f16* kp = p.k + b * p.k_sb + (long long)h * D;
   const f16* vp = p.v + b * p.v_sb + (long long)h * D;
 
-  f16x8 qf[NKS];
+  f16x8 qf[G][NKS];
 #pragma unroll
-  for (int s = 0; s < NKS; ++s) qf[s] = ea_ld8(qp + (long long)q_ld * p.q_sn + 16 * s + 8 * half);
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) qf[g][s] = ea_ld8(qp + (long long)(q_ok[g] ? q_row[g] : p.Nq - 1) * p.q_sn + 16 * s + 8 * half);
 
-  f32x16 oacc[NDT];
+  f32x16 oacc[G][NDT];
+  float m_run[G], l_run[G], m_use[G];
 #pragma unroll
-  for (int e = 0; e < NDT; ++e)
+  for (int g = 0; g < G; ++g) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[e][r] = 0.0f;
-  float m_run = -INFINITY, l_run = 0.0f, m_use = 0.0f;
+    for (int e = 0; e < NDT; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[g][e][r] = 0.0f;
+    m_run[g] = -INFINITY; l_run[g] = 0.0f; m_use[g] = 0.0f;
+  }
   const float sc2 = p.scale * LOG2E;
   const int nkt = (p.Nk + ATT_BK - 1) / ATT_BK, nfull = p.Nk / ATT_BK;
 
@@ -581,21 +605,24 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
 #pragma unroll
   for (int e = 0; e < NDT; ++e) vfo[e] = vrow0 * ROWB + (((4 * e + vcl) ^ (((vrow0 >> 1) & 1) << 2)) << 4) + 8 * (lane & 1);
 
-  auto qk = [&](int slot, f32x16 (&sc)[2]) {
+  auto qk = [&](int slot, f32x16 (&sc)[G][2]) {
     const char* ks = kring + slot * STAGE;
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sc[u][r] = 0.0f;
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[g][u][r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NKS; ++s)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const f16x8 a = *reinterpret_cast<const f16x8*>(ks + kfo[s] + 32 * u * ROWB);
-        sc[u] = ea_mfma_32x32x16(a, qf[s], sc[u]);
+#pragma unroll
+        for (int g = 0; g < G; ++g) sc[g][u] = ea_mfma_32x32x16(a, qf[g][s], sc[g][u]);
       }
   };
-  auto advance_max = [&](int t, f32x16 (&sc)[2], auto masked_tag) {
+  auto advance_max1 = [&](int t, f32x16 (&sc)[2], float& m_run, float& l_run, float& m_use, f32x16 (&oacc)[NDT], auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     float mx = -INFINITY;
 #pragma unroll
@@ -625,10 +652,14 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
     }
     m_use = (m_run == -INFINITY) ? 0.0f : m_run;
   };
+  auto advance_max = [&](int t, f32x16 (&sc)[G][2], auto masked_tag) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) advance_max1(t, sc[g], m_run[g], l_run[g], m_use[g], oacc[g], masked_tag);
+  };
 
   // iteration j: requests K(j+3) / V(j+2), reads K(j+1) (ring slot s1) and V(j) (slot s0); s0 = j % 3, s1 = (j+1) % 3,
   // s2 = (j+2) % 3.  K(j+3) goes to K slot s0 (K(j), last read in iteration j-1), V(j+2) to V slot s2 (V(j-1), ditto).
-  auto iter = [&](int j, int s0, int s1, int s2, f32x16 (&cur)[2], f32x16 (&nxt)[2], auto next_tag) {
+  auto iter = [&](int j, int s0, int s1, int s2, f32x16 (&cur)[G][2], f32x16 (&nxt)[G][2], auto next_tag) {
     constexpr int NEXT = decltype(next_tag)::value;
     const bool k_req = j + 3 < nkt, v_req = j + 2 < nkt;
     if (k_req) k_issue(j + 3, s0);
@@ -645,30 +676,34 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
       });
     });
     if (NEXT) qk(s1, nxt);
-    float psum = 0.0f;
-    f16x8 pb[2][2];
+    // per group: probabilities (VALU), then its PV MFMAs -- group 1's exponentials issue under group 0's PV
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int g = 0; g < G; ++g) {
+      float psum = 0.0f;
+      f16x8 pb[2][2];
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        f16x2 pp;
-        pp[0] = (f16)ea_exp2(fmaf(cur[u][r], sc2, -m_use));
-        pp[1] = (f16)ea_exp2(fmaf(cur[u][r + 1], sc2, -m_use));
-        psum = ea_dot2_ones(pp, psum);
-        pb[u][r >> 3][r & 7] = pp[0];
-        pb[u][r >> 3][(r & 7) + 1] = pp[1];
-      }
-    l_run += psum;
-    ea_lds_tr_wait();
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int tu = 0; tu < 4; ++tu)
+        for (int r = 0; r < 16; r += 2) {
+          f16x2 pp;
+          pp[0] = (f16)ea_exp2(fmaf(cur[g][u][r], sc2, -m_use[g]));
+          pp[1] = (f16)ea_exp2(fmaf(cur[g][u][r + 1], sc2, -m_use[g]));
+          psum = ea_dot2_ones(pp, psum);
+          pb[u][r >> 3][r & 7] = pp[0];
+          pb[u][r >> 3][(r & 7) + 1] = pp[1];
+        }
+      l_run[g] += psum;
+      if (g == 0) ea_lds_tr_wait();
 #pragma unroll
-      for (int e = 0; e < NDT; ++e) {
-        f16x8 a;
+      for (int tu = 0; tu < 4; ++tu)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) { a[jj] = vlo[e][tu][jj]; a[4 + jj] = vhi[e][tu][jj]; }
-        oacc[e] = ea_mfma_32x32x16(a, pb[tu >> 1][tu & 1], oacc[e]);
-      }
+        for (int e = 0; e < NDT; ++e) {
+          f16x8 a;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { a[jj] = vlo[e][tu][jj]; a[4 + jj] = vhi[e][tu][jj]; }
+          oacc[g][e] = ea_mfma_32x32x16(a, pb[tu >> 1][tu & 1], oacc[g][e]);
+        }
+    }
     if (NEXT) {
       advance_max(j + 1, nxt, std::integral_constant<bool, NEXT == 2>{});
       // the next iteration reads K(j+2) and V(j+1), requested one iteration ago; this iteration's requests stay in flight
@@ -679,7 +714,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
     }
   };
 
-  f32x16 sA[2], sB[2];
+  f32x16 sA[G][2], sB[G][2];
   k_issue(0, 0);
   v_issue(0, 0);
   if (nkt > 1) k_issue(1, 1);
@@ -693,9 +728,11 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
 
   auto take = [&]() {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sA[u][r] = sB[u][r];
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[g][u][r] = sB[g][u][r];
   };
   int j = 0, s0 = 0, s1 = 1, s2 = 2;
   auto rot = [&]() { const int t = s0; s0 = s1; s1 = s2; s2 = t; };
@@ -720,19 +757,22 @@ __global__ __launch_bounds__(64 * NW, 2) void ea_attn_dma_kernel(AttnParams p) {
   }
   iter(j, s0, s1, s2, sA, sB, std::integral_constant<int, 0>{});
 
-  const float l_tot = l_run + ea_shfl_xor(l_run, 32);
-  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-  if (q_ok) {
-    f16* op = p.o + b * p.o_sb + (long long)q_row * p.o_sn + (long long)h * D;
 #pragma unroll
-    for (int e = 0; e < NDT; ++e)
+  for (int g = 0; g < G; ++g) {
+    const float l_tot = l_run[g] + ea_shfl_xor(l_run[g], 32);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    if (q_ok[g]) {
+      f16* op = p.o + b * p.o_sb + (long long)q_row[g] * p.o_sn + (long long)h * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f16x4 o4;
+      for (int e = 0; e < NDT; ++e)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) o4[jj] = (f16)(oacc[e][4 * g + jj] * inv);
-        *reinterpret_cast<f16x4*>(op + 32 * e + 8 * g + 4 * half) = o4;
-      }
+        for (int c = 0; c < 4; ++c) {
+          f16x4 o4;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) o4[jj] = (f16)(oacc[g][e][4 * c + jj] * inv);
+          *reinterpret_cast<f16x4*>(op + 32 * e + 8 * c + 4 * half) = o4;
+        }
+    }
   }
 }
 
@@ -751,8 +791,22 @@ static int launch_attn(const AttnParams& p, void* stream) {
     // divides the chip evenly and -11 % at the level-0 shape, 640 workgroups on 256 CUs: profiles/r02_attention_counters.md)
     const long long span = (long long)p.Nk * (p.k_sn > p.v_sn ? p.k_sn : p.v_sn) * 2;
     if (p.Nk >= 4 * ATT_BK && span < (1ll << 31)) {
-      auto dfn = ea_attn_dma_kernel<4>;
       const int dsmem = 2 * 3 * ATT_BK * 128;        // K ring + V ring, three 8-KiB stages each
+#if (EA_ATTN_EXP & 2)
+      // EXPERIMENT (side builds and the emulation build only): two query groups per wave (256 queries per workgroup, one
+      // workgroup per CU) once the launch has a workgroup for every CU in that form.  Measured on the MI355X against the
+      // shipped form in the same call (profiles/r03_attention_two_groups_per_wave.jsonl): 531 vs 772 TF/s at the level-0
+      // shape (B8 H5 4096^2), 352 vs 531 at 1024^2 -- with ONE wave per SIMD nothing covers the LDS and MFMA result
+      // latencies between the dependent steps of a tile, and that costs more than sharing the fragments saves
+      const long long wg2 = (long long)p.B * p.H * ((p.Nq + 255) / 256);
+      if (wg2 >= ATT_G2_MIN_WG) {
+        auto dfn2 = ea_attn_dma_kernel<4, 2>;
+        ea_allow_big_lds(dfn2, dsmem);
+        EA_LAUNCH(dfn2, dim3((p.Nq + 255) / 256, p.B * p.H, 1), dim3(256), dsmem, stream, p);
+        return ea_launch_status();
+      }
+#endif
+      auto dfn = ea_attn_dma_kernel<4, 1>;
       ea_allow_big_lds(dfn, dsmem);
       EA_LAUNCH(dfn, grid, dim3(256), dsmem, stream, p);
       return ea_launch_status();

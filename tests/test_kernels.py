@@ -479,6 +479,11 @@ def test_layernorm_rows_and_gather_add(kb):
     (1, 1, 32, 330, 64),
     (1, 3, 400, 100, 64),
     (1, 3, 400, 300, 64),
+    # two query groups per wave (256-query workgroups; the emulation build takes this form from 2 workgroups up, the MI355X from
+    # 256): full and ragged last query block, even / odd / ragged key tile counts
+    (1, 2, 512, 330, 64),
+    (2, 1, 300, 256, 64),
+    (1, 2, 256, 384, 64),
 ])
 def test_attention(kb, B, H, Nq, Nk, D):
     q, k, v = f16(B, Nq, H, D), f16(B, Nk, H, D), f16(B, Nk, H, D)
@@ -488,6 +493,24 @@ def test_attention(kb, B, H, Nq, Nk, D):
                               Nk * H * D, H * D, Nq * H * D, H * D, scale, None, None, 0, kb.stream)
     assert st == 0
     assert relerr(kb.down(out), attn_ref(q, k, v, scale).numpy()) < 3e-3
+
+
+def test_attention_two_query_groups_per_wave_is_bit_identical(kb):
+    """The 256-query form of the pipelined d = 64 kernel (two 32-row groups per wave sharing every K / V fragment) does each
+    row's arithmetic exactly as the 128-query form: one head's first 256 rows, launched alone (one workgroup in the 256-query
+    form -> the emulation build's threshold sends it to the 128-query kernel), equal the big launch's rows bit for bit."""
+    if kb.name != "emu":
+        pytest.skip("needs the emulation build's low workgroup threshold to reach both forms at test size")
+    B, H, Nq, Nk, D = 1, 2, 512, 330, 64
+    q, k, v = f16(B, Nq, H, D), f16(B, Nk, H, D), f16(B, Nk, H, D)
+    out = kb.zeros((B, Nq, H, D), np.float16)
+    scale = D ** -0.5
+    args = lambda o, h, nq: (ptr(q), ptr(k), ptr(v), o, B, h, nq, Nk, D, Nq * H * D, H * D, Nk * H * D, H * D, Nk * H * D, H * D,
+                             Nq * H * D, H * D, scale, None, None, 0, kb.stream)
+    assert kb.lib.ea_attention_f16(*args(ptr(out), H, Nq)) == 0                 # 2 heads x 2 blocks = 4 workgroups: two groups per wave
+    one = kb.zeros((B, Nq, H, D), np.float16)
+    assert kb.lib.ea_attention_f16(*args(ptr(one), 1, 256)) == 0                # head 0, rows 0..255: 1 workgroup -> one group per wave
+    assert np.array_equal(kb.down(one)[0, :256, 0], kb.down(out)[0, :256, 0])
 
 
 def test_attention_fused_qkv_strides(kb):
