@@ -38,10 +38,16 @@ def parse():
     ap.add_argument("--sam", default="vit_h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the batches strictly one after the other (SAM -> prepare -> loop -> decode on one stream) "
+                         "instead of software-pipelined over consecutive batches (serving.PipelinedRunner)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
                          "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--loop-priority", choices=["default", "high"], default="default",
+                    help="experiment switch: issue the denoising loops on a high-priority stream (the side stream of the "
+                         "software pipeline keeps the default priority)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra single-GPU measurements (process() end-to-end WITH automatic mask generation; "
                          "the fp32-accurate SAM encoder) that are reported beside the headline")
@@ -128,7 +134,7 @@ def main():
         respawn_under_torchrun(args)
     if args.dry_run:
         return dry_run(args)
-    from editanything_amd import arch, dist as eadist, models, ops, synth
+    from editanything_amd import arch, dist as eadist, models, ops, serving, synth
     rank, world, local = eadist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
@@ -160,32 +166,89 @@ def main():
     # control batch == prompt batch (check_controlnet_conditioning_image, ...inpaint.py:782-790)
     embeds_b, neg_b = inp["embeds"].repeat(args.batch, 1, 1), inp["neg"].repeat(args.batch, 1, 1)
 
-    def one_step(seed):
+    def sam_encode():
         # SAM image encoding of the batch (ResizeLongestSide(1024) on device, then the ViT)
         x = torch.nn.functional.interpolate(inp["images_u8"].permute(0, 3, 1, 2).float(), size=(1024, 1024), mode="bilinear",
                                             align_corners=False)
         x = (x - sam.mean) / sam.std
-        emb = sam.forward(x) if args.no_graph else sam.forward_graph(x)
+        return sam.forward(x) if args.no_graph else sam.forward_graph(x)
+
+    def call_kwargs(seed):
         gen = torch.Generator("cpu").manual_seed(seed)
-        out = pipe(prompt_embeds=embeds_b, negative_prompt_embeds=neg_b, image=init_image, mask_image=mask_b,
-                   controlnet_conditioning_image=inp["control"], height=512, width=512, num_inference_steps=args.ddim_steps,
-                   guidance_scale=7.5, num_images_per_prompt=1, generator=gen, output_type="np_device")
-        return emb, out
+        return dict(prompt_embeds=embeds_b, negative_prompt_embeds=neg_b, image=init_image, mask_image=mask_b,
+                    controlnet_conditioning_image=inp["control"], height=512, width=512, num_inference_steps=args.ddim_steps,
+                    guidance_scale=7.5, num_images_per_prompt=1, generator=gen, output_type="np_device")
+
+    def one_step(seed):
+        """One batch, strictly in order on one stream (what a single reference request does)."""
+        emb = sam_encode()
+        return emb, pipe(**call_kwargs(seed))
+
+    embs = []
+
+    def request(seed):
+        """The same batch as a request of the software pipeline: the callable is the SAM part of the front stage."""
+        def make():
+            embs.append(sam_encode())
+            return call_kwargs(seed)
+        return make
 
     # output_type "np_device": keep the decoded batch on the device (the host copy of 4 images is not part of the path)
     orig_decode = pipe.decode_latents
     pipe.decode_latents = lambda lat: (pipe.vae.decode_nhwc(lat / pipe.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
+    pipelined = not args.no_pipeline and not args.no_graph
+    runner = serving.PipelinedRunner(pipe) if pipelined else None
+    hi_stream = torch.cuda.Stream(priority=-1) if (pipelined and args.loop_priority == "high") else None
 
-    for i in range(args.warmup):
-        one_step(args.seed + i)
+    def run_steps(first_seed, k):
+        """k steps = k batches through the whole path.  Pipelined: the k batches enter an EMPTY software pipeline and the
+        region ends when the last one has been decoded (fill and drain are inside the timed region)."""
+        if runner is None:
+            for i in range(k):
+                emb, out = one_step(first_seed + i)
+            return emb, out
+        del embs[:]
+        if hi_stream is not None:
+            hi_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(hi_stream):
+                outs = runner.run([request(first_seed + i) for i in range(k)])
+            torch.cuda.current_stream().wait_stream(hi_stream)
+        else:
+            outs = runner.run([request(first_seed + i) for i in range(k)])
+        return embs[-1], outs[-1]
+
+    if args.warmup:
+        run_steps(args.seed, args.warmup)
     eadist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        emb, out = one_step(args.seed + 1000 + i)
+    emb, out = run_steps(args.seed + 1000, args.steps)
     torch.cuda.synchronize()
     eadist.barrier()
     elapsed = eadist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    assert emb is not None and torch.isfinite(out.images if hasattr(out, "images") else out).all()
+    # the same batches one after the other on one stream (no overlap between batches), and per-batch latency of both modes:
+    # same box, same process, right after the timed region -- an A/B a reader can recompute the pipelining gain from
+    seq = None
+    if runner is not None:
+        k = max(2, min(args.steps, 5))
+        one_step(args.seed + 2000)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(k):
+            one_step(args.seed + 2001 + i)
+        torch.cuda.synchronize()
+        t_seq = (time.perf_counter() - t1) / k
+        runner.latency_events = []
+        runner.run([request(args.seed + 3000 + i) for i in range(k + 2)])
+        torch.cuda.synchronize()
+        lat = [a.elapsed_time(b) for a, b in runner.latency_events]
+        runner.latency_events = None
+        seq = {"value": round(args.batch / t_seq, 4), "ms_per_step": round(t_seq * 1e3, 2), "steps": k,
+               "latency_ms_per_batch": round(t_seq * 1e3, 2),
+               "pipelined_latency_ms_per_batch": round(float(np.mean(lat[1:-1])), 2),
+               "note": "sequential = SAM -> prepare -> loop -> decode of one batch after the other on one stream; latency = first "
+                       "launch of a batch's SAM encode to the end of its VAE decode (device events; steady-state requests)"}
     # untimed diagnostic pass: GPU time per phase of one step (events on the launch stream; not part of `value`).
     # pipeline marks: start | inputs+vae_encode | prepare(hint,text kv) | denoise loop | vae_decode
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -198,7 +261,6 @@ def main():
     for name, ev in marks:
         phases["sam_encode(+resize)" if name == "start" else name] = round(prev.elapsed_time(ev), 2)
         prev = ev
-    assert torch.isfinite(out.images if hasattr(out, "images") else out).all()
 
     n_images = args.batch * args.steps * world
     value = n_images / elapsed
@@ -214,12 +276,23 @@ def main():
                                "part of the metric, the SAM embedding is computed and dropped), decoded images stay on the "
                                "device (no D2H copy / PIL conversion in the timed region); the part of an evaluation in "
                                "front of the first cross-attention (conv_in, first ResBlock, first self-attention) is "
-                               "computed once for the two identical CFG halves",
+                               "computed once for the two identical CFG halves"
+                               + ("; the `steps` batches run through a two-stream software pipeline (serving.PipelinedRunner): "
+                                  "SAM encode + VAE encode + per-call invariants of batch i+1 and the VAE decode of batch i-1 are "
+                                  "issued on a side stream underneath the 20-step loop of batch i; the pipeline starts EMPTY "
+                                  "and is DRAINED inside the timed region; `sequential` = the same batches one after the "
+                                  "other, measured in the same process" if runner is not None else
+                                  "; batches strictly one after the other on one stream"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
                    "weights_setup_s": round(t_weights, 1), "phase_ms": phases},
     }
+    if seq is not None:
+        result["sequential"] = seq
+        result["pipelining_gain"] = round(value / world / seq["value"], 4)
+    if rank == 0:
+        result["calibration"] = calibration(dev)
     if world == 1 and not args.no_extras:
         result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases))
     if rank == 0:
@@ -230,6 +303,51 @@ def main():
         print(json.dumps(result), flush=True)
     pipe.decode_latents = orig_decode
     eadist.barrier()
+
+
+def calibration(dev):
+    """What lets a reader normalise `value` for the box it was measured on (boxes of this pool differ by up to 12 % on
+    one build): a device-to-device copy rate, the contraction kernel on one fixed cube, and the clocks /
+    power cap the box reports.  Untimed region; ~0.2 s."""
+    import subprocess
+    from editanything_amd import ops
+    out = {}
+    a = torch.empty(1 << 28, dtype=torch.float32, device=dev)        # 1 GiB
+    b = torch.empty_like(a)
+
+    def timed(fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    t = timed(lambda: b.copy_(a), 10)
+    out["hbm_copy_gbps"] = round(2 * a.numel() * 4 / t / 1e9, 1)      # bytes read + bytes written
+    del a, b
+    g = torch.Generator("cpu").manual_seed(1)
+    x = (torch.randn(4096, 4096, generator=g) * 0.5).half().to(dev)
+    w = (torch.randn(4096, 4096, generator=g) * 0.5).half().to(dev)
+    o = torch.empty(4096, 4096, dtype=torch.float16, device=dev)
+    t = timed(lambda: ops.gemm(x, w, out=o), 20)
+    out["mfma_probe_tflops"] = round(2 * 4096 ** 3 / t / 1e12, 1)
+    out["mfma_probe"] = "ea_gemm_f16 4096 x 4096 x 4096, random fp16 operands, 20 launches"
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--showpower", "--showmaxpower", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        card = next(iter(json.loads(r.stdout).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power")):
+                keep[k] = v
+        out["smi"] = keep
+    except Exception as e:       # the tool or its JSON layout is not there: say so, never fail the bench
+        out["smi"] = "unavailable: %s" % type(e).__name__
+    return out
 
 
 def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, s_per_step, phases):
@@ -339,52 +457,94 @@ def roofline_leg(one_step, pipe, args):
         one_step(args.seed + 7000)                     # warm (eager path allocations)
         torch.cuda.synchronize()
         ops.PROFILE = []
+        pipe.trace = []                                # phase marks land in the PROFILE list too (ops.profile_mark)
         one_step(args.seed + 7001)
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
     finally:
         ops.PROFILE = None
+        pipe.trace = None
         pipe.use_graph, args.no_graph = use_graph, no_graph
-    mm = [r for r in recs if r[3].startswith(("gemm", "conv"))]     # the MFMA contraction launches only
+    is_mm = lambda r: r[3].startswith(("gemm", "conv"))
+    mm = [r for r in recs if is_mm(r)]     # the MFMA contraction launches only
+    dur = {id(r): r[1].elapsed_time(r[2]) * 1e-3 for r in recs}
     tot_f = sum(r[0] for r in mm)
-    tot_t = sum(r[1].elapsed_time(r[2]) for r in mm) * 1e-3
-    other_t = sum(r[1].elapsed_time(r[2]) for r in recs if not r[3].startswith(("gemm", "conv"))) * 1e-3
+    tot_t = sum(dur[id(r)] for r in mm)
+    other_t = sum(dur[id(r)] for r in recs if not is_mm(r))
     n = len(mm)
     achieved = tot_f / tot_t / 1e12
+    # the launches between the pipeline's "prepare" and "denoise loop" marks: the ControlNet + UNet evaluations alone
+    # (north_star: ">= 0.5 of MFMA roofline on the UNet GEMMs")
+    names = [r[3] for r in recs]
+    i0, i1 = names.index("mark prepare(hint,text kv)"), names.index("mark denoise loop")
+    un = [r for r in recs[i0:i1] if is_mm(r)]
+    un_f, un_t = sum(r[0] for r in un), sum(dur[id(r)] for r in un)
     classes = {}
     for r in mm:
-        c = classes.setdefault(r[3], [0, 0.0])
+        c = classes.setdefault(r[3], [0, 0.0, r[0], r[4]])
         c[0] += 1
-        c[1] += r[1].elapsed_time(r[2]) * 1e3
-    traffic, traffic_note = pmc_traffic(classes)
+        c[1] += dur[id(r)] * 1e6
+    cases = pmc_cases()
+    traffic, traffic_note = pmc_traffic(classes, cases)
+    # per launch class: [launches per step, mean microseconds, algorithmic GFLOP, algorithmic MB (operands + output once),
+    # PMC MB per launch or null]; the wasted-traffic ratio of a class is [4] / [3], its rate [2] / [1]
+    table = {}
+    for label, (cnt, us, fl, nb) in sorted(classes.items(), key=lambda kv: -kv[1][1]):
+        pm = pmc_lookup(cases, label)
+        table[label] = [cnt, round(us / cnt, 1), round(fl / 1e9, 2), round(nb / 1e6, 1),
+                        None if pm is None else round(pm.get("hbm_bytes_with_reduce", pm["hbm_bytes"]) / 1e6, 1)]
     return {"bound": "mfma", "kernel": "ea_gemm2_kernel / ea_gemm_kernel (MFMA implicit-GEMM conv3x3/1x1 + linear)",
             "achieved": round(achieved, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP16_TFLOPS, 4), "traffic": traffic, "traffic_note": traffic_note,
             "launches_per_step": n,
             "avg_launch_us": round(tot_t / n * 1e6, 2), "algorithmic_gflop_per_launch": round(tot_f / n / 1e9, 3),
-            "contraction_ms_per_step": round(tot_t * 1e3, 2), "attention_norm_ms_per_step": round(other_t * 1e3, 2)}
+            "contraction_ms_per_step": round(tot_t * 1e3, 2), "attention_norm_ms_per_step": round(other_t * 1e3, 2),
+            "unet_only_frac": round(un_f / un_t / 1e12 / PEAK_FP16_TFLOPS, 4),
+            "unet_only": {"achieved": round(un_f / un_t / 1e12, 1), "launches": len(un), "ms": round(un_t * 1e3, 2),
+                          "what": "contraction launches of the 20 ControlNet + UNet evaluations only (SAM / VAE launches left out)"},
+            "classes_fields": ["launches_per_step", "mean_us", "algorithmic_gflop", "algorithmic_mb", "pmc_mb_per_launch"],
+            "classes": table}
 
 
-def pmc_traffic(classes):
+PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
+
+
+def pmc_cases():
+    """{launch class label: PMC record} from the newest PMC summary under profiles/ (None when there is none)."""
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return {k.split(" [variant")[0]: v for k, v in json.load(f)["cases"].items() if "hbm_bytes" in v}, name
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
+
+
+def pmc_lookup(cases, label):
+    if cases is None:
+        return None
+    c = cases[0].get(label)
+    if c is None:      # ResBlock forms ("... emb" / "... res") of the same convolution: the plain launch's record
+        c = next((v for k, v in cases[0].items() if k.startswith(label + " ")), None)
+    return c
+
+
+def pmc_traffic(classes, cases):
     """HBM-side bytes per launch of the dominant kernel.  Counters cannot be read inside this process, so the figure joins
-    two measurements: `classes` = {launch class: (launches, total microseconds)} of THIS run's step (the roofline leg's
-    events), and the PMC passes over the same shipped kernels, one launch class at a time (profiles/r03_pmc_traffic.json:
+    two measurements: `classes` = {launch class: (launches, total microseconds, ...)} of THIS run's step (the roofline leg's
+    events), and the PMC passes over the same shipped kernels, one launch class at a time (profiles/r0N_pmc_traffic.json:
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE ...` in separate passes over tools/gemm_bench, tools/gpu_visit.sh
     `pmc:tools/pmc_cases.txt`; bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes on gfx950).  -> the TIME-WEIGHTED mean over the classes of the step that have a PMC record, and how much of
     the contraction time those classes cover.  null when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-            cases = {k.split(" [variant")[0]: v for k, v in json.load(f)["cases"].items() if "hbm_bytes" in v}
-    except (OSError, ValueError, KeyError):
+    if cases is None:
         return None, "no PMC summary under profiles/"
     num = den = 0.0
     n = 0
-    total = sum(us for _, us in classes.values())
-    for label, (cnt, us) in classes.items():
-        c = cases.get(label)
-        if c is None:      # ResBlock forms ("... emb" / "... res") of the same convolution: the plain launch's record
-            c = next((v for k, v in cases.items() if k.startswith(label + " ")), None)
+    total = sum(c[1] for c in classes.values())
+    for label, c4 in classes.items():
+        us = c4[1]
+        c = pmc_lookup(cases, label)
         if c is not None:
             num += us * c.get("hbm_bytes_with_reduce", c["hbm_bytes"])
             den += us
@@ -393,15 +553,15 @@ def pmc_traffic(classes):
         return None, "no launch class of this step has a PMC record"
     return round(num / den), ("bytes per contraction launch (split-K reduce included where a class uses one), time-weighted mean over "
                              "the %d launch classes of this step with a PMC record = %.0f %% of its contraction time (separate --pmc "
-                             "passes on the shipped kernels, profiles/r03_pmc_traffic.json; 2*FETCH_SIZE + WRITE_SIZE, L2 fabric "
+                             "passes on the shipped kernels, profiles/%s; 2*FETCH_SIZE + WRITE_SIZE, L2 fabric "
                              "side: every XCD's L2 fetches the weights once, so weight-heavy classes sit above the algorithmic bytes "
-                             "by construction; per class: DESIGN.md 8c)" % (n, 100.0 * den / total))
+                             "by construction; per class: `classes`)" % (n, 100.0 * den / total, cases[1]))
 
 
 def cpu_baseline(sds, args):
     """The oracle (CPU restatement pinned to the reference) on this box's host cores, bounded sample: ControlNet + UNet
     evaluations at batch 1 (1 warm-up + 2 timed, best), one VAE decode and one VAE encode (after a small warm-up call),
-    4 of the SAM encoder's 32 blocks (extrapolated), extrapolated to images/s for the same 20-step CFG workload.  The
+    the SAM encoder from three bounded timings (windowed block, global block, fixed part), extrapolated to images/s for the same 20-step CFG workload.  The
     thread count is picked by a one-second probe (a 128-thread pool on this host is slower than 32 threads for these
     sizes).  `kind` is "port": /root/reference is not on the GPU box; the oracle is the restatement the goldens pin.
     A reported baseline, not the optimisation target."""
@@ -435,16 +595,25 @@ def cpu_baseline(sds, args):
         ldm_oracle.vae_decode(sds["vae"], arch.VAE_KL_F8, f(1, 4, 8, 8))          # warm the thread pool / allocator
         t_dec = timed(lambda: ldm_oracle.vae_decode(sds["vae"], arch.VAE_KL_F8, f(1, 4, 64, 64)), 0, 1)
         t_enc = timed(lambda: ldm_oracle.vae_encode_moments(sds["vae"], arch.VAE_KL_F8, f(1, 3, 512, 512)), 0, 1)
+        # SAM encoder: a windowed block and a global-attention block cost very different amounts and the real network
+        # has depth - len(global) of the first and len(global) of the second (ViT-H: 28 + 4) -- three bounded timings
+        # (1 windowed block, 2 windowed blocks, 1 global block; patch embedding + neck in each) give the per-kind cost
         cfg = models.SAM_CONFIGS[args.sam]
-        nblk = min(4, cfg["depth"])
-        cfg4 = dict(cfg, depth=nblk, global_attn_indexes=tuple(i for i in (nblk - 1,) if (cfg["depth"] - 1) in cfg["global_attn_indexes"]))
-        t_sam4 = timed(lambda: sam_oracle.image_encoder(sds["sam"], cfg4, f(1, 3, 1024, 1024)), 0, 1)
-        t_sam = t_sam4 * cfg["depth"] / nblk
+        n_glob = len(cfg["global_attn_indexes"])
+        xs = f(1, 3, 1024, 1024)
+        t_w1 = timed(lambda: sam_oracle.image_encoder(sds["sam"], dict(cfg, depth=1, global_attn_indexes=()), xs), 0, 1)
+        t_w2 = timed(lambda: sam_oracle.image_encoder(sds["sam"], dict(cfg, depth=2, global_attn_indexes=()), xs), 0, 1)
+        t_g1 = timed(lambda: sam_oracle.image_encoder(sds["sam"], dict(cfg, depth=1, global_attn_indexes=(0,)), xs), 0, 1)
+        blk_w = max(t_w2 - t_w1, 0.0)
+        fixed = max(t_w1 - blk_w, 0.0)
+        blk_g = max(t_g1 - fixed, 0.0)
+        t_sam = fixed + (cfg["depth"] - n_glob) * blk_w + n_glob * blk_g
     per_image = 2 * args.ddim_steps * t_eval + t_dec + t_enc + t_sam
     return {"value": round(1.0 / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32 on {cores} threads (probe over {cands}): ControlNet+UNet eval b=1, 1 warm-up + best of 2 ({t_eval:.2f}s) "
-                      f"+ VAE decode ({t_dec:.2f}s) + VAE encode ({t_enc:.2f}s) + SAM {args.sam} encoder, {nblk} of {cfg['depth']} blocks "
-                      f"timed ({t_sam4:.2f}s -> {t_sam:.2f}s); extrapolated to 2x{args.ddim_steps} evals/image; "
+                      f"+ VAE decode ({t_dec:.2f}s) + VAE encode ({t_enc:.2f}s) + SAM {args.sam} encoder from three bounded timings "
+                      f"(windowed block {blk_w:.2f}s x {cfg['depth'] - n_glob}, global block {blk_g:.2f}s x {n_glob}, patch embed + neck "
+                      f"{fixed:.2f}s -> {t_sam:.2f}s); extrapolated to 2x{args.ddim_steps} evals/image; "
                       "'port' = the CPU restatement pinned to the reference (the reference tree is not on the GPU box)"}
 
 

@@ -15,7 +15,6 @@ from . import _lib as L
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_GEGLU = L.ACT_NONE, L.ACT_SILU, L.ACT_GELU, L.ACT_GEGLU
 
 _WS_BYTES = 384 << 20
-_ws = {}
 # bench.py's roofline leg: when a list, every MFMA GEMM/conv launch appends (algorithmic flops, start, end events)
 PROFILE = None
 
@@ -28,13 +27,22 @@ def _prof_begin():
     return e
 
 
-def _prof_end(e0, flops, label=""):
+def _prof_end(e0, flops, label="", nbytes=0):
     """label: "gemm ..." / "conv ..." for the MFMA contraction launches (the ones bench.py's roofline leg sums),
-    anything else for the other kernels (tools/eval_breakdown.py)."""
+    anything else for the other kernels (tools/eval_breakdown.py).  nbytes: the launch's ALGORITHMIC bytes (every
+    operand and the output once)."""
     if e0 is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((flops, e0, e1, label))
+        PROFILE.append((flops, e0, e1, label, nbytes))
+
+
+def profile_mark(name):
+    """A zero-length record ("mark <name>") in the PROFILE list: bench.py cuts the launch list of a step into phases."""
+    if PROFILE is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        PROFILE.append((0.0, e, e, "mark " + name, 0))
 
 
 def _lib():
@@ -54,13 +62,24 @@ def _aux_tag():
     return getattr(_tls, "aux", 0)      # 0 = the main stream
 
 
+aux_tag = _aux_tag
+
+
+def workspace_refs():
+    """Every scratch buffer of the calling thread.  A captured HIP graph bakes these addresses into its launches, so
+    whoever caches the graph keeps this list next to it: the buffers then live as long as the graph, whichever thread
+    replays it and whether or not the capturing thread still exists."""
+    return list(getattr(_tls, "ws", {}).values())
+
+
 def workspace(device):
     """Persistent fp32 scratch per (device, host thread, stream tag) -- split-K partials, GroupNorm partial sums: one
     for the main stream and one per concurrent side stream (`aux_workspace`).  Allocated once, before any HIP-graph
     capture; ops on one stream use theirs serially.  The buffers live in the calling thread's `threading.local`, so
     two threads driving one GPU never share scratch and a thread's buffers are released with the thread (a pool of
-    short-lived server threads does not accumulate them).  A HIP graph captured on a thread bakes that thread's
-    buffer addresses in: keep the thread (or the tensors, `workspace(...)` returns them) alive as long as the graph."""
+    short-lived server threads does not accumulate them) -- unless a cached HIP graph holds them: a graph captured on
+    a thread bakes that thread's buffer addresses in, so every graph cache entry keeps `workspace_refs()` beside the
+    graph (pipeline._graphs, sam._graphs, sam_exact) and the buffers live exactly as long as the graph does."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     store = getattr(_tls, "ws", None)
     if store is None:
@@ -175,7 +194,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
         e.ln_stats, e.ln_parts, e.ln_colsum, e.ln_eps = _p(stats), stats.shape[0], _p(colsum), float(eps)
     ev = _prof_begin()
     st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
-    _prof_end(ev, 2.0 * M * N * K, f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}")
+    _prof_end(ev, 2.0 * M * N * K, f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}",
+              2 * (M * K + N * K) + out.element_size() * M * n_out + (residual.element_size() * M * n_out if residual is not None else 0))
     L.check(st, f"ea_gemm_f16 M{M} N{N} K{K}")
     return out
 
@@ -283,8 +303,11 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
             stats = (part, hw // rows)
     ev = _prof_begin()
     st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
-    _prof_end(ev, 2.0 * s.B * s.Hout * s.Wout * cout * w.shape[1],
-              f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}")
+    m_out = s.B * s.Hout * s.Wout
+    _prof_end(ev, 2.0 * m_out * cout * w.shape[1],
+              f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}",
+              2 * (s.B * s.Hin * s.Win * (s.c1 + s.c2) + w.numel()) + out.element_size() * m_out * cout
+              + (residual.element_size() * m_out * cout if residual is not None else 0))
     L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
     return (out, stats) if gn_groups else out
 

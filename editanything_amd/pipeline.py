@@ -43,6 +43,10 @@ def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
 
+class _Call:
+    """One pipeline call in flight: what `front` prepared, what `loop` left behind (attribute bag)."""
+
+
 class StableDiffusionControlNetInpaintPipeline:
     vae_scale_factor = 8
     _guess_mode_cond_only = False   # the generation pipeline runs the ControlNet on the conditional half only in guess mode
@@ -65,6 +69,7 @@ class StableDiffusionControlNetInpaintPipeline:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self.trace.append((name, e))
+            ops.profile_mark(name)
 
     # ---- no-op compatibility shims of the reference's pipeline object (sam2image.py:44-46, editany_lora.py:385-387)
     def to(self, device):
@@ -300,16 +305,30 @@ class StableDiffusionControlNetInpaintPipeline:
 
     # ------------------------------------------------------------------ __call__
     @torch.no_grad()
-    def __call__(self, prompt=None, image=None, mask_image=None, controlnet_conditioning_image=None, height=None,
-                 width=None, num_inference_steps=50, guidance_scale=7.5, negative_prompt=None,
-                 num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
-                 negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
-                 cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
-                 guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None,
-                 ref_image=None, ref_mask=None, ref_controlnet_conditioning_scale=1.0, ref_prompt=None,
-                 ref_prompt_embeds=None, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0,
-                 style_fidelity=0.5, reference_attn=True, reference_adain=True, ref_scale=1.0, **unused):
-        """`ref_image` (+ `ref_mask`, `ref_prompt` or `ref_prompt_embeds`, ...): reference-only control,
+    def __call__(self, *args, **kw):
+        """The reference call (…inpaint.py:1131-1703) = the three stages below, back to back on the caller's stream.
+        `serving.PipelinedRunner` runs the same three stages of CONSECUTIVE calls on two streams (front of call i+1 and
+        back of call i-1 underneath the denoising loop of call i)."""
+        call = self.front(*args, **kw)
+        self.loop(call)
+        return self.back(call)
+
+    @torch.no_grad()
+    def front(self, prompt=None, image=None, mask_image=None, controlnet_conditioning_image=None, height=None,
+              width=None, num_inference_steps=50, guidance_scale=7.5, negative_prompt=None,
+              num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
+              negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
+              cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
+              guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None,
+              ref_image=None, ref_mask=None, ref_controlnet_conditioning_scale=1.0, ref_prompt=None,
+              ref_prompt_embeds=None, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0,
+              style_fidelity=0.5, reference_attn=True, reference_adain=True, ref_scale=1.0, **unused):
+        """Stage 1 of a call: validation, prompt / control / latent / inpaint-input preparation, VAE encode, and the
+        per-call invariants of the denoiser (text K/V of every attention layer, ControlNet hint features, every step's
+        time-embedding rows).  Touches NO state another call's `loop` reads: everything lands in tensors owned by the
+        returned call object (the static buffers of the captured step are filled by `loop`).
+
+        `ref_image` (+ `ref_mask`, `ref_prompt` or `ref_prompt_embeds`, ...): reference-only control,
         …inpaint.py:1163-1182, 1307-1605 (reference_only.py).  Write pass + read pass + sampler step are captured as one
         HIP graph per call (not cached across calls: banks, masks and module selection are per-call state)."""
         if controlnet_conditioning_image is None and "control_image" in unused:
@@ -359,11 +378,11 @@ class StableDiffusionControlNetInpaintPipeline:
             per_net = [self._zero_uncond_rows(base, height, width, n_img) for base in per_net]
         sch = self.scheduler
         timesteps = sch.set_timesteps(num_inference_steps, eta=eta)
-        nsteps = len(timesteps)
         lat = self.prepare_latents(n_img, 4, height, width, generator, latents)
         noise0 = lat.clone()
         unet_in = self.unet.cfg["in_channels"]
         extra = blend_mask = x_orig = None
+        msk = None
         if image is not None:
             img = host.prepare_image(image).to(self.device)
             msk = host.prepare_mask_image(mask_image).to(self.device, torch.float32)
@@ -387,19 +406,19 @@ class StableDiffusionControlNetInpaintPipeline:
                 keep = 1 - F.interpolate(msk, size=(h8, w8), mode="nearest")
                 keep = keep.repeat(n_img // keep.shape[0], 4, 1, 1).contiguous()
                 blend_mask = (1 - keep).contiguous()         # 1 where the sample is generated
-        ref_state = None
+        c = _Call()
+        c.ref_state = c.ref_ctx = None
         if ref_image is not None:
-            ref_state, ref_den, ref_lat, ref_noise = self._prepare_reference(
+            c.ref_state, ref_den, ref_lat, ref_noise = self._prepare_reference(
                 ref_image, ref_mask, ref_prompt, ref_prompt_embeds, ref_controlnet_conditioning_scale, hints, cond_images,
-                width, height, n_img, num_images_per_prompt, do_cfg, generator, lat.shape, msk if image is not None else None,
+                width, height, n_img, num_images_per_prompt, do_cfg, generator, lat.shape, msk,
                 unet_in, dict(style_fidelity=style_fidelity, ref_scale=ref_scale,
                               attention_auto_machine_weight=attention_auto_machine_weight,
                               gn_auto_machine_weight=gn_auto_machine_weight, reference_attn=reference_attn,
                               reference_adain=reference_adain), guess_mode)
-            ref_ctx = dict(state=ref_state, den=ref_den, lat=ref_lat, noise=ref_noise, n_img=n_img, graph=None,
-                           coef=torch.zeros(2, dtype=torch.float32, device=self.device))
+            c.ref_ctx = dict(state=c.ref_state, den=ref_den, lat=ref_lat, noise=ref_noise, n_img=n_img, graph=None,
+                             coef=torch.zeros(2, dtype=torch.float32, device=self.device))
         self._mark("inputs+vae_encode")
-        self.denoiser.only_mid_control = False
         unipc = isinstance(sch, UniPCMultistepScheduler)
         step_noise = eta > 0 and not unipc          # UniPC's step() takes no eta (prepare_extra_step_kwargs drops it)
         # alpha-weighted mixing (StableDiffusionControlNetInpaintMixingPipeline, …inpaint.py:1707-2088): its own blend
@@ -409,64 +428,87 @@ class StableDiffusionControlNetInpaintPipeline:
             raise TypeError("the mixing pipeline compares `i < len(timesteps) * alignment_ratio`: pass alignment_ratio")
         in_loop_blend = x_orig is not None and alignment_ratio is not None and not mixing
         # One denoising step is captured ONCE per (shapes, mode) and replayed by every later call: the graph reads the
-        # latents / text K,V / hint features / inpaint tensors from static buffers that later calls overwrite in place.
+        # latents / text K,V / hint features / inpaint tensors from static buffers that `loop` overwrites in place.
         # Control scales are baked into the captured launches, so they are part of the key; per-pixel scale maps are
         # per-call tensors -> such calls capture afresh.
         gkey = None
-        if self.use_graph and not step_noise and not in_loop_blend and ref_state is None and \
+        if self.use_graph and not step_noise and not in_loop_blend and c.ref_state is None and \
                 all(not torch.is_tensor(v) for sc in per_net for v in sc):
             gkey = (type(sch).__name__, n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
                     tuple(tuple(h.shape) for h in hints), tuple(tuple(sc) for sc in per_net))
-        ent = self._graphs.get(gkey) if gkey is not None else None
         if unipc:
-            coef_table, coef_c_table, coef_p_table = sch.coef_tables(guidance_scale, self.device)
+            c.coef_table, c.coef_c_table, c.coef_p_table = sch.coef_tables(guidance_scale, self.device)
         else:
-            coef_table = sch.coef_table(guidance_scale, self.device)
-        nb = 2 * n_img if do_cfg else n_img
+            c.coef_table = sch.coef_table(guidance_scale, self.device)
+        # the denoiser's per-call invariants (text K/V, hint features) and every step's time-embedding rows, as values
+        c.invariants = self.denoiser.compute_invariants(embeds, hints)
+        c.emb_tables = self.denoiser.time_embeddings(torch.as_tensor(timesteps.astype(np.int64), device=self.device))
+        self._mark("prepare(hint,text kv)")
+        c.sch, c.timesteps, c.lat, c.noise0, c.extra, c.blend_mask, c.x_orig = sch, timesteps, lat, noise0, extra, blend_mask, x_orig
+        c.per_net, c.unipc, c.step_noise, c.mixing, c.in_loop_blend, c.gkey = per_net, unipc, step_noise, mixing, in_loop_blend, gkey
+        c.do_cfg, c.n_img, c.generator, c.alignment_ratio, c.alpha_weight = do_cfg, n_img, generator, alignment_ratio, alpha_weight
+        c.callback, c.callback_steps, c.output_type, c.return_dict = callback, callback_steps, output_type, return_dict
+        c.final = None
+        return c
+
+    def has_graph(self, call):
+        """True when `loop(call)` will replay an already captured step (nothing is captured, nothing allocated)."""
+        return call.gkey is not None and call.gkey in self._graphs
+
+    @torch.no_grad()
+    def loop(self, c):
+        """Stage 2: hand the call's tensors to the (static) buffers of the captured step, run the denoising steps, leave
+        the final latents in `c.final` (a tensor the call owns)."""
+        sch, timesteps, generator = c.sch, c.timesteps, c.generator
+        nsteps = len(timesteps)
+        lat, x_orig, extra, blend_mask = c.lat, c.x_orig, c.extra, c.blend_mask
+        unipc, step_noise, mixing, in_loop_blend, gkey = c.unipc, c.step_noise, c.mixing, c.in_loop_blend, c.gkey
+        ref_state, ref_ctx = c.ref_state, c.ref_ctx
+        self.denoiser.only_mid_control = False
+        ent = self._graphs.get(gkey) if gkey is not None else None
+        nb = 2 * c.n_img if c.do_cfg else c.n_img
         if ent is not None:
-            self.denoiser.prepare(embeds, hints, per_net, static=ent["den"])
+            self.denoiser.install(c.invariants, c.per_net, static=ent["den"])
             st = ent["st"]
             st["lat"].copy_(lat)
             if extra is not None:
                 st["extra"].copy_(extra)
             if x_orig is not None:
                 st["x_orig"].copy_(x_orig)
-                st["noise_orig"].copy_(noise0)
-            x_orig = st["x_orig"]
+                st["noise_orig"].copy_(c.noise0)
             graph = ent["graph"]
             if unipc:
                 for k in ("m_t", "m0", "m1", "last", "lat_c"):
                     st["unipc"][k].zero_()
         else:
-            self.denoiser.prepare(embeds, hints, per_net)
+            self.denoiser.install(c.invariants, c.per_net)
             st = dict(lat=lat.contiguous(), lat_out=torch.empty_like(lat),
-                      t=torch.zeros(nb, dtype=torch.long, device=self.device), coef=coef_table[0].clone(), cfg=do_cfg,
-                      extra=extra, noise=None, blend_mask=None, x_orig=x_orig,
-                      noise_orig=noise0 if x_orig is not None else None)
+                      t=torch.zeros(nb, dtype=torch.long, device=self.device), coef=c.coef_table[0].clone(), cfg=c.do_cfg,
+                      extra=extra, noise=None, blend_mask=None, x_orig=None if x_orig is None else x_orig.clone(),
+                      noise_orig=c.noise0 if x_orig is not None else None)
             graph = None
             if unipc:
                 z = lambda: torch.zeros_like(st["lat"])
                 st["unipc"] = dict(m_t=z(), m0=z(), m1=z(), last=z(), lat_c=z(), scratch=z(),
-                                   coefC=coef_c_table[0].clone(), coefP=coef_p_table[0].clone())
-        # every step's time-embedding rows in one shot; step i copies row i into the static [1, sum(Cout)] buffers
-        emb_tables = self.denoiser.time_embeddings(torch.as_tensor(timesteps.astype(np.int64), device=self.device))
+                                   coefC=c.coef_c_table[0].clone(), coefP=c.coef_p_table[0].clone())
+        # every step's time-embedding rows were computed in one shot; step i copies row i into the static [1, sum(Cout)] buffers
+        emb_tables = c.emb_tables
         if st.get("embs") is None:
             st["embs"] = [tb[:1].clone() for tb in emb_tables]
-        self._mark("prepare(hint,text kv)")
         mix_gen = generator if not isinstance(generator, list) else generator[0]
         if mixing:   # …inpaint.py:1968-1975: the kept region starts from the re-noised original, the rest from pure noise
             self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[0])]), 0.0, True, mix_gen)
         for i in range(nsteps):
             st["t"].fill_(int(timesteps[i]))
-            st["coef"].copy_(coef_table[i])
+            st["coef"].copy_(c.coef_table[i])
             if unipc:
-                st["unipc"]["coefC"].copy_(coef_c_table[i])
-                st["unipc"]["coefP"].copy_(coef_p_table[i])
+                st["unipc"]["coefC"].copy_(c.coef_c_table[i])
+                st["unipc"]["coefP"].copy_(c.coef_p_table[i])
             for dst, tb in zip(st["embs"], emb_tables):
                 dst.copy_(tb[i:i + 1])
             st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
                 if step_noise else None
-            blend_now = in_loop_blend and i < nsteps * alignment_ratio and i + 1 < nsteps
+            blend_now = in_loop_blend and i < nsteps * c.alignment_ratio and i + 1 < nsteps
             st["blend_mask"] = blend_mask if blend_now else None
             if ref_state is not None:
                 # …inpaint.py:1562-1605: the reference latents, noised to this step's level, go through ControlNet + UNet
@@ -485,27 +527,35 @@ class StableDiffusionControlNetInpaintPipeline:
                 if graph is None:
                     graph = self._capture(st)
                     if gkey is not None:
-                        self._graphs[gkey] = dict(st=st, graph=graph, den=self.denoiser.static_state())
+                        # the entry owns everything the captured launches address: the static tensors, the denoiser's
+                        # invariants and the scratch buffers of every stream of the step (ops.workspace_refs)
+                        self._graphs[gkey] = dict(st=st, graph=graph, den=self.denoiser.static_state(),
+                                                  scratch=ops.workspace_refs())
                 graph.replay()
             else:
                 self._step(st)
-            if callback is not None and i % callback_steps == 0:
-                callback(i, int(timesteps[i]), st["lat"])
+            if c.callback is not None and i % c.callback_steps == 0:
+                c.callback(i, int(timesteps[i]), st["lat"])
             if mixing and i < nsteps - 1:     # …inpaint.py:2039-2051
                 self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[i + 1])]),
-                                float(alpha_weight), i < nsteps * alignment_ratio, mix_gen)
-        lat = st["lat"]
+                                float(c.alpha_weight), i < nsteps * c.alignment_ratio, mix_gen)
+        c.final = st["lat"].clone()           # never hand out (or decode from) the captured step's static buffer
         self._mark("denoise loop")
-        if x_orig is not None and not mixing and (alignment_ratio is None or alignment_ratio == 1.0):
-            lat = x_orig * (1 - blend_mask) + lat * blend_mask     # fill the kept region with the original
-        if output_type == "latent":
-            images = lat.clone() if lat is st["lat"] else lat      # never hand out the graph's static buffer
+
+    @torch.no_grad()
+    def back(self, c):
+        """Stage 3: final fill of the kept region, VAE decode, output conversion.  Reads only tensors the call owns."""
+        lat = c.final
+        if c.x_orig is not None and not c.mixing and (c.alignment_ratio is None or c.alignment_ratio == 1.0):
+            lat = c.x_orig * (1 - c.blend_mask) + lat * c.blend_mask     # fill the kept region with the original
+        if c.output_type == "latent":
+            images = lat
         else:
             images = self.decode_latents(lat)
-            if output_type == "pil":
+            if c.output_type == "pil":
                 images = host.numpy_to_pil(images)
         self._mark("vae_decode")
-        if not return_dict:
+        if not c.return_dict:
             return images, None
         return StableDiffusionPipelineOutput(images, None)
 

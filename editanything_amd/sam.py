@@ -154,9 +154,11 @@ class ImageEncoderViT:
         return self._wmaps[key]
 
     def forward_graph(self, x):
-        """`forward` replayed from a HIP graph captured once per input shape (~450 launches per ViT-H pass otherwise;
-        the serving path: same result, no per-launch host cost, no inter-kernel gaps from the Python side)."""
-        key = tuple(x.shape)
+        """`forward` replayed from a HIP graph captured once per (input shape, scratch tag) (~450 launches per ViT-H pass
+        otherwise; the serving path: same result, no per-launch host cost, no inter-kernel gaps from the Python side).
+        The scratch tag (ops.aux_workspace) is part of the key: a pass issued on a side stream beside other work uses --
+        and its graph bakes in -- that stream's own split-K scratch.  The cache entry owns the scratch it addresses."""
+        key = tuple(x.shape) + (ops.aux_tag(),)
         ent = self._graphs.get(key)
         if ent is None:
             xs = x.to(self.device).clone()
@@ -169,8 +171,8 @@ class ImageEncoderViT:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.forward(xs)
-            ent = self._graphs[key] = (g, xs, out)
-        g, xs, out = ent
+            ent = self._graphs[key] = (g, xs, out, ops.workspace_refs())
+        g, xs, out = ent[:3]
         xs.copy_(x)
         g.replay()
         return out.clone()

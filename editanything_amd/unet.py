@@ -443,24 +443,30 @@ class ControlledDenoiser:
         """The per-call invariants a captured step reads (pipeline graph cache keeps them alive and refills them)."""
         return dict(kv_u=self.kv_u, kv_c=self.kv_c, hints=self.hints)
 
-    def prepare(self, context, hints=None, control_scales=None, static=None):
-        """`static`: a `static_state()` of an earlier call with identical shapes -- the new values are written INTO
-        those buffers (same addresses), so a HIP graph captured over them stays valid."""
+    def compute_invariants(self, context, hints=None):
+        """The per-call invariants as VALUES (nothing of this object changes): text K/V projections of every attention
+        layer of the UNet and of each ControlNet, and each ControlNet's hint features.  `install` makes them current."""
         kv_u = self.unet.project_context(context)
         kv_c, hs = [], []
         hints = [] if hints is None else (hints if isinstance(hints, (list, tuple)) else [hints])
         for cn, hint in zip(self.controlnets, hints):
             kv_c.append(cn.project_context(context))
             hs.append(None if hint is None else cn.encode_hint(hint))
+        return dict(kv_u=kv_u, kv_c=kv_c, hints=hs)
+
+    def install(self, inv, control_scales=None, static=None):
+        """Make `compute_invariants` values the ones `eps` reads.  `static`: a `static_state()` of an earlier call with
+        identical shapes -- the new values are written INTO those buffers (same addresses), so a HIP graph captured
+        over them stays valid."""
         if static is None:
-            self.kv_u, self.kv_c, self.hints = kv_u, kv_c, hs
+            self.kv_u, self.kv_c, self.hints = inv["kv_u"], inv["kv_c"], inv["hints"]
         else:
-            for dst, src in zip(static["kv_u"], kv_u):
+            for dst, src in zip(static["kv_u"], inv["kv_u"]):
                 dst.copy_(src)
-            for dl, sl in zip(static["kv_c"], kv_c):
+            for dl, sl in zip(static["kv_c"], inv["kv_c"]):
                 for dst, src in zip(dl, sl):
                     dst.copy_(src)
-            for dst, src in zip(static["hints"], hs):
+            for dst, src in zip(static["hints"], inv["hints"]):
                 if dst is not None:
                     dst.copy_(src)
             self.kv_u, self.kv_c, self.hints = static["kv_u"], static["kv_c"], static["hints"]
@@ -470,6 +476,10 @@ class ControlledDenoiser:
         elif not isinstance(control_scales[0], (list, tuple)):
             control_scales = [list(control_scales) for _ in self.controlnets]
         self.control_scales = control_scales
+
+    def prepare(self, context, hints=None, control_scales=None, static=None):
+        """compute_invariants + install (ControlLDM.apply_model's per-call part for a fixed (context, hint))."""
+        self.install(self.compute_invariants(context, hints), control_scales, static)
 
     def time_embeddings(self, timesteps):
         """Per-network time-embedding projections (fp32 [len(timesteps), sum(Cout)]) for a vector of timesteps.  The

@@ -101,6 +101,54 @@ def test_inpaint_pipeline_decoded_image_vs_reference_golden(mg, gold, tiny):
     assert np.abs(np.asarray(pil[0]).astype(np.int32) - np.round(ref[0] * 255).astype(np.int32)).max() <= 6
 
 
+def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny):
+    """serving.PipelinedRunner (front of request i+1 and back of request i-1 on a side stream under the loop of request i)
+    computes, request by request, the bits `pipe(**kw)` computes -- five requests with different seeds / images / controls
+    / prompts (front as a plain kwargs dict and as a callable that runs a SAM encode on the side stream first), and
+    request 0 still meets the reference golden."""
+    from editanything_amd import serving
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+    from editanything_amd.sam import ImageEncoderViT
+    ukey, cns, kw0 = mg.pipe_case_kwargs("a_none", mg.pipe_inputs())
+    enc = ImageEncoderViT(arch.TINY_SAM, synth.synth_state_dict_torch(arch.sam_encoder_param_shapes(arch.TINY_SAM), 10), DEV)
+    rng = np.random.default_rng(5)
+    x_sam = torch.from_numpy(rng.standard_normal((1, 3, 448, 448)).astype(np.float32)).to(DEV)
+    reqs = []
+    for r in range(5):
+        kw = dict(kw0)
+        if r:
+            for k, v in kw0.items():
+                if torch.is_tensor(v) and v.is_floating_point() and k not in ("mask_image",):
+                    kw[k] = v + 0.05 * r * torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32)).to(v.device)
+            if torch.is_tensor(kw.get("image")):
+                kw["image"] = kw["image"].clamp(-1, 1)
+        reqs.append(kw)
+    seq_pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
+    want = [seq_pipe(generator=torch.Generator("cpu").manual_seed(11 + r), **kw).images.clone() for r, kw in enumerate(reqs)]
+    sam_want = enc.forward_graph(x_sam).clone()
+    assert rel_l2(want[0], gold["inpaint_a_none"]) <= 1.5e-2
+    pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
+    runner = serving.PipelinedRunner(pipe)
+    embs = []
+
+    def request(r, kw):
+        def make():
+            embs.append(enc.forward_graph(x_sam))          # replayed on the side stream, with the side stream's scratch
+            return dict(kw, generator=torch.Generator("cpu").manual_seed(11 + r))
+        return make if r % 2 else dict(kw, generator=torch.Generator("cpu").manual_seed(11 + r))
+    for rounds in range(2):                                 # second round: every request replays the cached graph
+        got = runner.run([request(r, kw) for r, kw in enumerate(reqs)])
+        torch.cuda.synchronize()
+        for r, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g.images, w), f"round {rounds} request {r}: rel-L2 {rel_l2(g.images, w):.3e}"
+    assert len(pipe._graphs) == 1 and all(torch.equal(e, sam_want) for e in embs)
+    # decoded output through the side stream's VAE decode
+    kw = dict(reqs[1], output_type="np")
+    a = seq_pipe(generator=torch.Generator("cpu").manual_seed(3), **kw).images
+    b = runner.run([dict(kw, generator=torch.Generator("cpu").manual_seed(3)) for _ in range(3)])
+    assert all(np.array_equal(a, o.images) for o in b)
+
+
 @pytest.mark.parametrize("nets", [["cn"], ["cn", "cn2"]])
 def test_shared_cfg_prefix_equals_the_doubled_batch(mg, tiny, nets):
     """eps(cfg_halves=True): conv_in, the first ResBlock and the first transformer's self-attention computed on ONE copy

@@ -109,13 +109,22 @@ def test_call_front_half_with_bench_shaped_inputs():
         seen["vae_in"], seen["vae_noise"] = tuple(img.shape), tuple(noise.shape)
         return torch.zeros(img.shape[0], 4, 64, 64)
 
-    def prepare(embeds, hints, per_net, static=None):
-        seen["embeds"], seen["hints"], seen["scales"] = tuple(embeds.shape), [tuple(h.shape) for h in hints], per_net
+    def compute_invariants(embeds, hints):
+        seen["embeds"], seen["hints"] = tuple(embeds.shape), [tuple(h.shape) for h in hints]
+        return {}
+
+    def time_embeddings(ts):
+        seen["timesteps"] = len(ts)
+        return []
+
+    def install(inv, per_net, static=None):
+        seen["scales"] = per_net
         raise Stop()
 
     p.vae = types.SimpleNamespace(encode=encode, scale_factor=0.18215)
     p.scheduler, p.text_encoder, p.tokenizer, p.device = DDIMScheduler(), None, None, torch.device("cpu")
-    p.denoiser = types.SimpleNamespace(prepare=prepare, only_mid_control=False)
+    p.denoiser = types.SimpleNamespace(compute_invariants=compute_invariants, time_embeddings=time_embeddings, install=install,
+                                       only_mid_control=False)
     p.use_graph, p._graphs, p.trace = True, {}, None
     mask = torch.zeros(1, 1, 512, 512)
     mask[:, :, 128:384, 128:384] = 1
@@ -126,7 +135,7 @@ def test_call_front_half_with_bench_shaped_inputs():
           guidance_scale=7.5, num_images_per_prompt=1, generator=torch.Generator("cpu").manual_seed(0))
     assert seen["vae_in"] == (4, 3, 512, 512) and seen["vae_noise"] == (4, 4, 64, 64)
     assert seen["embeds"] == (8, 77, 1024) and seen["hints"] == [(8, 3, 512, 512)]          # [uncond || cond]
-    assert seen["scales"] == [[1.0] * 13]
+    assert seen["scales"] == [[1.0] * 13] and seen["timesteps"] == 20
 
 
 def test_load_textual_inversion_adds_tokens_and_rows(tmp_path):
