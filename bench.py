@@ -45,6 +45,12 @@ def parse():
                     help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
                          "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--quick", action="store_true",
+                    help="timed region only (for profiler traces): no sequential A/B, phase pass, extras, roofline leg, calibration")
+    ap.add_argument("--side-priority", choices=["torch", "low", "normal", "high"], default="low",
+                    help="experiment switch: HIP priority of the software pipeline's side stream (torch = a torch.cuda.Stream())")
+    ap.add_argument("--pipeline-thread", choices=["on", "off"], default="on",
+                    help="experiment switch: off = the side stream's stages are issued by the thread that issues the loops")
     ap.add_argument("--loop-priority", choices=["default", "high"], default="default",
                     help="experiment switch: issue the denoising loops on a high-priority stream (the side stream of the "
                          "software pipeline keeps the default priority)")
@@ -197,7 +203,8 @@ def main():
     orig_decode = pipe.decode_latents
     pipe.decode_latents = lambda lat: (pipe.vae.decode_nhwc(lat / pipe.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
     pipelined = not args.no_pipeline and not args.no_graph
-    runner = serving.PipelinedRunner(pipe) if pipelined else None
+    runner = serving.PipelinedRunner(pipe, threaded=args.pipeline_thread == "on",
+                                     side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority]) if pipelined else None
     hi_stream = torch.cuda.Stream(priority=-1) if (pipelined and args.loop_priority == "high") else None
 
     def run_steps(first_seed, k):
@@ -230,7 +237,7 @@ def main():
     # the same batches one after the other on one stream (no overlap between batches), and per-batch latency of both modes:
     # same box, same process, right after the timed region -- an A/B a reader can recompute the pipelining gain from
     seq = None
-    if runner is not None:
+    if runner is not None and not args.quick:
         k = max(2, min(args.steps, 5))
         one_step(args.seed + 2000)
         torch.cuda.synchronize()
@@ -239,23 +246,35 @@ def main():
             one_step(args.seed + 2001 + i)
         torch.cuda.synchronize()
         t_seq = (time.perf_counter() - t1) / k
-        runner.latency_events = []
-        runner.run([request(args.seed + 3000 + i) for i in range(k + 2)])
+        runner.latency_events, runner.host_trace, runner.timeline = [], [], {}
+        reqs = [request(args.seed + 3000 + i) for i in range(k + 2)]
+        runner.run(reqs)
         torch.cuda.synchronize()
         lat = [a.elapsed_time(b) for a, b in runner.latency_events]
-        runner.latency_events = None
+        host_ms = [round(t * 1e3, 1) for _, t in runner.host_trace]
+        # device timeline of one steady-state iteration: the loop of request m, and what the side stream did meanwhile
+        # (decode of request m-1, front of request m+1), in ms from the loop's first launch
+        tl, m = runner.timeline, (k + 2) // 2
+        base = tl[("loop", id(reqs[m]))][0]
+        rel = lambda key: [round(base.elapsed_time(e), 1) for e in tl[key]]
+        timeline = {"loop": rel(("loop", id(reqs[m]))), "side_decode_prev": rel(("back", id(reqs[m - 1]))),
+                    "side_front_next": rel(("front", id(reqs[m + 1]))), "next_loop": rel(("loop", id(reqs[m + 1])))}
+        runner.latency_events = runner.host_trace = runner.timeline = None
         seq = {"value": round(args.batch / t_seq, 4), "ms_per_step": round(t_seq * 1e3, 2), "steps": k,
                "latency_ms_per_batch": round(t_seq * 1e3, 2),
                "pipelined_latency_ms_per_batch": round(float(np.mean(lat[1:-1])), 2),
+               "host_ms_issuing_one_loop": host_ms, "pipelined_timeline_ms": timeline,
                "note": "sequential = SAM -> prepare -> loop -> decode of one batch after the other on one stream; latency = first "
                        "launch of a batch's SAM encode to the end of its VAE decode (device events; steady-state requests)"}
     # untimed diagnostic pass: GPU time per phase of one step (events on the launch stream; not part of `value`).
     # pipeline marks: start | inputs+vae_encode | prepare(hint,text kv) | denoise loop | vae_decode
     ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record()
-    pipe.trace = []
-    one_step(args.seed + 5000)
-    marks, pipe.trace = pipe.trace, None
+    marks = []
+    if not args.quick:
+        pipe.trace = []
+        one_step(args.seed + 5000)
+        marks, pipe.trace = pipe.trace, None
     torch.cuda.synchronize()
     phases, prev = {}, ev0
     for name, ev in marks:
@@ -291,14 +310,14 @@ def main():
     if seq is not None:
         result["sequential"] = seq
         result["pipelining_gain"] = round(value / world / seq["value"], 4)
-    if rank == 0:
+    if rank == 0 and not args.quick:
         result["calibration"] = calibration(dev)
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.quick:
         result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases))
     if rank == 0:
-        result["roofline"] = roofline_leg(one_step, pipe, args)
+        result["roofline"] = None if args.quick else roofline_leg(one_step, pipe, args)
         result["cpu_baseline"] = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.quick:
             result["cpu_baseline"] = cpu_baseline(sds, args)
         print(json.dumps(result), flush=True)
     pipe.decode_latents = orig_decode

@@ -21,53 +21,136 @@ stage ever reads a buffer another in-flight request writes.  The side stream has
 Latency: a request leaves the runner one denoising loop after the sequential path would have finished it at the
 latest (its decode waits for nothing but its own loop); throughput is what moves -- bench.py reports both.
 """
+import concurrent.futures
+import time
+
 import torch
 
 from . import ops
 
 SIDE_TAG = 16      # scratch number of the side stream (0 / 1 and 2g / 2g+1 belong to the streams of an evaluation, unet.py)
+_keep = []         # HIP streams made by make_stream (never destroyed: graphs / events may reference them)
+
+
+def make_stream(device, priority):
+    """A non-blocking HIP stream of an explicit HIP priority (-1 high, 0 normal, 1 low), wrapped for torch.
+
+    Why not torch.cuda.Stream(): HIP multiplexes its streams onto a few hardware queues PER PRIORITY LEVEL (4 by default),
+    handing each new stream the least-used queue of its level.  A side stream of normal priority can therefore land on the
+    hardware queue that also carries the ControlNet branch of the captured step -- the two then run strictly in order and
+    the side stream's work displaces exactly the overlap the step already had (measured: pipelining gain 1.00,
+    profiles/r04_pipelined_ab.jsonl).  A stream of another priority level draws from another set of queues."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = hipStreamNonBlocking
+    if rc != 0:
+        raise RuntimeError(f"hipStreamCreateWithPriority(priority={priority}) failed: {rc}")
+    _keep.append(h)
+    return torch.cuda.ExternalStream(h.value, device=device)
 
 
 class PipelinedRunner:
-    def __init__(self, pipe, side_stream=None):
+    def __init__(self, pipe, side_stream=None, threaded=True, side_priority=1):
+        """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
+        the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
+        packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:
+        side-stream work issued by the same thread afterwards would reach the device when the loop is nearly over
+        (measured: zero overlap, profiles/r04_pipelined_ab.jsonl).  The worker owns its scratch (ops.workspace is per
+        thread) and lives as long as the runner, so graphs captured on it stay valid."""
         self.pipe = pipe
         self.device = pipe.device
+        self.threaded = threaded
+        self._pool = None
         with torch.cuda.device(self.device):
-            self.side = side_stream if side_stream is not None else torch.cuda.Stream()
-            with ops.aux_workspace(SIDE_TAG):
-                ops.workspace(self.device)        # allocated here, eagerly -- never inside a capture
+            if side_stream is None:
+                side_stream = torch.cuda.Stream() if side_priority is None else make_stream(self.device, side_priority)
+            self.side = side_stream
+        self._on_side(lambda: ops.workspace(self.device)).result()     # allocated here, eagerly -- never inside a capture
         self.latency_events = None                # set to a list: (front start, back end) event pairs per request
+        self.host_trace = None                    # set to a list: (request, seconds spent issuing its loop)
+        self.timeline = None                      # set to a dict: (stage, request) -> (start event, end event), device timeline
 
-    def _front(self, req):
-        """Runs on the side stream: `req` is the pipeline's kwargs, or a callable producing them (the SAM encode +
-        mask generation + control-image part of a request belongs here: it is issued on the side stream too)."""
-        with torch.cuda.stream(self.side), ops.aux_workspace(SIDE_TAG):
+    def _span(self, key):
+        """Context manager recording a timed event pair on the current stream into `timeline` (no-op when it is None)."""
+        runner = self
+
+        class _S:
+            def __enter__(self):
+                if runner.timeline is not None:
+                    self.e0 = torch.cuda.Event(enable_timing=True)
+                    self.e0.record()
+
+            def __exit__(self, *exc):
+                if runner.timeline is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    runner.timeline[key] = (self.e0, e1)
+        return _S()
+
+    def _on_side(self, fn):
+        """Run fn() with the side stream current and the side scratch selected -- on the worker thread (-> Future) or,
+        unthreaded, right here (-> an already finished Future)."""
+        def task():
+            with torch.cuda.device(self.device), torch.cuda.stream(self.side), ops.aux_workspace(SIDE_TAG), torch.no_grad():
+                return fn()
+        if self.threaded:
+            if self._pool is None:
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="ea-side-stream")
+            return self._pool.submit(task)
+        f = concurrent.futures.Future()
+        try:
+            f.set_result(task())
+        except BaseException as e:      # delivered where the result is awaited, like the threaded form
+            f.set_exception(e)
+        return f
+
+    def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+
+    def _front(self, req, after=None):
+        """On the side stream: `req` is the pipeline's kwargs, or a callable producing them (the SAM encode + mask
+        generation + control-image part of a request belongs here: it is issued on the side stream too).
+        after: an event of the caller's stream the inputs depend on."""
+        def fn():
+            if after is not None:
+                self.side.wait_event(after)
             e0 = None
             if self.latency_events is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            kw = req() if callable(req) else req
-            call = self.pipe.front(**kw)
-            call._t0 = e0
+            with self._span(("front", id(req))):
+                kw = req() if callable(req) else req
+                call = self.pipe.front(**kw)
+            call._t0, call._req = e0, id(req)
             ev = torch.cuda.Event()
             ev.record()
-        return call, ev
+            return call, ev
+        return self._on_side(fn)
 
-    def _back(self, call, ev_loop):
-        with torch.cuda.stream(self.side), ops.aux_workspace(SIDE_TAG):
+    def _back(self, call, ev_loop, consumer):
+        def fn():
             self.side.wait_event(ev_loop)
             call.final.record_stream(self.side)   # allocated on the caller's stream, read here
-            out = self.pipe.back(call)
+            with self._span(("back", call._req)):
+                out = self.pipe.back(call)
+            img = getattr(out, "images", None)
+            if torch.is_tensor(img):
+                img.record_stream(consumer)       # allocated here, read by the caller on its stream
             if call._t0 is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
                 self.latency_events.append((call._t0, e1))
-        return out
+            return out
+        return self._on_side(fn)
 
     @torch.no_grad()
     def run(self, requests):
         """requests: a sequence of kwargs dicts (or callables returning one) for `pipe(...)`.  Returns the list of
-        pipeline outputs, in order.  Everything is enqueued asynchronously; the caller's stream is made to wait for the
+        pipeline outputs, in order.  Device work is enqueued asynchronously; the caller's stream is made to wait for the
         side stream before returning, so the outputs are ordinary tensors of the caller's stream."""
         requests = list(requests)
         n = len(requests)
@@ -75,26 +158,38 @@ class PipelinedRunner:
         if n == 0:
             return outs
         main = torch.cuda.current_stream(self.device)
-        self.side.wait_stream(main)               # inputs the caller produced on its stream
-        nxt = self._front(requests[0])
+        start = torch.cuda.Event()
+        start.record(main)                        # inputs the caller produced on its stream
+        nxt = self._front(requests[0], after=start)
         prev = None                               # (call, loop-done event) of the request whose decode is still owed
         for i in range(n):
-            call, ev_front = nxt
-            main.wait_event(ev_front)
-            if not self.pipe.has_graph(call):
+            call, ev_front = nxt.result()
+            capture = not self.pipe.has_graph(call)
+            if capture:
                 # first call of a shape: the step is captured inside `loop` -- nothing else may run on the device then
                 if prev is not None:
-                    outs[i - 1] = self._back(*prev)
-                    prev = None
+                    outs[i - 1] = self._back(*prev, main).result()
                 torch.cuda.synchronize(self.device)
-            self.pipe.loop(call)
+            else:
+                # the side stream's share of this iteration goes out first (on the worker: concurrently with the loop below)
+                if prev is not None:
+                    outs[i - 1] = self._back(*prev, main)
+                if i + 1 < n:
+                    nxt = self._front(requests[i + 1])
+            main.wait_event(ev_front)
+            t0 = time.perf_counter()
+            with self._span(("loop", call._req)):
+                self.pipe.loop(call)
+            if self.host_trace is not None:
+                self.host_trace.append((i, time.perf_counter() - t0))
             ev_loop = torch.cuda.Event()
             ev_loop.record(main)
-            if prev is not None:
-                outs[i - 1] = self._back(*prev)
             prev = (call, ev_loop)
-            if i + 1 < n:
+            if capture and i + 1 < n:
                 nxt = self._front(requests[i + 1])
-        outs[n - 1] = self._back(*prev)
-        main.wait_stream(self.side)
+        outs[n - 1] = self._back(*prev, main)
+        outs = [o.result() if isinstance(o, concurrent.futures.Future) else o for o in outs]
+        done = torch.cuda.Event()
+        self._on_side(lambda: done.record()).result()
+        main.wait_event(done)
         return outs
