@@ -6,7 +6,6 @@ libeditanything_hip.so on `torch.cuda.current_stream()`.  Activations are NHWC f
 There is no eager/CPU fallback: tensors must live on the MI355X.
 """
 import ctypes as C
-import os
 
 import torch
 
@@ -154,12 +153,32 @@ def geglu_block(n_gemm, k):
     return 32 if (n_gemm % 128 == 0 and k % 64 == 0) else 64
 
 
-LN_FOLD = os.environ.get("EA_LN_FOLD", "1") != "0"      # A/B switch (tools/): 0 keeps the LayerNorm launches
+class _Config:
+    """Fusion switches of the host layer -- plain attributes, set through `configure()` (tools / tests A-B runs) or by the
+    constructors that own them; nothing here reads the environment.
+      ln_fold       LayerNorm -> Linear as one launch where the shape qualifies (False keeps the LayerNorm launches)
+      gn_epilogue   GroupNorm statistics from the producing contraction's epilogue (False keeps the statistics passes)
+      gn_next       the split-K reduction applies the consuming GroupNorm itself (one launch instead of three at the
+                    16 x 16 / 8 x 8 levels: ea_epilogue.gn_next_out)"""
+    ln_fold = True
+    gn_epilogue = True
+    gn_next = False
+
+
+CONFIG = _Config()
+
+
+def configure(**kw):
+    for k, v in kw.items():
+        if not hasattr(_Config, k):
+            raise TypeError(f"unknown ops option {k!r}")
+        setattr(CONFIG, k, bool(v))
+    return CONFIG
 
 
 def ln_fold_ok(M, N, K):
     """Can a LayerNorm-folded GEMM of this shape run (register-direct epilogue, no split-K)?"""
-    return LN_FOLD and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
+    return CONFIG.ln_fold and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
 
 
 def row_stats_buffer(M, N, device):
@@ -235,13 +254,10 @@ def _rows_per_group(rowvec, s):
     return s.Hout * s.Wout
 
 
-GN_EPILOGUE = os.environ.get("EA_GN_EPILOGUE", "1") != "0"      # A/B switch (tools/): 0 keeps the statistics passes
-# The split-K reduction can apply the consuming GroupNorm itself (ea_epilogue.gn_next_out; one launch instead of three at the
-# 16 x 16 / 8 x 8 levels).  Measured on the MI355X (profiles/r03_fused_reduce_groupnorm_ab.jsonl): -6 us per site, 29 sites per
-# evaluation, -0.8 % on the denoising loop -- but one graph replay in ten runs 7 % SLOWER with identical kernel times: the
-# (sample, group) workgroups take half a CU each and, when they land beside the other stream's contraction launch, the two
-# streams stop packing into each other (that overlap is worth 19 %).  Net zero, with a tail: OFF unless EA_GN_NEXT=1.
-GN_NEXT = os.environ.get("EA_GN_NEXT", "0") == "1"
+# CONFIG.gn_next -- measured on the MI355X with the two-stream phase-1 overlap (profiles/r03_fused_reduce_groupnorm_ab.jsonl):
+# -6 us per site, 29 sites per evaluation, -0.8 % on the denoising loop, but one graph replay in ten ran 7 % SLOWER with
+# identical kernel times: the (sample, group) workgroups take half a CU each and, when they landed beside the other stream's
+# contraction launch, the two streams stopped packing into each other.
 
 
 class Normed:
@@ -255,7 +271,7 @@ class Normed:
 def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
     """True when a contraction of this shape is split along K and its reduction can apply the GroupNorm that consumes the
     output (`ea_epilogue.gn_next_out`)."""
-    if not GN_EPILOGUE or not GN_NEXT or PROFILE is not None or N % groups:
+    if not CONFIG.gn_epilogue or not CONFIG.gn_next or PROFILE is not None or N % groups:
         return False
     return bool(_lib().ea_gemm_gn_next_ok(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 
@@ -263,7 +279,7 @@ def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
 def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
     """Rows per GroupNorm-statistics chunk when a contraction of this shape can leave the partials of its OUTPUT behind
     for the GroupNorm that reads it (`ea_epilogue.gn_stats_out`), else 0."""
-    if not GN_EPILOGUE or PROFILE is not None or N % groups:
+    if not CONFIG.gn_epilogue or PROFILE is not None or N % groups:
         return 0
     return int(_lib().ea_gemm_gn_stats_chunk_rows(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 

@@ -52,14 +52,15 @@ class StableDiffusionControlNetInpaintPipeline:
     _guess_mode_cond_only = False   # the generation pipeline runs the ControlNet on the conditional half only in guess mode
 
     def __init__(self, vae, unet, controlnet, scheduler=None, text_encoder=None, tokenizer=None, device="cuda",
-                 use_graph=True):
+                 use_graph=True, denoiser_options=None):
+        """denoiser_options: keyword arguments of `unet.ControlledDenoiser` (stream overlap, shared CFG prefix, twin launches)."""
         self.vae, self.unet = vae, unet
         self.controlnet = controlnet
         self.controlnets = list(controlnet) if isinstance(controlnet, (list, tuple)) else [controlnet]
         self.scheduler = scheduler or DDIMScheduler()
         self.text_encoder, self.tokenizer = text_encoder, tokenizer
         self.device = torch.device(device)
-        self.denoiser = ControlledDenoiser(unet, self.controlnets)
+        self.denoiser = ControlledDenoiser(unet, self.controlnets, **(denoiser_options or {}))
         self.use_graph = use_graph
         self._graphs = {}       # (shape / mode key) -> {"st", "graph", "den"}: captured once, replayed by every later call
         self.trace = None       # set to a list: (phase name, torch.cuda.Event) marks are appended (bench.py --phases)
@@ -278,10 +279,15 @@ class StableDiffusionControlNetInpaintPipeline:
     # ------------------------------------------------------------------ the step
     def _step(self, st):
         lat = st["lat"]
-        x2 = torch.cat([lat] * 2) if st["cfg"] else lat
-        if st["extra"] is not None:                               # 9-ch inpaint UNet: latents || mask || masked latents
-            x2 = torch.cat([x2, st["extra"]], dim=1)
-        eps = self.denoiser.eps(x2, st["t"], embs=st.get("embs"), cfg_halves=bool(st["cfg"]))
+        if st["cfg"] and st["extra"] is None and self.denoiser.will_share_prefix(st["t"].shape[0], st.get("embs")):
+            # the evaluation reads ONE copy of the CFG batch's identical halves: `cat([latents] * 2)` (…inpaint.py:1540-1547)
+            # is never materialised (eps(cfg_single=True): x holds the conditional = unconditional rows once)
+            eps = self.denoiser.eps(lat, st["t"], embs=st.get("embs"), cfg_halves=True, cfg_single=True)
+        else:
+            x2 = torch.cat([lat] * 2) if st["cfg"] else lat
+            if st["extra"] is not None:                           # 9-ch inpaint UNet: latents || mask || masked latents
+                x2 = torch.cat([x2, st["extra"]], dim=1)
+            eps = self.denoiser.eps(x2, st["t"], embs=st.get("embs"), cfg_halves=bool(st["cfg"]))
         if st["cfg"]:
             e_u, e_c = eps.chunk(2)
         else:

@@ -55,6 +55,7 @@ class Demo:
         self.captioner = captioner
         self.device = torch.device(device)
         self.last_embedding = None
+        self._runners = {}
 
     def _pipe(self, path):
         if path not in self.pipes:
@@ -81,38 +82,72 @@ class Demo:
             masks = self.mask_generator.generate(image)
         return host.show_anns(masks)
 
+    def _prepare(self, condition_model, input_image, enable_auto_prompt, prompt, a_prompt, n_prompt, num_samples,
+                 image_resolution, detect_resolution, ddim_steps, guess_mode, strength, scale, seed, eta,
+                 prompt_embeds=None, negative_prompt_embeds=None):
+        """Everything `process` does in front of the pipeline call (sam2image.py:122-167): prompt, resize, SAM encode +
+        mask generation + id-map control, seed.  -> (pipeline kwargs, full_segmask, prompt)."""
+        if enable_auto_prompt or (len(prompt) == 0 and prompt_embeds is None):
+            if self.captioner is None:
+                raise ValueError("auto-prompting needs a `captioner` (BLIP2 is outside the hot path)")
+            cap = self.captioner(input_image)
+            prompt = cap + ',' + prompt if len(prompt) > 0 else cap
+        input_image = host.HWC3(input_image)
+        img = host.resize_image(input_image, image_resolution)
+        H, W, _ = img.shape
+        full_segmask, detected_map = self.get_sam_control(host.resize_image(input_image, detect_resolution))
+        control = host.make_control(detected_map, H, W, num_samples, self.device)
+        seed, generator = host.resolve_seed(seed)
+        if prompt_embeds is not None:
+            kw = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        else:
+            kw = dict(prompt=[prompt + ', ' + a_prompt] * 1, negative_prompt=[n_prompt] * 1)
+        # NOTE scale / strength / guess_mode / eta are accepted but NOT forwarded, exactly like the reference
+        # (sam2image.py:168-177): guidance stays at the pipeline default 7.5.
+        # The reference passes num_samples prompts AND num_images_per_prompt=num_samples (sam2image.py:168-177), i.e. it
+        # denoises num_samples^2 images and keeps the first num_samples.  Those are the images of prompt 0 (all
+        # prompts and control images are identical) drawn from the first num_samples rows of the generator's x_T,
+        # which is exactly what ONE prompt x num_samples images produces: same outputs, 1/num_samples of the work.
+        kw.update(num_images_per_prompt=num_samples, num_inference_steps=ddim_steps, generator=generator, height=H, width=W,
+                  controlnet_conditioning_image=control[:1])
+        return kw, full_segmask, prompt
+
     def process(self, condition_model, input_image, enable_auto_prompt, prompt, a_prompt, n_prompt, num_samples,
                 image_resolution, detect_resolution, ddim_steps, guess_mode, strength, scale, seed, eta,
                 prompt_embeds=None, negative_prompt_embeds=None):
-        path = config_dict.get(condition_model, condition_model)
-        pipe = self._pipe(path)
+        pipe = self._pipe(config_dict.get(condition_model, condition_model))
         with torch.no_grad():
-            if enable_auto_prompt or (len(prompt) == 0 and prompt_embeds is None):
-                if self.captioner is None:
-                    raise ValueError("auto-prompting needs a `captioner` (BLIP2 is outside the hot path)")
-                cap = self.captioner(input_image)
-                prompt = cap + ',' + prompt if len(prompt) > 0 else cap
-            input_image = host.HWC3(input_image)
-            img = host.resize_image(input_image, image_resolution)
-            H, W, _ = img.shape
-            full_segmask, detected_map = self.get_sam_control(host.resize_image(input_image, detect_resolution))
-            control = host.make_control(detected_map, H, W, num_samples, self.device)
-            seed, generator = host.resolve_seed(seed)
-            kw = {}
-            if prompt_embeds is not None:
-                kw = dict(prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
-            else:
-                kw = dict(prompt=[prompt + ', ' + a_prompt] * 1, negative_prompt=[n_prompt] * 1)
-            # NOTE scale / strength / guess_mode / eta are accepted but NOT forwarded, exactly like the reference
-            # (sam2image.py:168-177): guidance stays at the pipeline default 7.5.
-            # The reference passes num_samples prompts AND num_images_per_prompt=num_samples (sam2image.py:168-177), i.e. it
-            # denoises num_samples^2 images and keeps the first num_samples.  Those are the images of prompt 0 (all
-            # prompts and control images are identical) drawn from the first num_samples rows of the generator's x_T,
-            # which is exactly what ONE prompt x num_samples images produces: same outputs, 1/num_samples of the work.
-            x_samples = pipe(num_images_per_prompt=num_samples, num_inference_steps=ddim_steps, generator=generator,
-                             height=H, width=W, controlnet_conditioning_image=control[:1], **kw).images
+            kw, full_segmask, prompt = self._prepare(condition_model, input_image, enable_auto_prompt, prompt, a_prompt, n_prompt,
+                                                     num_samples, image_resolution, detect_resolution, ddim_steps, guess_mode,
+                                                     strength, scale, seed, eta, prompt_embeds, negative_prompt_embeds)
+            x_samples = pipe(**kw).images
             results = [x_samples[i] for i in range(num_samples)]
         return [full_segmask] + results, prompt
+
+    def process_many(self, requests):
+        """A queue of `process` requests (each a tuple / dict of its arguments) through the software pipeline
+        (serving.PipelinedRunner): SAM encode + mask generation + control of request i+1 and the VAE decode of request
+        i-1 are issued on a side stream underneath the denoising loop of request i.  Returns `process`' return value per
+        request, in order -- the same values `process` gives one request at a time."""
+        from .serving import PipelinedRunner
+        reqs = [r if isinstance(r, dict) else dict(zip(self.process.__code__.co_varnames[1:], r)) for r in requests]
+        paths = {config_dict.get(r["condition_model"], r["condition_model"]) for r in reqs}
+        if len(paths) != 1:           # the pipeline overlaps calls of ONE pipeline object
+            return [self.process(**r) for r in reqs]
+        pipe = self._pipe(paths.pop())
+        runner = self._runners.get(id(pipe))
+        if runner is None:
+            runner = self._runners[id(pipe)] = PipelinedRunner(pipe)
+        meta = [None] * len(reqs)
+
+        def front(i, r):
+            def make():
+                kw, seg, prompt = self._prepare(**r)
+                meta[i] = (seg, prompt, r["num_samples"])
+                return kw
+            return make
+        outs = runner.run([front(i, r) for i, r in enumerate(reqs)])
+        return [([seg] + [o.images[j] for j in range(n)], prompt) for o, (seg, prompt, n) in zip(outs, meta)]
 
 
 def create_demo(pipe_factory=None, sam_encoder=None, mask_generator=None, captioner=None, device="cuda"):

@@ -20,7 +20,6 @@ MI355X-first data flow (not the reference's NCHW module tree):
   * all 22 (10) time-embedding projections of the ResBlocks are one GEMM per step.
 """
 import math
-import os
 
 import torch
 
@@ -425,18 +424,20 @@ class ControlledDenoiser:
     (text K/V of every attention layer, ControlNet hint features) are prepared once, then `eps(x, t)` is the
     per-step hot function: UNet encoder -> ControlNet (accumulating into the skips) -> UNet decoder."""
 
-    def __init__(self, unet, controlnets=()):
+    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True):
+        """overlap: the ControlNet trunk runs beside the UNet encoder on a second stream (False: one stream, in order).
+        share_cfg_prefix: `eps(cfg_halves=True)` computes the part the two CFG halves share once."""
         self.unet = unet
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
         self.only_mid_control = False
-        self.overlap = os.environ.get("EA_OVERLAP", "1") != "0"   # concurrent streams: batch row groups x (UNet encoder | ControlNet trunk); env: A/B switch (tools/)
+        self.overlap = bool(overlap)   # concurrent streams: batch row groups x (UNet encoder | ControlNet trunk)
         self.cn_overlap = True
         # row groups of one evaluation run as independent stream sets (2 = the uncond / cond halves of a CFG batch).
         # Measured at C2 (network batch 8): 2 groups 357 ms vs 1 group 336 ms per 20 evaluations -- halving M costs the
         # contraction kernels more than the extra overlap returns, so the default stays 1.
         self.split = 1
-        self.share_cfg_prefix = os.environ.get("EA_SHARE_CFG", "1") != "0"      # A/B switch (tools/): eps(cfg_halves=True)
+        self.share_cfg_prefix = bool(share_cfg_prefix)
         self._strm = []
 
     def static_state(self):
@@ -487,7 +488,17 @@ class ControlledDenoiser:
         to step i (`embs=`) instead of re-running five tiny GEMMs inside every step."""
         return [self.unet.time_embedding(timesteps)] + [cn.time_embedding(timesteps) for cn in self.controlnets]
 
-    def eps(self, x, timesteps, embs=None, cfg_halves=False):
+    def will_share_prefix(self, B, embs):
+        """Will `eps(x [B rows], ..., embs, cfg_halves=True)` compute the CFG halves' shared prefix once?  (Then the
+        caller may hand over one copy of the rows: `cfg_single`.)"""
+        per_row = embs is not None and any(e.shape[0] != 1 for e in embs)
+        concurrent = self.overlap and ops.PROFILE is None and self.unet.ref is None
+        split = self.split if (concurrent and not per_row and B % self.split == 0 and B >= 2 * self.split) else 1
+        u = self.unet
+        return self.share_cfg_prefix and split == 1 and B % 2 == 0 and embs is not None and not per_row \
+            and u.ref is None and u.shares_cfg_prefix() and all(cn.shares_cfg_prefix() for cn in self.controlnets)
+
+    def eps(self, x, timesteps, embs=None, cfg_halves=False, cfg_single=False):
         """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32.  `embs`: optional precomputed
         `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch).
 
@@ -507,27 +518,29 @@ class ControlledDenoiser:
         latency, and independent launch sequences pack into each other's gaps.  Every branch forks from and joins the
         caller's stream only (edges between two forked streams crash hipStreamEndCapture on ROCm 7.2), so the same
         code runs eagerly and inside the HIP-graph capture of a step."""
-        B = x.shape[0]
+        B = timesteps.shape[0] if cfg_single else x.shape[0]
         per_row = embs is not None and any(e.shape[0] != 1 for e in embs)
         concurrent = self.overlap and ops.PROFILE is None and self.unet.ref is None     # reference-only passes: in order
         split = self.split if (concurrent and not per_row and B % self.split == 0 and B >= 2 * self.split) else 1
         n = B // split
         u = self.unet
-        shared = bool(cfg_halves) and self.share_cfg_prefix and split == 1 and B % 2 == 0 and embs is not None and not per_row \
-            and u.ref is None and u.shares_cfg_prefix() and all(cn.shares_cfg_prefix() for cn in self.controlnets)
+        shared = bool(cfg_halves) and self.will_share_prefix(B, embs)
+        if cfg_single and not shared:
+            raise ValueError("cfg_single needs the shared-prefix evaluation (ask will_share_prefix first)")
         half = slice(0, B // 2)
         ctx = []
         for g in range(split):
             rows = slice(g * n, (g + 1) * n)
-            xg, tg = x[rows], timesteps[rows]
-            c = dict(xin=u.to_nhwc(xg[half] if shared else xg), emb_u=u.time_embedding(tg) if embs is None else embs[0],
+            xg, tg = (x if cfg_single else x[rows]), timesteps[rows]
+            half_x = slice(None) if cfg_single else half
+            c = dict(xin=u.to_nhwc(xg[half_x] if shared else xg), emb_u=u.time_embedding(tg) if embs is None else embs[0],
                      kv_u=[kv[rows] for kv in self.kv_u], jobs=[])
             for i, (cn, kv, gh, sc) in enumerate(zip(self.controlnets, self.kv_c, self.hints, self.control_scales)):
                 if gh is None:
                     continue
                 emb_c = cn.time_embedding(tg) if embs is None else embs[1 + i]
                 x_cn = c["xin"] if cn.cfg["in_channels"] == u.cfg["in_channels"] else \
-                    cn.to_nhwc((xg[half] if shared else xg)[:, :cn.cfg["in_channels"]])
+                    cn.to_nhwc((xg[half_x] if shared else xg)[:, :cn.cfg["in_channels"]])
                 if self.only_mid_control:
                     sc = [0.0] * (len(sc) - 1) + [sc[-1]]
                 per = [s.numel() // gh.shape[0] if torch.is_tensor(s) else 0 for s in sc]

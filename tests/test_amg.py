@@ -261,6 +261,46 @@ def test_device_id_map_equals_show_anns_of_the_records(device_decoder):
 
 
 @gpu
+def test_process_many_equals_process_one_at_a_time():
+    """`Demo.process_many` (requests software-pipelined over two streams, SAM + AMG + control of request i+1 issued by the side
+    thread under the loop of request i) returns, request by request, exactly what `Demo.process` returns."""
+    from editanything_amd import sam2image
+    from editanything_amd.amg import SamAutomaticMaskGenerator, SamPromptDecoder
+    from editanything_amd.pipeline import StableDiffusionControlNetPipeline
+    from editanything_amd.sam import ImageEncoderViT
+    from editanything_amd.scheduler import DDIMScheduler
+    from editanything_amd.unet import ControlledUnetModel, ControlNet
+    from editanything_amd.vae import AutoencoderKL
+    dev = "cuda"
+    scfg = dict(arch.TINY_SAM, out_chans=256)
+    enc = ImageEncoderViT(scfg, synth.synth_state_dict_torch(arch.sam_encoder_param_shapes(scfg), SEED + 3), dev)
+    dec = SamPromptDecoder(decoder_sd(), dev, img_size=scfg["img_size"])
+    gen = SamAutomaticMaskGenerator(enc, dec, points_per_side=4, points_per_batch=8, pred_iou_thresh=-1e9, stability_score_thresh=-1.0,
+                                    stability_score_offset=0.002, box_nms_thresh=2.0)
+    cn = ControlNet(arch.TINY_CONTROLNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.TINY_CONTROLNET, True), SEED), dev)
+    un = ControlledUnetModel(arch.TINY_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.TINY_UNET), SEED + 1), dev)
+    vae = AutoencoderKL(arch.TINY_VAE, synth.synth_state_dict_torch(arch.vae_param_shapes(arch.TINY_VAE), SEED + 2), dev)
+    demo = sam2image.create_demo(lambda path: StableDiffusionControlNetPipeline(vae, un, cn, DDIMScheduler(), device=dev),
+                                 sam_encoder=None, mask_generator=gen, device=dev)
+    rng = np.random.default_rng(6)
+    g = torch.Generator().manual_seed(2)
+    reqs = []
+    for r in range(4):
+        img = rng.integers(0, 256, size=(8, 8, 3)).astype(np.uint8).repeat(16, 0).repeat(16, 1)
+        pe = torch.randn(1, 77, arch.TINY_UNET["context_dim"], generator=g)
+        ne = torch.randn(1, 77, arch.TINY_UNET["context_dim"], generator=g)
+        reqs.append(("x", img, False, "a photo", "best quality", "blurry", 2, 128, 128, 4, False, 1.0, 9.0, 3 + r, 0.0, pe, ne))
+    want = [demo.process(*r) for r in reqs]
+    for _ in range(2):
+        got = demo.process_many(reqs)
+        assert len(got) == len(want)
+        for (go, gp), (wo, wp) in zip(got, want):
+            assert gp == wp and len(go) == len(wo) == 3
+            for a, b in zip(go, wo):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@gpu
 def test_process_outputs_vs_oracle_chain():
     """`sam2image.process()` (sam2image.py:122-180) against the oracle chained the same way, same seed:
       stage A  image -> SAM encoder -> prompt / mask decoder -> AMG records: every oracle record has a device record from
