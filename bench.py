@@ -313,6 +313,7 @@ def main():
     if rank == 0 and not args.quick:
         result["calibration"] = calibration(dev)
     if world == 1 and not args.no_extras and not args.quick:
+        result.update(other_configs(args, dev, sds, pipe, sam))
         result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases, runner))
     if rank == 0:
         result["roofline"] = None if args.quick else roofline_leg(one_step, pipe, args)
@@ -480,6 +481,124 @@ def extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, 
     del enc32
     print(json.dumps(dict(out["with_amg"], n_gpus=1, steps=args.steps, higher_is_better=True, data="synthetic", dtype="f16")),
           file=sys.stderr, flush=True)
+    return out
+
+
+def contraction_summary(step_fn, pipes):
+    """Contraction roofline of an arbitrary step (the extras): the step run eagerly on one stream with a HIP event pair
+    around every MFMA contraction launch -> achieved TFLOP/s, fraction of the fp16 peak, launches."""
+    from editanything_amd import ops
+    saved = [p.use_graph for p in pipes]
+    try:
+        for p in pipes:
+            p.use_graph = False
+        step_fn()
+        torch.cuda.synchronize()
+        ops.PROFILE = []
+        step_fn()
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+    finally:
+        ops.PROFILE = None
+        for p, u in zip(pipes, saved):
+            p.use_graph = u
+    mm = [r for r in recs if r[3].startswith(("gemm", "conv"))]
+    tot_f, tot_t = sum(r[0] for r in mm), sum(r[1].elapsed_time(r[2]) for r in mm) * 1e-3
+    return {"achieved_tflops": round(tot_f / tot_t / 1e12, 1), "roofline_frac": round(tot_f / tot_t / 1e12 / PEAK_FP16_TFLOPS, 4),
+            "contraction_launches": len(mm), "contraction_ms": round(tot_t * 1e3, 2)}
+
+
+def other_configs(args, dev, sds, pipe, sam):
+    """BASELINE.json configs 4 and 5 at their per-GPU shape (bs 1 per GPU), beside the headline:
+
+    c4  editany_lora path (editany_lora.py:611-938): SAM ViT-H encode of one image -> SD1.5 + TWO ControlNets (SAM id map +
+        inpaint condition, MultiControlNet) alpha-weight mixing inpaint at 768^2, 20 DDIM steps, CFG -> tile-ControlNet
+        refinement of the result at 768^2, 20 steps, CFG (the stage the reference itself labels "slow inference").
+    c5  SAM ViT-H encode + SD2.1 ControlNet inpaint at 1024^2 (128 x 128 latents, 16384-token self-attention), 50 DDIM steps.
+    Synthetic weights of the exact architectures, inputs resident in HBM, decoded images stay on the device."""
+    from editanything_amd import arch, models, synth
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintMixingPipeline, StableDiffusionControlNetInpaintPipeline
+    from editanything_amd.scheduler import DDIMScheduler
+    from editanything_amd.unet import ControlledUnetModel, ControlNet
+    out = {}
+    rng = np.random.default_rng(args.seed + 77)
+    g = torch.Generator("cpu").manual_seed(args.seed + 78)
+
+    def sam_encode(img_u8):
+        x = torch.nn.functional.interpolate(img_u8.permute(0, 3, 1, 2).float(), size=(1024, 1024), mode="bilinear", align_corners=False)
+        x = (x - sam.mean) / sam.std
+        return sam.forward(x) if args.no_graph else sam.forward_graph(x)
+
+    def idmap_control(res):
+        ids = rng.integers(0, 300, size=(res // 32, res // 32)).repeat(32, 0).repeat(32, 1)
+        c = np.zeros((1, 3, res, res), np.float32)
+        c[0, 0], c[0, 1] = ids % 256, ids // 256
+        return torch.from_numpy(c).to(dev)
+
+    def timed(fn, reps=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def device_decode(p):
+        p.decode_latents = lambda lat: (p.vae.decode_nhwc(lat / p.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
+    # ---- c5: the headline networks at 1024^2, 50 steps, one image
+    res = 1024
+    img5 = torch.from_numpy(rng.integers(0, 256, size=(1, 32, 32, 3)).astype(np.uint8).repeat(res // 32, 1).repeat(res // 32, 2)).to(dev)
+    init5 = img5.permute(0, 3, 1, 2).float() / 127.5 - 1.0
+    mask5 = torch.zeros(1, 1, res, res, device=dev)
+    mask5[:, :, res // 4:3 * res // 4, res // 4:3 * res // 4] = 1.0
+    ctrl5 = idmap_control(res)
+    e5, n5 = (torch.randn(1, 77, 1024, generator=g) * 0.5).to(dev), (torch.randn(1, 77, 1024, generator=g) * 0.5).to(dev)
+
+    def step5():
+        emb = sam_encode(img5)
+        gen = torch.Generator("cpu").manual_seed(args.seed + 5)
+        return emb, pipe(prompt_embeds=e5, negative_prompt_embeds=n5, image=init5, mask_image=mask5, controlnet_conditioning_image=ctrl5,
+                         height=res, width=res, num_inference_steps=50, guidance_scale=7.5, num_images_per_prompt=1, generator=gen,
+                         output_type="np_device")
+    t5 = timed(step5)
+    out["c5"] = dict({"metric": "1024^2 images/s per GPU: SAM vit_h encode + SD2.1 ControlNet inpaint, 128 x 128 latents, 50 DDIM steps, CFG 7.5, bs 1",
+                      "value": round(1.0 / t5, 4), "unit": "images/s", "ms_per_step": round(t5 * 1e3, 2)},
+                     **contraction_summary(step5, [pipe]))
+    # ---- c4: SD1.5, two ControlNets + tile refinement, 768^2
+    res = 768
+    un = ControlledUnetModel(arch.SD15_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_UNET), args.seed + 31), dev)
+    cns = [ControlNet(arch.SD15_CONTROLNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_CONTROLNET, True), args.seed + 32 + i), dev)
+           for i in range(3)]
+    pipe_a = StableDiffusionControlNetInpaintMixingPipeline(pipe.vae, un, cns[:2], DDIMScheduler(), device=dev, use_graph=not args.no_graph)
+    pipe_t = StableDiffusionControlNetInpaintPipeline(pipe.vae, un, cns[2], DDIMScheduler(), device=dev, use_graph=not args.no_graph)
+    device_decode(pipe_a)
+    device_decode(pipe_t)
+    img4 = torch.from_numpy(rng.integers(0, 256, size=(1, 24, 24, 3)).astype(np.uint8).repeat(32, 1).repeat(32, 2)).to(dev)
+    init4 = img4.permute(0, 3, 1, 2).float() / 127.5 - 1.0
+    mask4 = torch.zeros(1, 1, res, res, device=dev)
+    mask4[:, :, res // 4:3 * res // 4, res // 4:3 * res // 4] = 1.0
+    ctrl4 = idmap_control(res)
+    inp_cond = torch.where(mask4.expand(-1, 3, -1, -1) > 0.5, torch.full_like(init4, -1.0), img4.permute(0, 3, 1, 2).float() / 255.0)   # make_inpaint_condition
+    e4, n4 = (torch.randn(1, 77, 768, generator=g) * 0.5).to(dev), (torch.randn(1, 77, 768, generator=g) * 0.5).to(dev)
+
+    def step4():
+        emb = sam_encode(img4)
+        gen = torch.Generator("cpu").manual_seed(args.seed + 4)
+        a = pipe_a(prompt_embeds=e4, negative_prompt_embeds=n4, image=init4, mask_image=mask4, controlnet_conditioning_image=[ctrl4, inp_cond],
+                   controlnet_conditioning_scale=[1.0, 1.0], height=res, width=res, num_inference_steps=20, guidance_scale=7.5,
+                   num_images_per_prompt=1, generator=gen, alpha_weight=0.5, alignment_ratio=0.95, output_type="np_device").images
+        tile = a.permute(0, 3, 1, 2).contiguous()                      # decoded NHWC [0, 1] -> the tile stage's image / control
+        b = pipe_t(prompt_embeds=e4, negative_prompt_embeds=n4, image=tile * 2 - 1, mask_image=mask4, controlnet_conditioning_image=tile,
+                   controlnet_conditioning_scale=1.0, height=res, width=res, num_inference_steps=20, guidance_scale=7.5,
+                   num_images_per_prompt=1, generator=gen, output_type="np_device")
+        return emb, b
+    t4 = timed(step4)
+    out["c4"] = dict({"metric": "768^2 images/s per GPU: SAM vit_h encode + SD1.5 two-ControlNet mixing inpaint (20 steps) + tile-ControlNet refinement (20 steps), CFG 7.5, bs 1",
+                      "value": round(1.0 / t4, 4), "unit": "images/s", "ms_per_step": round(t4 * 1e3, 2)},
+                     **contraction_summary(step4, [pipe_a, pipe_t]))
+    del pipe_a, pipe_t, un, cns
+    torch.cuda.empty_cache()
     return out
 
 

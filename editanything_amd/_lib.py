@@ -69,6 +69,9 @@ SIGNATURES = {
     "ea_groupnorm_apply_f16": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "ea_gemm_f16": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _ll, _ll, _ll, _ll, C.POINTER(Epilogue), _vp, _sz, _vp]),
     "ea_conv2d_f16": (_i, [C.POINTER(ConvSrc), _vp, _i, C.POINTER(Epilogue), _vp, _sz, _vp]),
+    "ea_gemm_f16_pair": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.POINTER(Epilogue), C.POINTER(Epilogue), _vp, _sz, _vp]),
+    "ea_conv2d_f16_pair": (_i, [C.POINTER(ConvSrc), C.POINTER(ConvSrc), _vp, _vp, _i, C.POINTER(Epilogue), C.POINTER(Epilogue),
+                                _vp, _sz, _vp]),
     "ea_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_groupnorm_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ea_groupnorm_silu_conv3x3": (_i, [C.POINTER(ConvSrc), _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(Epilogue),

@@ -12,7 +12,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["ea_gemm.hip", "ea_norm.hip", "ea_attn.hip", "ea_elem.hip", "ea_sam.hip"]
-HEADERS = ["ea_platform.h", "ea_gemm.h", "ea_gemm2.h", "ea_gemm3.h", "ea_prims.h", "ea_epi_tr.h", os.path.join(ROOT, "include", "editanything_hip.h")]
+HEADERS = ["ea_platform.h", "ea_gemm.h", "ea_gemm2.h", "ea_prims.h", "ea_epi_tr.h", os.path.join(ROOT, "include", "editanything_hip.h")]
+# experiment kernels compiled into the tools / emulation builds only (-DEA_TOOLS=1)
+TOOLS_HEADERS = [os.path.join(ROOT, "tools", "kernels", "ea_gemm3.h")]
 LIB = os.path.join(HERE, "libeditanything_hip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libeditanything_emu.so")
@@ -65,10 +67,10 @@ def build_emu(force=False, verbose=True):
     srcs = [os.path.join(HERE, s) for s in SOURCES]
     emu_srcs = [os.path.join(EMU_DIR, "hip_emu.cpp")]
     deps = srcs + emu_srcs + [os.path.join(EMU_DIR, "hip_emu.h")] + \
-        [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS] + [os.path.abspath(__file__)]
+        [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS] + TOOLS_HEADERS + [os.path.abspath(__file__)]
     if not force and not _newer(EMU_LIB, deps):
         return EMU_LIB
-    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-DEA_TOOLS=1", "-DEA_ATTN_EXP=2", "-I", EMU_DIR, "-I", HERE,
+    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-DEA_TOOLS=1", "-I", EMU_DIR, "-I", HERE,
            "-Wno-unknown-attributes", "-Wno-unused-value", "-o", EMU_LIB]
     for s in srcs:
         cmd += ["-x", "c++", s]
@@ -78,6 +80,26 @@ def build_emu(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return EMU_LIB
+
+
+def build_emu_attn_exp(force=False, verbose=True):
+    """TEST INFRASTRUCTURE: the attention kernels alone with the round-3 experiment compiled in (-DEA_ATTN_EXP=2: two query
+    groups per wave, measured slower on the MI355X and not shipped) -- its own emulation library, so that the main
+    emulation build dispatches exactly as the product does."""
+    lib = os.path.join(EMU_DIR, "libeditanything_emu_attn_exp2.so")
+    srcs = [os.path.join(HERE, "ea_attn.hip"), os.path.join(EMU_DIR, "hip_emu.cpp")]
+    deps = srcs + [os.path.join(EMU_DIR, "hip_emu.h"), os.path.join(HERE, "ea_platform.h"), os.path.join(HERE, "ea_prims.h"),
+                   os.path.abspath(__file__)]
+    if not force and not _newer(lib, deps):
+        return lib
+    cmd = [_host_cxx(), "-O1", "-std=c++17", "-fPIC", "-shared", "-DEA_EMU", "-DEA_TOOLS=1", "-DEA_ATTN_EXP=2", "-I", EMU_DIR, "-I", HERE,
+           "-Wno-unknown-attributes", "-Wno-unused-value", "-o", lib]
+    for s in srcs:
+        cmd += ["-x", "c++", s]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return lib
 
 
 if __name__ == "__main__":

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void ea_gemm_kernel(EaGemmParams p) {
 }
 
 // Reduce split-K partials and run the epilogue.  One thread per 8 outputs.
-__global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
+__device__ __forceinline__ void ea_splitk_reduce_body(const EaGemmParams& p) {
   const long long vec_per_row = (p.N + 7) / 8;
   const long long total = (long long)p.batch * p.M * vec_per_row;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -522,6 +522,13 @@ __global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
   }
 }
 
+__global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) { ea_splitk_reduce_body(p); }
+// the reductions of a twin launch (ea_gemm2_pair_kernel) as one grid: blockIdx.y = problem
+__global__ __launch_bounds__(256) void ea_splitk_reduce_pair_kernel(EaGemmParams p0, EaGemmParams p1) {
+  const EaGemmParams& p = blockIdx.y ? p1 : p0;
+  ea_splitk_reduce_body(p);
+}
+
 // Split-K reduction + the GroupNorm (+ SiLU) that consumes the result, one workgroup per (sample, group): the slab
 // [gn_hw rows x gn_cpg channels] is summed over the slices in 4-channel pieces (<= MAXQ per thread, kept in registers as the
 // ROUNDED fp16 values the output holds), its statistics are reduced over the workgroup, and both the output and its
@@ -533,7 +540,7 @@ __global__ __launch_bounds__(256) void ea_splitk_reduce_kernel(EaGemmParams p) {
 // half a CU's registers: 1024 x 1 piece (<= 64 registers) and 512 x 5 pieces (<= 128).
 constexpr int EA_RGN_MAXQ = 5;
 template <int MAXQ>
-__global__ __launch_bounds__(MAXQ == 1 ? 1024 : 512) void ea_splitk_reduce_gn_kernel(EaGemmParams p) {
+__device__ __forceinline__ void ea_splitk_reduce_gn_body(const EaGemmParams& p) {
   constexpr int EA_RGN_THREADS = MAXQ == 1 ? 1024 : 512;
   EA_SMEM(smem);
   float (*red)[16] = reinterpret_cast<float (*)[16]>(smem);    // [2][16]
@@ -633,6 +640,15 @@ __global__ __launch_bounds__(MAXQ == 1 ? 1024 : 512) void ea_splitk_reduce_gn_ke
       *reinterpret_cast<f16x4*>(e.gn_next_out + (long long)mrow[u] * e.ldc + col[u]) = y;
     }
   }
+}
+
+template <int MAXQ>
+__global__ __launch_bounds__(MAXQ == 1 ? 1024 : 512) void ea_splitk_reduce_gn_kernel(EaGemmParams p) { ea_splitk_reduce_gn_body<MAXQ>(p); }
+// twin form: blockIdx.z = problem
+template <int MAXQ>
+__global__ __launch_bounds__(MAXQ == 1 ? 1024 : 512) void ea_splitk_reduce_gn_pair_kernel(EaGemmParams p0, EaGemmParams p1) {
+  const EaGemmParams& p = blockIdx.z ? p1 : p0;
+  ea_splitk_reduce_gn_body<MAXQ>(p);
 }
 
 // Row statistics of a finished fp16 [M][ld] output, in the layout the register-direct epilogue writes

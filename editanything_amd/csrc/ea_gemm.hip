@@ -1,6 +1,11 @@
 // ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
 #include "ea_gemm2.h"
-#include "ea_gemm3.h"
+#ifndef EA_TOOLS
+#define EA_TOOLS 0
+#endif
+#if EA_TOOLS
+#include "../../tools/kernels/ea_gemm3.h"   // the persistent-kernel experiment of round 3 (measured slower; tools build only)
+#endif
 #include <stdlib.h>
 #include "../../include/editanything_hip.h"
 
@@ -243,15 +248,6 @@ static bool gn_next_epi_ok(const EaGemmParams& p) {
          (!e.rowvec || (e.rowvec_ld & 3) == 0) &&
          ((((uintptr_t)e.out) | ((uintptr_t)e.residual)) & 7) == 0 && ((((uintptr_t)e.bias) | ((uintptr_t)e.rowvec)) & 15) == 0;
 }
-static int launch_reduce_gn(EaGemmParams& p, void* stream) {
-  const EaEpilogue& e = p.epi;
-  const long long nq = (long long)e.gn_hw * (e.gn_cpg >> 2);
-  dim3 grid((unsigned)(p.N / e.gn_cpg), (unsigned)(p.M / e.gn_hw), 1);
-  if (nq <= 1024) { auto k = ea_splitk_reduce_gn_kernel<1>; EA_LAUNCH(k, grid, dim3(1024), 128, stream, p); }
-  else { auto k = ea_splitk_reduce_gn_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(512), 128, stream, p); }
-  return ea_launch_status();
-}
-
 // fallback producer of the output row statistics (launches whose epilogue could not write them)
 static int launch_row_stats(EaGemmParams& p, void* stream) {
   const EaEpilogue& e = p.epi;
@@ -262,6 +258,7 @@ static int launch_row_stats(EaGemmParams& p, void* stream) {
   return ea_launch_status();
 }
 
+#if EA_TOOLS
 // ---- ea_gemm3.h: the persistent 8-wave kernel.  Number of workgroups = CUs of the device (one resident per CU).
 static int cu_count() {
 #ifdef EA_EMU
@@ -308,7 +305,7 @@ static int plan3_splits(int tiles, int nk, long long MN, int allow_split) {
 static Plan3 plan3(const EaGemmParams& p, int want) {
   Plan3 t{};
   const EaEpilogue& e = p.epi;
-  if (want == 0) return t;                      // automatic policy: see plan3_auto()
+  if (want == 0) return t;                      // never chosen automatically: opt-in through ea_set_tuning variants 20-23
   if (p.batch != 1 || g_no_tr) return t;
   const bool geglu = e.act == EA_ACT_GEGLU;
   if (geglu && e.geglu_block != 32) return t;
@@ -397,12 +394,26 @@ static int launch_fast3(EaGemmParams& p, const Plan3& t, void* workspace, size_t
   return st;
 }
 
-static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
-  {
-    const Plan3 t3 = plan3(p, (g_variant >= 20 && g_variant <= 23) ? g_variant : 0);
-    if (t3.use) return launch_fast3(p, t3, workspace, ws_bytes, stream);
-    if (g_variant >= 20 && g_variant <= 23) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
-  }
+#endif  // EA_TOOLS
+
+// ---- the LDS-DMA kernel (ea_gemm2.h): selection and issue are separate steps so that TWO problems that select the same
+// launch (twins: ea_gemm_f16_pair / ea_conv2d_f16_pair) can be issued as one grid.
+struct FastSel {
+  Plan2 t;        // tile plan: instantiation kind, tile shape, tiles, split-K
+  int tr;         // register-direct epilogue instantiation (0: the LDS-slab epilogue kernels)
+  int tr_raw;     // split-K slices dumped raw by the register-direct epilogue
+  int lnx;        // TR = 2: LayerNorm fold / row statistics / GroupNorm partials compiled in
+  int reduce_gn;  // the split-K reduction applies the consuming GroupNorm
+};
+
+static bool same_launch(const FastSel& a, const FastSel& b) {
+  return a.t.kind == b.t.kind && a.t.bm == b.t.bm && a.t.bn == b.t.bn && a.t.tiles == b.t.tiles && a.t.splits == b.t.splits &&
+         a.t.ktiles_per_split == b.t.ktiles_per_split && a.tr == b.tr && a.tr_raw == b.tr_raw && a.lnx == b.lnx && a.reduce_gn == b.reduce_gn;
+}
+
+// Plans the launch of p: fills the plan-dependent fields of p (split-K, partial buffer at workspace + ws_off, epilogue
+// form, tile order) and `s`.
+static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t ws_off, FastSel& s) {
   Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
@@ -410,17 +421,17 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   p.debug = EA_TOOLS ? g_tune.debug : 0;
   if (t.splits > 1) {
     const size_t need = (size_t)p.batch * t.splits * p.M * p.N * sizeof(float);
-    if (!workspace || ws_bytes < need) return EA_ERR_WORKSPACE;
-    p.partial = (float*)workspace;
+    if (!workspace || ws_bytes < ws_off + need) return EA_ERR_WORKSPACE;
+    p.partial = (float*)((char*)workspace + ws_off);
   } else if (p.debug == 3) {   // phase-timestamp dump (tools/phase_times.py): 8 x u64 per workgroup
-    if (!workspace || ws_bytes < (size_t)t.tiles * p.batch * 64) return EA_ERR_WORKSPACE;
-    p.partial = (float*)workspace;
+    if (!workspace || ws_bytes < ws_off + (size_t)t.tiles * p.batch * 64) return EA_ERR_WORKSPACE;
+    p.partial = (float*)((char*)workspace + ws_off);
   }
   // streamlined epilogue (ea_gemm2.h): every per-output option it does not implement must be off, offsets must fit
   // 32 bits, rows of a workgroup tile must share one row-vector group
+  const EaEpilogue& e = p.epi;
+  const long long span = (long long)p.M * e.ldc + e.N;
   {
-    const EaEpilogue& e = p.epi;
-    const long long span = (long long)p.M * e.ldc + e.N;
     bool ok = t.splits == 1 && !e.out_f32 && !e.residual32 && !e.row_scale && !e.bias_per_row && e.act != EA_ACT_GEGLU &&
               (e.N & 7) == 0 && (e.ldc & 7) == 0 && (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 &&
               span < 0x7fffffffLL && p.debug != 9;
@@ -451,15 +462,6 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     // projection, whose 1.6-MB weight is L2 resident, LOSES 6 % and keeps the row-major order)
     if (!(EA_TOOLS && g_tune.debug == 20) && tiles_n > 8 && tiles_m >= 16 && (long long)p.N * p.K * 2 > (3ll << 20)) p.raster_gm = 8;   // debug 20: row-major everywhere (A/B)
   }
-  dim3 grid(t.tiles, 1, p.batch * t.splits);
-#define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
-  do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_>;               \
-    const int smem = ST_ * (BM_ + BN_) * 128;                                         \
-    ea_allow_big_lds(kfn, smem);                                                      \
-    EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64 * (1 + LD_), 1, 1), smem, stream, p);    \
-  } while (0)
-#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
   const bool tr_kind = t.kind == 1 || t.kind == 9 || (EA_TOOLS && t.kind == 24);
@@ -474,22 +476,71 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   // ... and so do the GroupNorm partials (callers ask ea_gemm_gn_stats_chunk_rows first)
   if (p.epi.gn_stats_out && (!tr || t.splits > 1 || p.epi_fast != 1 || p.batch != 1 || !gn_stats_rows(t, p.M, p.N, p.epi.gn_hw, p.epi.gn_cpg)))
     return EA_ERR_UNSUPPORTED;
+  s.t = t;
+  s.tr = tr ? 1 : 0;
+  s.tr_raw = tr_raw ? 1 : 0;
+  s.lnx = (tr && (p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1))) ? 1 : 0;   // fold / statistics compiled in
+  s.reduce_gn = p.epi.gn_next_out ? 1 : 0;
+  return EA_OK;
+}
+
+// split-K reduction (+ the consuming GroupNorm) of p, or of the twins p and q as one grid
+static int issue_reduce(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* stream) {
+  if (s.reduce_gn) {
+    const EaEpilogue& e = p.epi;
+    const long long nq = (long long)e.gn_hw * (e.gn_cpg >> 2);
+    dim3 grid((unsigned)(p.N / e.gn_cpg), (unsigned)(p.M / e.gn_hw), q ? 2 : 1);
+    if (!q) {
+      if (nq <= 1024) { auto k = ea_splitk_reduce_gn_kernel<1>; EA_LAUNCH(k, grid, dim3(1024), 128, stream, p); }
+      else { auto k = ea_splitk_reduce_gn_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(512), 128, stream, p); }
+    } else {
+      if (nq <= 1024) { auto k = ea_splitk_reduce_gn_pair_kernel<1>; EA_LAUNCH(k, grid, dim3(1024), 128, stream, p, *q); }
+      else { auto k = ea_splitk_reduce_gn_pair_kernel<EA_RGN_MAXQ>; EA_LAUNCH(k, grid, dim3(512), 128, stream, p, *q); }
+    }
+    return ea_launch_status();
+  }
+  const long long total = (long long)p.batch * p.M * ((p.N + 7) / 8);
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (!q) { auto rfn = ea_splitk_reduce_kernel; EA_LAUNCH(rfn, dim3((unsigned)nb), dim3(256), 0, stream, p); }
+  else { auto rfn = ea_splitk_reduce_pair_kernel; EA_LAUNCH(rfn, dim3((unsigned)nb, 2, 1), dim3(256), 0, stream, p, *q); }
+  return ea_launch_status();
+}
+
+// Issues the launch fast_select planned for p -- and for its twin q (same FastSel: same instantiation, grid and LDS) in the
+// same grid, blockIdx.y = problem.  Twins exist for the register-direct instantiations of the two planned tile heights.
+static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* stream) {
+  const Plan2& t = s.t;
+  dim3 grid(t.tiles, q ? 2 : 1, p.batch * t.splits);
+#define EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_)                             \
+  do {                                                                                \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, WM_, WN_, ST_, MT_, IL_, LD_>;               \
+    const int smem = ST_ * (BM_ + BN_) * 128;                                         \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64 * (1 + LD_), 1, 1), smem, stream, p);    \
+  } while (0)
+#define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
 #define EA_LAUNCH_TR(BM_, BN_, TR_)                                                   \
   do {                                                                                \
-    auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, TR_>;                     \
     const int smem = 2 * (BM_ + BN_) * 128;                                           \
-    ea_allow_big_lds(kfn, smem);                                                      \
-    EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                           \
+    if (!q) {                                                                         \
+      auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, TR_>;                   \
+      ea_allow_big_lds(kfn, smem);                                                    \
+      EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                         \
+    } else {                                                                          \
+      auto kfn = ea_gemm2_pair_kernel<BM_, BN_, 2, 2, 2, 16, 0, 0, TR_>;              \
+      ea_allow_big_lds(kfn, smem);                                                    \
+      EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p, *q);                     \
+    }                                                                                 \
   } while (0)
-  if (tr) {
-    const bool lnx = p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1);   // fold / statistics compiled in
+  if (s.tr) {
 #if EA_TOOLS
     // kind 24 (experiment, round 3): ONE 8-wave workgroup per CU on a 256-row tile -- the two co-resident 128-row workgroups
     // merged, the weight panel fetched once for both halves (22 % fewer operand bytes from L2); same wave tiles, same
     // epilogue.  Measured 3-10 % SLOWER than the two independent workgroups on every level-0 / SAM class
     // (profiles/r03_kind24_merged_workgroups.jsonl): operand traffic is not what bounds the loop
     if (t.kind == 24) {
-      if (lnx) return EA_ERR_UNSUPPORTED;
+      if (s.lnx || q) return EA_ERR_UNSUPPORTED;
       if (t.bn == 160) {
         auto kfn = ea_gemm2_kernel<256, 160, 4, 2, 2, 16, 0, 0, 1>;
         const int smem = 2 * (256 + 160) * 128;
@@ -504,20 +555,22 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
     } else
 #endif
     if (t.kind == 1) {
-      if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
-      else { if (lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
+      if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
+      else { if (s.lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
     } else {
-      if (t.bn == 160) { if (lnx) EA_LAUNCH_TR(64, 160, 2); else EA_LAUNCH_TR(64, 160, 1); }
-      else { if (lnx) EA_LAUNCH_TR(64, 128, 2); else EA_LAUNCH_TR(64, 128, 1); }
+      if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR(64, 160, 2); else EA_LAUNCH_TR(64, 160, 1); }
+      else { if (s.lnx) EA_LAUNCH_TR(64, 128, 2); else EA_LAUNCH_TR(64, 128, 1); }
     }
     int st_tr = ea_launch_status();
     if (st_tr == EA_OK && t.splits > 1) {
-      st_tr = p.epi.gn_next_out ? launch_reduce_gn(p, stream) : launch_reduce(p, stream);
+      st_tr = issue_reduce(s, p, q, stream);
       if (st_tr == EA_OK) st_tr = launch_row_stats(p, stream);
+      if (st_tr == EA_OK && q) st_tr = launch_row_stats(*q, stream);
     }
     return st_tr;                  // (unsplit launches: row statistics, if asked for, were written by the epilogue)
   }
 #undef EA_LAUNCH_TR
+  if (q) return EA_ERR_UNSUPPORTED;   // twins run on the register-direct instantiations only (launch_pair checks first)
   switch (t.kind) {
     case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
 #if EA_TOOLS
@@ -542,9 +595,23 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 #undef EA_LAUNCH_G2L
   int st = ea_launch_status();
   if (st != EA_OK) return st;
-  if (t.splits > 1) st = launch_reduce(p, stream);
+  if (t.splits > 1) st = issue_reduce(s, p, nullptr, stream);
   if (st == EA_OK) st = launch_row_stats(p, stream);
   return st;
+}
+
+static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
+#if EA_TOOLS
+  {   // the persistent kernel of tools/kernels/ea_gemm3.h: opt-in (variants 20-23), tools build only
+    const Plan3 t3 = plan3(p, (g_variant >= 20 && g_variant <= 23) ? g_variant : 0);
+    if (t3.use) return launch_fast3(p, t3, workspace, ws_bytes, stream);
+    if (g_variant >= 20 && g_variant <= 23) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
+  }
+#endif
+  FastSel s;
+  const int st = fast_select(p, workspace, ws_bytes, 0, s);
+  if (st != EA_OK) return st;
+  return fast_issue(s, p, nullptr, stream);
 }
 
 static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
@@ -584,6 +651,26 @@ static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
   return st;
 }
 
+// Twins: two problems of one shape.  One grid when both select the same register-direct launch (the ControlNet trunk beside
+// the UNet encoder: always); otherwise -- other instantiations, tools-only variants, scratch too small for two sets of
+// split-K partials -- the two launches go out one after the other on the same stream (and then share the scratch).
+static int launch_pair(EaGemmParams& p, EaGemmParams& q, void* workspace, size_t ws_bytes, void* stream) {
+  read_env();
+  const bool same_shape = p.M == q.M && p.N == q.N && p.K == q.K && p.batch == q.batch && p.conv == q.conv;
+  if (same_shape && !g_force_generic && !(g_variant >= 20 && g_variant <= 23) && fast_eligible(p) && fast_eligible(q)) {
+    FastSel sp, sq;
+    const size_t half = (ws_bytes / 2) & ~(size_t)255;
+    int st = fast_select(p, workspace, half, 0, sp);
+    if (st == EA_OK) st = fast_select(q, workspace, 2 * half, half, sq);
+    if (st == EA_OK && same_launch(sp, sq) && sp.tr && (sp.t.kind == 1 || sp.t.kind == 9) && p.debug == 0 && q.debug == 0)
+      return fast_issue(sp, p, &q, stream);
+    if (st != EA_OK && st != EA_ERR_WORKSPACE) return st;
+  }
+  int st = launch_gemm(p, workspace, ws_bytes, stream);
+  if (st == EA_OK) st = launch_gemm(q, workspace, ws_bytes, stream);
+  return st;
+}
+
 }  // namespace
 
 extern "C" int ea_set_tuning(const ea_tuning* t) {
@@ -611,12 +698,14 @@ static EaGemmParams query_params(int M, int N, int K, int conv, int geglu32) {
 
 extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+#if EA_TOOLS
   if (g_variant >= 20 && g_variant <= 23) {
     EaGemmParams q = query_params(M, N, K, 0, 0);
     static const float dummy = 0.0f;
     q.epi.ln_stats = &dummy;
     return plan3(q, g_variant).use;
   }
+#endif
   Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
   return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
 }
@@ -632,6 +721,7 @@ extern "C" int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sa
 
 extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
+#if EA_TOOLS
   if (g_variant >= 20 && g_variant <= 23) {
     EaGemmParams q = query_params(M, N, K, conv ? 1 : 0, 0);
     static float dummy = 0.0f;
@@ -641,6 +731,7 @@ extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int ro
     const Plan3 t3 = plan3(q, g_variant);
     return t3.use ? t3.gn_rows : 0;
   }
+#endif
   Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
   return gn_stats_rows(t, M, N, rows_per_sample, cpg);
 }
@@ -655,24 +746,28 @@ extern "C" size_t ea_gemm_workspace_bytes(int M, int N, int K, int batch) {
       if (f.splits > splits) splits = f.splits;
     }
   }
-  if (K % EA_BK == 0 && batch == 1 && (N & 3) == 0) {   // the persistent kernel's own split choice
+#if EA_TOOLS
+  if (K % EA_BK == 0 && batch == 1 && (N & 3) == 0 && g_variant >= 20 && g_variant <= 23) {   // the persistent kernel's own split choice, when forced
     const int bn = (N % 160 == 0) ? 160 : 128;
     const int s3 = plan3_splits(((M + 127) / 128) * ((N + bn - 1) / bn), K / EA_BK, (long long)M * N, 1);
     if (s3 > splits) splits = s3;
   }
+#endif
   if (splits <= 1) return 0;
   return (size_t)batch * splits * M * N * sizeof(float);
 }
 
 extern "C" int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
                            long long strideA, long long strideW, long long strideC, long long strideR,
-                           const ea_epilogue* epi, void* workspace, size_t ws_bytes, void* stream) {
+                           const ea_epilogue* epi, void* workspace, size_t ws_bytes, void* stream);
+
+static int setup_gemm(EaGemmParams& p, const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
+                      long long strideA, long long strideW, long long strideC, long long strideR, const ea_epilogue* epi) {
   if (!A || !W) return EA_ERR_BAD_ARG;
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return EA_ERR_BAD_SHAPE;
   if ((K & 7) || (lda & 7) || (ldw & 7) || lda < K || ldw < K) return EA_ERR_BAD_SHAPE;
   if ((strideA & 7) || (strideW & 7)) return EA_ERR_BAD_SHAPE;
   if (((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return EA_ERR_BAD_ARG;
-  EaGemmParams p;
   memset(&p, 0, sizeof(p));
   int st = fill_epilogue(p.epi, epi, M, N);
   if (st != EA_OK) return st;
@@ -684,7 +779,16 @@ extern "C" int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M
   p.M = M; p.N = N; p.K = K;
   p.batch = batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideR = strideR;
-  return launch_gemm(p, workspace, ws_bytes, stream);
+  return EA_OK;
+}
+
+extern "C" int ea_gemm_f16_pair(const void* A0, const void* A1, int lda, const void* W0, const void* W1, int ldw, int M, int N, int K,
+                                const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream) {
+  EaGemmParams p, q;
+  int st = setup_gemm(p, A0, lda, W0, ldw, M, N, K, 1, 0, 0, 0, 0, epi0);
+  if (st == EA_OK) st = setup_gemm(q, A1, lda, W1, ldw, M, N, K, 1, 0, 0, 0, 0, epi1);
+  if (st != EA_OK) return st;
+  return launch_pair(p, q, workspace, ws_bytes, stream);
 }
 
 static int setup_conv(EaGemmParams& p, const ea_conv_src* s, const void* W, int Cout, const ea_epilogue* epi) {
@@ -715,6 +819,24 @@ static int setup_conv(EaGemmParams& p, const ea_conv_src* s, const void* W, int 
   p.M = (int)M; p.N = Cout;
   p.batch = 1;
   return EA_OK;
+}
+
+extern "C" int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
+                           long long strideA, long long strideW, long long strideC, long long strideR,
+                           const ea_epilogue* epi, void* workspace, size_t ws_bytes, void* stream) {
+  EaGemmParams p;
+  int st = setup_gemm(p, A, lda, W, ldw, M, N, K, batch, strideA, strideW, strideC, strideR, epi);
+  if (st != EA_OK) return st;
+  return launch_gemm(p, workspace, ws_bytes, stream);
+}
+
+extern "C" int ea_conv2d_f16_pair(const ea_conv_src* src0, const ea_conv_src* src1, const void* W0, const void* W1, int Cout,
+                                  const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream) {
+  EaGemmParams p, q;
+  int st = setup_conv(p, src0, W0, Cout, epi0);
+  if (st == EA_OK) st = setup_conv(q, src1, W1, Cout, epi1);
+  if (st != EA_OK) return st;
+  return launch_pair(p, q, workspace, ws_bytes, stream);
 }
 
 extern "C" int ea_conv2d_f16(const ea_conv_src* src, const void* W, int Cout, const ea_epilogue* epi,

@@ -53,7 +53,7 @@
 #define EA_STAMP(i)                                                                                   \
   do {                                                                                                \
     if (EA_DBG(3) && tid == 0)                                                                     \
-      reinterpret_cast<unsigned long long*>(p.partial)[(blockIdx.x + gridDim.x * blockIdx.z) * 8 + (i)] = wall_clock64(); \
+      reinterpret_cast<unsigned long long*>(p.partial)[(wg_x + gridDim.x * wg_z) * 8 + (i)] = wall_clock64(); \
   } while (0)
 #endif
 
@@ -80,9 +80,10 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // slab, no scatter / gather passes, no waits between slabs.  Measured with tools/gemm_bench --debug 0,1,2 (round 2): the
 // LDS-slab epilogues cost 25 % of the contraction time of an evaluation (10-54 us per launch; the bare store stream of
 // the same bytes takes 5-15 us, tools/probe_misc).  Same products and the same fp32 summation order as TR = 0.
+// The body is a device function of (problem, workgroup x index, workgroup z index) so that ONE grid can carry the tiles
+// of two problems (ea_gemm2_pair_kernel below).
 template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
-__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
-void ea_gemm2_kernel(EaGemmParams p) {
+__device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int wg_x, const int wg_z) {
   constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR);
   static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && STAGES == 2), "register-direct epilogue: the 2-stage 16x16x32 tiles");
   static_assert(!LDR || !ILV, "loader waves replace the interleaved issue");
@@ -107,7 +108,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
   EA_STAMP(0);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
-  const int tile = ea_xcd_remap(blockIdx.x, ntile);
+  const int tile = ea_xcd_remap(wg_x, ntile);
   // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
   // (K position, descriptors, scalar offsets) stays in SGPRs -- otherwise every DMA is wrapped in a waterfall loop (T20)
   int tm = ea_uniform(tile / tiles_n), tn = tile - tm * tiles_n;
@@ -118,7 +119,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     tn = ea_uniform(tn);
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int bz = blockIdx.z;
+  const int bz = wg_z;
   const int batch = ea_uniform(bz / p.splits), split = bz - batch * p.splits;
 
   const int nk_total = p.K / EA_BK;
@@ -434,7 +435,7 @@ void ea_gemm2_kernel(EaGemmParams p) {
     // for the texture path, then both for the matrix pipe).  Workgroups b and b + 256 normally share a CU (dispatch
     // is round-robin over XCDs, then CUs): delaying the second one by ~half an iteration lets them alternate
     // (measured +8..12 % on the 512-tile 64x64-level convolutions; a speed heuristic only, never correctness).
-    if (!EA_DBG(8) && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
+    if (!EA_DBG(8) && ((wg_x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
 #endif
     for (int kt = 0; kt < nk; ++kt) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
@@ -1020,4 +1021,23 @@ void ea_gemm2_kernel(EaGemmParams p) {
     if (slab == 0) EA_STAMP(6);
   }
   EA_STAMP(4);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
+__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
+void ea_gemm2_kernel(EaGemmParams p) {
+  ea_gemm2_tile<BM, BN, WM, WN, STAGES, MT, ILV, LDR, TR>(p, blockIdx.x, blockIdx.z);
+}
+
+// TWIN launch: two problems of ONE shape and plan (same M, N, K, tile plan, split-K factor, epilogue form -- the host
+// checks, ea_gemm.hip launch_pair) in one grid, blockIdx.y = problem.  The ControlNet trunk is a copy of the UNet encoder
+// (cldm/cldm.py:284-305 vs :22-45: identical layers on identical shapes), so every contraction of one has a twin in the
+// other: as one grid the pair fills twice the workgroup slots exactly where M is smallest (16 x 16 / 8 x 8 latents: 80-320
+// workgroups on 512 slots), deterministically, instead of two streams packing into each other when the timing allows.
+// The problem is picked by a wave-uniform select between the two kernel-argument blocks: every field stays a scalar load.
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
+__global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
+void ea_gemm2_pair_kernel(EaGemmParams p0, EaGemmParams p1) {
+  const EaGemmParams& p = blockIdx.y ? p1 : p0;
+  ea_gemm2_tile<BM, BN, WM, WN, STAGES, MT, ILV, LDR, TR>(p, blockIdx.x, blockIdx.z);
 }

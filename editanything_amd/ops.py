@@ -104,6 +104,105 @@ class aux_workspace:
         _tls.aux = self._prev
 
 
+class Pair:
+    """Two lanes of one computation: the same layer of two networks (the UNet encoder and the ControlNet trunk, unet.py
+    `twin`).  Every op of this module takes Pairs wherever it takes tensors: the contractions go out as ONE twin launch
+    (`ea_gemm_f16_pair` / `ea_conv2d_f16_pair`: one grid carrying both problems), everything else lane by lane.  A lane may be
+    None (an optional operand only one network has, e.g. the hint residual of the ControlNet's first convolution)."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def __iter__(self):
+        return iter((self.a, self.b))
+
+    def _both(self, f):
+        return Pair(None if self.a is None else f(self.a), None if self.b is None else f(self.b))
+
+    @property
+    def shape(self):
+        assert self.a.shape == self.b.shape, (self.a.shape, self.b.shape)
+        return self.a.shape
+
+    @property
+    def device(self):
+        return self.a.device
+
+    @property
+    def dtype(self):
+        return self.a.dtype
+
+    def view(self, *shape):
+        return self._both(lambda t: t.view(*shape))
+
+    def __getitem__(self, idx):
+        return self._both(lambda t: t[idx])
+
+
+def _has_pair(x):
+    if isinstance(x, Pair):
+        return True
+    if isinstance(x, (tuple, list)):
+        return any(_has_pair(v) for v in x)
+    if isinstance(x, dict):
+        return any(_has_pair(v) for v in x.values())
+    return False
+
+
+def _lane(x, i):
+    """Lane i of a value that may hold Pairs at any depth of tuples / lists / dicts."""
+    if isinstance(x, Pair):
+        return x.b if i else x.a
+    if isinstance(x, tuple):
+        return tuple(_lane(v, i) for v in x)
+    if isinstance(x, list):
+        return [_lane(v, i) for v in x]
+    if isinstance(x, dict):
+        return {k: _lane(v, i) for k, v in x.items()}
+    return x
+
+
+def _zip(a, b):
+    """Inverse of _lane: two lane results -> one value with Pairs where the lanes hold tensors (or differ)."""
+    if isinstance(a, tuple) and isinstance(b, tuple) and len(a) == len(b):
+        return tuple(_zip(x, y) for x, y in zip(a, b))
+    if isinstance(a, list) and isinstance(b, list) and len(a) == len(b):
+        return [_zip(x, y) for x, y in zip(a, b)]
+    if a is None and b is None:
+        return None
+    if not torch.is_tensor(a) and not torch.is_tensor(b) and not isinstance(a, Normed) and a == b:
+        return a
+    return Pair(a, b)
+
+
+def lanewise(fn):
+    """An op without a twin kernel: with Pair arguments it runs once per lane (two launches, back to back)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(*args, **kw):
+        if not (_has_pair(args) or _has_pair(kw)):
+            return fn(*args, **kw)
+        return _zip(fn(*_lane(args, 0), **_lane(kw, 0)), fn(*_lane(args, 1), **_lane(kw, 1)))
+    return wrap
+
+
+def dup_rows(t, dim=0):
+    """cat([t, t], dim): the two identical halves of a CFG batch materialised (unet.py shared prefix)."""
+    if isinstance(t, Pair):
+        return t._both(lambda x: torch.cat([x, x], dim))
+    return torch.cat([t, t], dim)
+
+
+def cols(t, off, n):
+    """t[:, off:off + n] -- per lane, with per-lane offsets where they differ."""
+    if isinstance(t, Pair):
+        o = off if isinstance(off, Pair) else Pair(off, off)
+        return Pair(t.a[:, o.a:o.a + n], t.b[:, o.b:o.b + n])
+    return t[:, off:off + n]
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -162,7 +261,7 @@ class _Config:
                     16 x 16 / 8 x 8 levels: ea_epilogue.gn_next_out)"""
     ln_fold = True
     gn_epilogue = True
-    gn_next = False
+    gn_next = True
 
 
 CONFIG = _Config()
@@ -181,17 +280,16 @@ def ln_fold_ok(M, N, K):
     return CONFIG.ln_fold and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
 
 
-def row_stats_buffer(M, N, device):
-    """[parts][M][2] fp32 row partials a GEMM with N outputs writes (`row_stats=`) for the next launch's fold."""
-    return torch.empty((_lib().ea_row_stats_parts(int(N)), M, 2), dtype=torch.float32, device=device)
+def row_stats_buffer(M, N, like):
+    """[parts][M][2] fp32 row partials a GEMM with N outputs writes (`row_stats=`) for the next launch's fold; one per
+    lane when `like` (the tensor whose device it lives on) is a Pair."""
+    mk = lambda: torch.empty((_lib().ea_row_stats_parts(int(N)), M, 2), dtype=torch.float32, device=like.device)
+    return Pair(mk(), mk()) if isinstance(like, Pair) else mk()
 
 
-def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
-         rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
-    """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor.
-    row_stats: a `row_stats_buffer` to fill with the output rows' (sum, sum of squares) partials.
-    ln_fold = (stats, colsum, eps): LayerNorm over a's rows folded into the contraction -- `w` carries gamma, `bias`
-    carries W beta + b, `stats` are the partials the launch that produced `a` wrote."""
+def _gemm_prep(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
+               rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
+    """Checks, output allocation and the epilogue block of one dense contraction (one lane of a twin launch)."""
     _check_dev(a, w)
     _dense(a, residual, out)
     if w.stride(-1) != 1:
@@ -202,7 +300,6 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
     n_out = N // 2 if act == ACT_GEGLU else N
     if out is None:
         out = torch.empty(a.shape[:-1] + (n_out,), dtype=out_dtype, device=a.device)
-    ws = workspace(a.device)
     e = _epilogue(out, n_out, bias, act, scale, residual, rowvec, rows_per_group, row_scale, bias_per_row)
     if act == ACT_GEGLU:
         e.geglu_block = geglu_block(N, K)       # must match unet.pack_geglu
@@ -211,12 +308,39 @@ def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch
     if ln_fold is not None:
         stats, colsum, eps = ln_fold
         e.ln_stats, e.ln_parts, e.ln_colsum, e.ln_eps = _p(stats), stats.shape[0], _p(colsum), float(eps)
+    nbytes = 2 * (M * K + N * K) + out.element_size() * M * n_out + (residual.element_size() * M * n_out if residual is not None else 0)
+    return dict(a=a, w=w, M=M, N=N, K=K, out=out, e=e, flops=2.0 * M * N * K, nbytes=nbytes,
+                label=f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}")
+
+
+def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
+         rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
+    """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor.
+    row_stats: a `row_stats_buffer` to fill with the output rows' (sum, sum of squares) partials.
+    ln_fold = (stats, colsum, eps): LayerNorm over a's rows folded into the contraction -- `w` carries gamma, `bias`
+    carries W beta + b, `stats` are the partials the launch that produced `a` wrote.
+    With `Pair` operands (two lanes of one shape): ONE twin launch, returns a Pair."""
+    kw = dict(bias=bias, act=act, residual=residual, out=out, out_dtype=out_dtype, scale=scale, rowvec=rowvec,
+              rows_per_group=rows_per_group, row_scale=row_scale, bias_per_row=bias_per_row, row_stats=row_stats, ln_fold=ln_fold)
+    if _has_pair((a, w)) or _has_pair(kw):
+        g0, g1 = _gemm_prep(_lane(a, 0), _lane(w, 0), **_lane(kw, 0)), _gemm_prep(_lane(a, 1), _lane(w, 1), **_lane(kw, 1))
+        if (g0["M"], g0["N"], g0["K"], g0["w"].stride(0)) != (g1["M"], g1["N"], g1["K"], g1["w"].stride(0)):
+            raise ValueError("twin gemm: the two lanes must have one shape")
+        ws = workspace(g0["a"].device)
+        ev = _prof_begin()
+        st = _lib().ea_gemm_f16_pair(_p(g0["a"]), _p(g1["a"]), g0["K"], _p(g0["w"]), _p(g1["w"]), g0["w"].stride(0), g0["M"], g0["N"],
+                                     g0["K"], C.byref(g0["e"]), C.byref(g1["e"]), _p(ws), ws.numel(), _stream())
+        _prof_end(ev, g0["flops"] + g1["flops"], g0["label"] + " x2", g0["nbytes"] + g1["nbytes"])
+        L.check(st, f"ea_gemm_f16_pair M{g0['M']} N{g0['N']} K{g0['K']}")
+        return Pair(g0["out"], g1["out"])
+    g = _gemm_prep(a, w, **kw)
+    ws = workspace(a.device)
     ev = _prof_begin()
-    st = _lib().ea_gemm_f16(_p(a), K, _p(w), w.stride(0), M, N, K, 1, 0, 0, 0, 0, C.byref(e), _p(ws), ws.numel(), _stream())
-    _prof_end(ev, 2.0 * M * N * K, f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}",
-              2 * (M * K + N * K) + out.element_size() * M * n_out + (residual.element_size() * M * n_out if residual is not None else 0))
-    L.check(st, f"ea_gemm_f16 M{M} N{N} K{K}")
-    return out
+    st = _lib().ea_gemm_f16(_p(a), g["K"], _p(w), w.stride(0), g["M"], g["N"], g["K"], 1, 0, 0, 0, 0, C.byref(g["e"]), _p(ws), ws.numel(),
+                            _stream())
+    _prof_end(ev, g["flops"], g["label"], g["nbytes"])
+    L.check(st, f"ea_gemm_f16 M{g['M']} N{g['N']} K{g['K']}")
+    return g["out"]
 
 
 def gemm_batched(a, w, out, M, N, K, batch, stride_a, stride_w, stride_c, lda=None, ldw=None, bias=None,
@@ -254,10 +378,10 @@ def _rows_per_group(rowvec, s):
     return s.Hout * s.Wout
 
 
-# CONFIG.gn_next -- measured on the MI355X with the two-stream phase-1 overlap (profiles/r03_fused_reduce_groupnorm_ab.jsonl):
-# -6 us per site, 29 sites per evaluation, -0.8 % on the denoising loop, but one graph replay in ten ran 7 % SLOWER with
-# identical kernel times: the (sample, group) workgroups take half a CU each and, when they landed beside the other stream's
-# contraction launch, the two streams stopped packing into each other.
+# CONFIG.gn_next -- round 3 (profiles/r03_fused_reduce_groupnorm_ab.jsonl): -6 us per site, 29 sites per evaluation, -0.8 % on
+# the denoising loop, but one graph replay in ten ran 7 % slower with identical kernel times, so it shipped off.  Round 4
+# re-measured it in tools/eval_time.py (three separate captures, 18 rounds of 10 replays, profiles/r04_twin_launch_ab.jsonl):
+# 14.03-14.07 against 14.19-14.23 ms per evaluation in every capture, no slow mode -> ON by default.
 
 
 class Normed:
@@ -284,22 +408,16 @@ def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
     return int(_lib().ea_gemm_gn_stats_chunk_rows(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 
 
-def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
-           residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None,
-           gn_groups=0, gn_next=None):
-    """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin).
-
-    gn_groups > 0: the caller's next op is a GroupNorm over this output -- returns (out, stats) with stats =
-    (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them.
-    gn_next = (gamma, beta, eps, silu) of that GroupNorm, when the caller knows it: where the launch is split along K its
-    reduction applies the norm itself and stats is a `Normed` (the normalised tensor)."""
+def _conv_prep(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
+               residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None,
+               gn_groups=0, gn_next=None):
+    """Checks, output allocation, source and epilogue blocks of one convolution (one lane of a twin launch)."""
     _check_dev(x1, w)
     _dense(x1, x2, x2_add, w, residual, out)
     s = _conv_src(x1, x2, x2_add, ksize, stride, pad, ups, hout, wout)
     cout = w.shape[0]
     if out is None:
         out = torch.empty((s.B, s.Hout, s.Wout, cout), dtype=out_dtype, device=x1.device)
-    ws = workspace(x1.device)
     e = _epilogue(out, cout, bias, act, scale, residual, rowvec, _rows_per_group(rowvec, s), row_scale)
     stats = None
     if gn_groups:
@@ -317,17 +435,48 @@ def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_ad
             part = torch.empty((s.B, hw // rows, gn_groups, 2), dtype=torch.float32, device=x1.device)
             e.gn_stats_out, e.gn_rows_per_sample, e.gn_cpg = _p(part), hw, cout // gn_groups
             stats = (part, hw // rows)
-    ev = _prof_begin()
-    st = _lib().ea_conv2d_f16(C.byref(s), _p(w), cout, C.byref(e), _p(ws), ws.numel(), _stream())
     m_out = s.B * s.Hout * s.Wout
-    _prof_end(ev, 2.0 * m_out * cout * w.shape[1],
-              f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}",
-              2 * (s.B * s.Hin * s.Win * (s.c1 + s.c2) + w.numel()) + out.element_size() * m_out * cout
-              + (residual.element_size() * m_out * cout if residual is not None else 0))
-    L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{cout}")
-    return (out, stats) if gn_groups else out
+    nbytes = 2 * (s.B * s.Hin * s.Win * (s.c1 + s.c2) + w.numel()) + out.element_size() * m_out * cout \
+        + (residual.element_size() * m_out * cout if residual is not None else 0)
+    return dict(s=s, w=w, cout=cout, out=out, e=e, stats=stats, flops=2.0 * m_out * cout * w.shape[1], nbytes=nbytes,
+                label=f"conv{ksize} B{s.B} H{s.Hin} c{s.c1}+{s.c2}->{cout} s{stride} u{int(ups)}",
+                geom=(s.B, s.Hin, s.Win, s.c1, s.c2, s.Hout, s.Wout, cout))
 
 
+def conv2d(x1, w, bias=None, ksize=3, stride=1, pad=1, ups=False, x2=None, x2_add=None, act=ACT_NONE, scale=1.0,
+           residual=None, rowvec=None, row_scale=None, out=None, out_dtype=torch.float16, hout=None, wout=None,
+           gn_groups=0, gn_next=None):
+    """Implicit-GEMM convolution on NHWC fp16; `w` is [Cout, ksize*ksize*(c1+c2)] (K = tap*Cin + cin).
+
+    gn_groups > 0: the caller's next op is a GroupNorm over this output -- returns (out, stats) with stats =
+    (partials [B, nchunk, groups, 2], nchunk) written by the epilogue, or None when this launch cannot emit them.
+    gn_next = (gamma, beta, eps, silu) of that GroupNorm, when the caller knows it: where the launch is split along K its
+    reduction applies the norm itself and stats is a `Normed` (the normalised tensor).
+    With `Pair` operands (two lanes of one geometry): ONE twin launch, returns Pairs."""
+    kw = dict(bias=bias, ksize=ksize, stride=stride, pad=pad, ups=ups, x2=x2, x2_add=x2_add, act=act, scale=scale, residual=residual,
+              rowvec=rowvec, row_scale=row_scale, out=out, out_dtype=out_dtype, hout=hout, wout=wout, gn_groups=gn_groups, gn_next=gn_next)
+    if _has_pair((x1, w)) or _has_pair(kw):
+        c0, c1 = _conv_prep(_lane(x1, 0), _lane(w, 0), **_lane(kw, 0)), _conv_prep(_lane(x1, 1), _lane(w, 1), **_lane(kw, 1))
+        if c0["geom"] != c1["geom"]:
+            raise ValueError("twin conv2d: the two lanes must have one geometry")
+        ws = workspace(c0["out"].device)
+        ev = _prof_begin()
+        st = _lib().ea_conv2d_f16_pair(C.byref(c0["s"]), C.byref(c1["s"]), _p(c0["w"]), _p(c1["w"]), c0["cout"], C.byref(c0["e"]),
+                                       C.byref(c1["e"]), _p(ws), ws.numel(), _stream())
+        _prof_end(ev, c0["flops"] + c1["flops"], c0["label"] + " x2", c0["nbytes"] + c1["nbytes"])
+        L.check(st, f"ea_conv2d_f16_pair {c0['geom']}")
+        outs = Pair(c0["out"], c1["out"])
+        return (outs, _zip(c0["stats"], c1["stats"])) if gn_groups else outs
+    c = _conv_prep(x1, w, **kw)
+    ws = workspace(x1.device)
+    ev = _prof_begin()
+    st = _lib().ea_conv2d_f16(C.byref(c["s"]), _p(w), c["cout"], C.byref(c["e"]), _p(ws), ws.numel(), _stream())
+    _prof_end(ev, c["flops"], c["label"], c["nbytes"])
+    L.check(st, f"ea_conv2d_f16 {tuple(x1.shape)}->{c['cout']}")
+    return (c["out"], c["stats"]) if gn_groups else c["out"]
+
+
+@lanewise
 def groupnorm(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=None, out=None, stats=None):
     """GroupNorm (+SiLU).  stats = (partials, nchunk) left behind by the contraction that produced x1 (conv2d / gemm
     `gn_groups=`): the normalise pass alone, no statistics pass."""
@@ -367,9 +516,11 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
     gn_in: this GroupNorm's statistics, left behind by the launch that produced x1 (then the norm is the streaming
     normalise pass alone).  gn_out_groups > 0: the conv's epilogue leaves the statistics of ITS output for the next
     GroupNorm -- returns (out, stats-or-None).  Without either it is ONE C-ABI call (statistics, normalise, conv)."""
-    _check_dev(x1, w)
-    _dense(x1, x2, x2_add, residual)
-    if gn_in is not None or gn_out_groups:
+    pair = _has_pair((x1, gamma, w, x2, residual, rowvec, gn_in))
+    if not pair:
+        _check_dev(x1, w)
+        _dense(x1, x2, x2_add, residual)
+    if gn_in is not None or gn_out_groups or pair:      # (twin lanes: the norm lane by lane, the convolution as ONE launch)
         n = groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add, stats=gn_in)
         return conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype,
                       gn_groups=gn_out_groups, gn_next=gn_next)
@@ -389,6 +540,7 @@ def groupnorm_silu_conv3x3(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=Non
     return out
 
 
+@lanewise
 def layernorm(x, gamma, beta, eps=1e-5):
     _check_dev(x, gamma)
     _dense(x)
@@ -429,6 +581,8 @@ def gather_add_rows(x32, src16, rows):
 
 def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None, out_dtype=torch.float16):
     """LayerNorm -> Linear as one C-ABI call (BasicTransformerBlock norm -> to_q / GEGLU proj)."""
+    if _has_pair((x, w)):        # twin lanes: the norm lane by lane, the contraction as ONE launch
+        return gemm(layernorm(x, gamma, beta, eps), w, bias, act, residual, out_dtype=out_dtype)
     _check_dev(x, w)
     if PROFILE is not None:
         return gemm(layernorm(x, gamma, beta, eps), w, bias, act, residual, out_dtype=out_dtype)
@@ -448,6 +602,7 @@ def ln_gemm(x, gamma, beta, w, bias=None, eps=1e-5, act=ACT_NONE, residual=None,
     return out
 
 
+@lanewise
 def attention(q, k, v, heads, dim_head, scale=None, bias_h=None, bias_w=None, S=0, out=None):
     """q/k/v: [B, N, >=heads*dim_head] fp16 views (last-dim stride 1; row/batch strides free, e.g. slices of a fused
     QKV buffer).  Returns [B, Nq, heads*dim_head]."""
@@ -616,6 +771,7 @@ def silu_f32(x):
     return out
 
 
+@lanewise
 def add_f16(a, b):
     out = torch.empty_like(a)
     L.check(_lib().ea_add_f16(_p(a), _p(b), _p(out), a.numel(), _stream()), "ea_add_f16")

@@ -88,7 +88,7 @@ class _Res:
         from the in_layers conv's epilogue where that launch can emit them (ops.gn_stats_plan) -- or, where that conv is
         split along K, is applied by its reduction kernel outright (ops.gn_next_plan); gn_next = (gamma, beta, eps, silu) of
         the caller's norm lets the out_layers conv do the same for it."""
-        rowvec = emb_all[:, self.emb_off:self.emb_off + self.cout]
+        rowvec = ops.cols(emb_all, self.emb_off, self.cout)
         h, st2 = ops.groupnorm_silu_conv3x3(x1, self.g1w, self.g1b, self.w1, self.b1, x2=x2, rowvec=rowvec,
                                             gn_in=gn_in if x2 is None else None, gn_out_groups=32,
                                             gn_next=(self.g2w, self.g2b, 1e-5, True))
@@ -154,7 +154,7 @@ class _Attn:
         # (row_stats), the consumer's epilogue applies the LayerNorm algebraically (ops.gemm ln_fold)
         fold = [ref is None and ops.PROFILE is None and ops.ln_fold_ok(m, wf.shape[0], inner)
                 for m, (wf, _, _) in zip((M, M2, M2), self.fold)]
-        st = [ops.row_stats_buffer(m, inner, x.device) if f else None for m, f in zip((M, M, M2), fold)]
+        st = [ops.row_stats_buffer(m, inner, x) if f else None for m, f in zip((M, M, M2), fold)]
 
         def normed(h, i, w, b=None, act=ops.ACT_NONE):
             if fold[i]:
@@ -171,9 +171,9 @@ class _Attn:
             a = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], self.heads, self.d)
             h = ops.gemm(a, self.wo1, self.bo1, residual=h, row_stats=st[1])
         if dup_after_attn1:
-            h, xt, B = torch.cat([h, h]), torch.cat([xt, xt]), 2 * B
+            h, xt, B = ops.dup_rows(h), ops.dup_rows(xt), 2 * B
             if st[1] is not None:
-                st[1] = torch.cat([st[1], st[1]], dim=1)
+                st[1] = ops.dup_rows(st[1], dim=1)
         q = normed(h, 1, self.wq2)
         a = ops.attention(q, kv[..., :inner], kv[..., inner:], self.heads, self.d)
         h = ops.gemm(a, self.wo2, self.bo2, residual=h, row_stats=st[2])
@@ -189,6 +189,28 @@ class _Conv:
 
     def forward(self, x, residual=None, act=ops.ACT_NONE):
         return ops.conv2d(x, self.w, self.b, stride=self.stride, ups=self.ups, residual=residual, act=act)
+
+
+class _Twin:
+    """The same layer of two networks as ONE module whose tensors are `ops.Pair`s: `type(a).forward(_Twin(a, b), Pair, ...)`
+    runs the layer's own forward code once for both lanes -- every contraction in it goes out as a twin launch."""
+
+    def __init__(self, a, b):
+        object.__setattr__(self, "_a", a)
+        object.__setattr__(self, "_b", b)
+
+    def __getattr__(self, name):
+        return _twin_value(getattr(self._a, name), getattr(self._b, name))
+
+
+def _twin_value(va, vb):
+    if torch.is_tensor(va) or torch.is_tensor(vb):
+        return ops.Pair(va, vb)
+    if isinstance(va, (tuple, list)):
+        return type(va)(_twin_value(x, y) for x, y in zip(va, vb))
+    if va is None and vb is None:
+        return None
+    return va if va == vb else ops.Pair(va, vb)
 
 
 class _UNetBase:
@@ -287,6 +309,31 @@ class _UNetBase:
                 dup = False
             else:
                 h = m.forward(h)
+            stats = None
+        return h
+
+    @staticmethod
+    def run_twin(na, nb, mods_a, mods_b, h, emb_all, kvs_a, kvs_b, residual=None, dup=False):
+        """`_run` for the same block of two networks in lock step (no reference-only pass, single-source inputs): h /
+        emb_all / residual are `ops.Pair`s (lane a = network na, lane b = nb), the result is a Pair."""
+        stats = None
+        for k, ((kind, ma), (_, mb)) in enumerate(zip(mods_a, mods_b)):
+            m = _Twin(ma, mb)
+            if kind == "conv_in":
+                h = _Conv.forward(m, h, residual=residual)
+            elif kind == "res":
+                if k + 1 < len(mods_a) and mods_a[k + 1][0] == "attn":
+                    nxt = _Twin(mods_a[k + 1][1], mods_b[k + 1][1])
+                    h, stats = _Res.forward(m, h, None, emb_all, gn_out=True, gn_next=(nxt.nw, nxt.nb, 1e-6, False))
+                else:
+                    h = _Res.forward(m, h, None, emb_all)
+                continue
+            elif kind == "attn":
+                kv = ops.Pair(kvs_a[na._attn_index[id(ma)]], kvs_b[nb._attn_index[id(mb)]])
+                h = _Attn.forward(m, h, kv, gn_in=stats, dup_after_attn1=dup)
+                dup = False
+            else:
+                h = _Conv.forward(m, h)
             stats = None
         return h
 
@@ -424,9 +471,13 @@ class ControlledDenoiser:
     (text K/V of every attention layer, ControlNet hint features) are prepared once, then `eps(x, t)` is the
     per-step hot function: UNet encoder -> ControlNet (accumulating into the skips) -> UNet decoder."""
 
-    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True):
+    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True, twin=False):
         """overlap: the ControlNet trunk runs beside the UNet encoder on a second stream (False: one stream, in order).
-        share_cfg_prefix: `eps(cfg_halves=True)` computes the part the two CFG halves share once."""
+        share_cfg_prefix: `eps(cfg_halves=True)` computes the part the two CFG halves share once.
+        twin: the (first) ControlNet's trunk and the UNet encoder run in LOCK STEP on one stream, every contraction of the
+        pair as one twin launch (ops.Pair / ea_*_pair: one grid, two problems) -- the deterministic form of what `overlap`
+        gets from two streams packing into each other.  Needs a ControlNet whose trunk is layer for layer the UNet's
+        encoder (every SD ControlNet; not the 9-channel inpainting UNet), else the pair falls back to `overlap`."""
         self.unet = unet
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
@@ -438,6 +489,7 @@ class ControlledDenoiser:
         # contraction kernels more than the extra overlap returns, so the default stays 1.
         self.split = 1
         self.share_cfg_prefix = bool(share_cfg_prefix)
+        self.twin = bool(twin)
         self._strm = []
 
     def static_state(self):
@@ -547,6 +599,14 @@ class ControlledDenoiser:
                 sc = [s[rows.start * k:rows.stop * k] if torch.is_tensor(s) else s for s, k in zip(sc, per)]
                 c["jobs"].append((cn, x_cn, emb_c, [k[rows] for k in kv], gh[half] if shared else gh[rows], sc))
             ctx.append(c)
+        if self.twin and split == 1 and u.ref is None and ctx[0]["jobs"] and self._twinable(ctx[0]["jobs"][0][0]):
+            c = ctx[0]
+            cn0, x_cn, emb_c, kv0, gh0, sc0 = c["jobs"][0]
+            hs, mid, feats = self._encode_twin(cn0, c["xin"], x_cn, c["emb_u"], emb_c, c["kv_u"], kv0, gh0, shared)
+            cn0.add_features(feats, hs, mid, sc0)
+            for cn, x_cn, emb_c, kv, gh, sc in c["jobs"][1:]:
+                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared)
+            return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         if not concurrent:
             c = ctx[0]
             hs, mid = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared)
@@ -595,9 +655,31 @@ class ControlledDenoiser:
         del ctx             # branch-stream tensors stay alive until every consumer has been issued
         return out
 
-    @staticmethod
-    def _nrows(t):
-        return t.shape[0]
+    def _twinable(self, cn):
+        u = self.unet
+        return cn.ref is None and cn.plan["input"] == u.plan["input"] and cn.plan["middle"] == u.plan["middle"] and \
+            cn.cfg.get("context_dim") == u.cfg.get("context_dim")
+
+    def _encode_twin(self, cn, x_u, x_c, emb_u, emb_c, kv_u, kv_c, guided_hint, shared):
+        """`unet.encode` and `cn._features` in lock step (lane a = UNet encoder, lane b = ControlNet trunk):
+        -> (UNet skips, UNet middle output, ControlNet features incl. its middle output)."""
+        u = self.unet
+        h, emb = ops.Pair(x_u, x_c), ops.Pair(emb_u, emb_c)
+        hs, feats = [], []
+        for i, (mu, mc) in enumerate(zip(u.input_blocks, cn.input_blocks)):
+            res = ops.Pair(None, guided_hint) if i == 0 else None       # the hint enters the ControlNet's first convolution
+            if shared and i == 0:
+                h = _UNetBase.run_twin(u, cn, mu, mc, h, emb, kv_u, kv_c, residual=res)
+                d = ops.dup_rows(h)
+                hs.append(d.a)
+                feats.append(d.b)
+                continue
+            h = _UNetBase.run_twin(u, cn, mu, mc, h, emb, kv_u, kv_c, residual=res, dup=shared and i == 1)
+            hs.append(h.a)
+            feats.append(h.b)
+        h = _UNetBase.run_twin(u, cn, u.middle_block, cn.middle_block, h, emb, kv_u, kv_c)
+        feats.append(h.b)
+        return hs, h.a, feats
 
     def _streams(self, ngroups):
         """[(group stream, its ControlNet side stream)] per row group; group 0 runs on the caller's stream.  Streams and

@@ -158,11 +158,11 @@ int ea_gemm_ln_fold_ok(int M, int N, int K);
 /* Rows per GroupNorm-statistics chunk (the wave tile height of the instantiation the planner picks) when a launch of
  * this shape can emit `gn_stats_out` from its epilogue, else 0: unsplit register-direct launches whose wave tiles hold
  * whole groups and whole-sample row ranges.  conv: 1 for ea_conv2d_f16 launches (M = B * Hout * Wout, K = ks*ks*Cin). */
+int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg);
 /* 1 if a launch of this shape (conv != 0: implicit-GEMM convolution) is split along K and its reduction can apply the
  * consuming GroupNorm (ea_epilogue.gn_next_out): whole samples of rows_per_sample rows, groups of cpg channels (cpg % 4 == 0),
  * one (sample, group) slab small enough for one workgroup's registers. */
 int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sample, int cpg);
-int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg);
 
 /* C[b] = epilogue(A[b] (MxK, lda) * W[b]^T (NxK, ldw)), b < batch. */
 int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int batch,
@@ -172,6 +172,19 @@ int ea_gemm_f16(const void* A, int lda, const void* W, int ldw, int M, int N, in
 /* Implicit-GEMM convolution; M = B*Hout*Wout, K = ksize^2*(c1+c2), W [Cout][K]. */
 int ea_conv2d_f16(const ea_conv_src* src, const void* W, int Cout, const ea_epilogue* epi,
                   void* workspace, size_t ws_bytes, void* stream);
+
+/* TWIN launches: two contractions of ONE shape (same M, N, K / same convolution geometry; own operands, weights and
+ * epilogues) issued as one grid when both plan onto the same kernel instantiation -- otherwise as two launches back to back.
+ * Swap point: cldm/cldm.py:328-341 (ControlLDM.apply_model) runs `control_model(...)` and then `diffusion_model(...)`; the
+ * ControlNet trunk (cldm.py:284-305) is a layer-for-layer copy of the UNet encoder (cldm.py:22-33,
+ * openaimodel.py:716-760) on the same shapes, so every Linear / conv2d of one has a twin in the other with no dependency
+ * between them.  As one grid the pair fills twice the workgroup slots where M is smallest (16 x 16 / 8 x 8 latents).
+ * workspace: both problems' split-K partials (2 x ea_gemm_workspace_bytes, each half 256-byte aligned); a smaller workspace
+ * makes the call fall back to the two-launch form.  Results are bit-identical to two single calls. */
+int ea_gemm_f16_pair(const void* A0, const void* A1, int lda, const void* W0, const void* W1, int ldw, int M, int N, int K,
+                     const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream);
+int ea_conv2d_f16_pair(const ea_conv_src* src0, const ea_conv_src* src1, const void* W0, const void* W1, int Cout,
+                       const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream);
 
 /* GroupNorm (+ optional SiLU) on NHWC fp16, statistics in fp32.
  * workspace: ea_groupnorm_workspace_bytes(B, HW, C, groups). */

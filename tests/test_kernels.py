@@ -496,21 +496,26 @@ def test_attention(kb, B, H, Nq, Nk, D):
 
 
 def test_attention_two_query_groups_per_wave_is_bit_identical(kb):
-    """The 256-query form of the pipelined d = 64 kernel (two 32-row groups per wave sharing every K / V fragment) does each
-    row's arithmetic exactly as the 128-query form: one head's first 256 rows, launched alone (one workgroup in the 256-query
-    form -> the emulation build's threshold sends it to the 128-query kernel), equal the big launch's rows bit for bit."""
+    """EXPERIMENT build only (-DEA_ATTN_EXP=2, its own emulation library: the main emulation build dispatches as the product
+    does).  The 256-query form of the pipelined d = 64 kernel (two 32-row groups per wave sharing every K / V fragment) does
+    each row's arithmetic exactly as the shipped 128-query form: the experiment library's big launch (two groups per wave)
+    equals the product dispatch's result bit for bit."""
     if kb.name != "emu":
-        pytest.skip("needs the emulation build's low workgroup threshold to reach both forms at test size")
+        pytest.skip("experiment build: emulation only")
+    from editanything_amd.csrc import build
+    exp = C.CDLL(build.build_emu_attn_exp(verbose=False))
+    from editanything_amd import _lib
+    exp.ea_attention_f16.restype, exp.ea_attention_f16.argtypes = _lib.SIGNATURES["ea_attention_f16"]
     B, H, Nq, Nk, D = 1, 2, 512, 330, 64
     q, k, v = f16(B, Nq, H, D), f16(B, Nk, H, D), f16(B, Nk, H, D)
-    out = kb.zeros((B, Nq, H, D), np.float16)
     scale = D ** -0.5
-    args = lambda o, h, nq: (ptr(q), ptr(k), ptr(v), o, B, h, nq, Nk, D, Nq * H * D, H * D, Nk * H * D, H * D, Nk * H * D, H * D,
-                             Nq * H * D, H * D, scale, None, None, 0, kb.stream)
-    assert kb.lib.ea_attention_f16(*args(ptr(out), H, Nq)) == 0                 # 2 heads x 2 blocks = 4 workgroups: two groups per wave
+    args = lambda o: (ptr(q), ptr(k), ptr(v), o, B, H, Nq, Nk, D, Nq * H * D, H * D, Nk * H * D, H * D, Nk * H * D, H * D,
+                      Nq * H * D, H * D, scale, None, None, 0, kb.stream)
+    out = kb.zeros((B, Nq, H, D), np.float16)
+    assert exp.ea_attention_f16(*args(ptr(out))) == 0               # 2 heads x 2 blocks = 4 workgroups: two groups per wave
     one = kb.zeros((B, Nq, H, D), np.float16)
-    assert kb.lib.ea_attention_f16(*args(ptr(one), 1, 256)) == 0                # head 0, rows 0..255: 1 workgroup -> one group per wave
-    assert np.array_equal(kb.down(one)[0, :256, 0], kb.down(out)[0, :256, 0])
+    assert kb.lib.ea_attention_f16(*args(ptr(one))) == 0            # the product dispatch: ea_attn_dma_kernel<4, 1>
+    assert np.array_equal(kb.down(one), kb.down(out))
 
 
 def test_attention_fused_qkv_strides(kb):
@@ -1409,3 +1414,139 @@ def test_sam_t2i_fused(kb, B, T, shared):
     ref = torch.einsum("bqt,btc->bqc", P, kk)
     assert relerr(kb.down(ctx), ref.numpy()) < 3e-3
     assert kb.lib.ea_sam_t2i_f16(ptr(k), 0, ptr(pe), ptr(g), 0.25, ptr(ctx), B, 100, Cc, kb.stream) != 0     # T % 64
+
+
+# ---------------------------------------------------------------------------------------------- twin launches
+@pytest.mark.parametrize("M,N,K,act,res,rowvec,splits,stats", [
+    (256, 320, 128, 0, True, False, 0, False),     # 128x160 tiles, residual in lane 0 only (lane 1: none)
+    (200, 160, 64, 1, False, False, 0, False),     # ragged M, SiLU
+    (72, 192, 192, 2, True, False, 0, False),      # 64-row tiles, 128-wide column tiles, GELU
+    (256, 256, 64, 1, False, True, 0, False),      # per-sample row vector (time embedding)
+    (128, 320, 512, 0, True, True, 4, False),      # split-K: two sets of partials in one scratch, twin reduction
+    (256, 320, 128, 0, False, False, 0, True),     # row statistics out (TR = 2 instantiation)
+])
+def test_twin_gemm_equals_two_single_launches(kb, M, N, K, act, res, rowvec, splits, stats):
+    """ea_gemm_f16_pair: two problems of one shape in ONE grid (ea_gemm2_pair_kernel, blockIdx.y = problem; own operands,
+    weights, epilogues) == the two single launches, bit for bit -- and == torch."""
+    if splits:
+        tune(kb, splits=splits)
+    A = [f16(M, K), f16(M, K)]
+    W = [f16(N, K, scale=0.2), f16(N, K, scale=0.2)]
+    bias = [f32(N), f32(N)]
+    R = [f16(M, N) if res else None, None]                  # lanes may differ in optional operands
+    rv = [f32(M // 128, N) if rowvec else None for _ in range(2)]
+    parts = kb.lib.ea_row_stats_parts(N)
+    need = kb.lib.ea_gemm_workspace_bytes(M, N, K, 1)
+    ws = workspace(kb, 2 * need + 1024)
+
+    def epi(i, out, st):
+        return epilogue(out, bias=bias[i], act=act, scale=0.75, residual=R[i], rowvec=rv[i], rows_per_group=128 if rowvec else 1,
+                        row_stats_out=st)
+    single, sstat = [], []
+    for i in range(2):
+        out = kb.zeros((M, N), np.float16)
+        st = kb.zeros((parts, M, 2), np.float32) if stats else None
+        e = epi(i, out, st)
+        assert kb.lib.ea_gemm_f16(ptr(A[i]), K, ptr(W[i]), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        single.append(kb.down(out).copy())
+        sstat.append(kb.down(st).copy() if stats else None)
+    outs = [kb.zeros((M, N), np.float16) for _ in range(2)]
+    sts = [kb.zeros((parts, M, 2), np.float32) if stats else None for _ in range(2)]
+    e0, e1 = epi(0, outs[0], sts[0]), epi(1, outs[1], sts[1])
+    assert kb.lib.ea_gemm_f16_pair(ptr(A[0]), ptr(A[1]), K, ptr(W[0]), ptr(W[1]), K, M, N, K, C.byref(e0), C.byref(e1), ptr(ws),
+                                   ws_nbytes(ws), kb.stream) == 0
+    for i in range(2):
+        assert np.array_equal(kb.down(outs[i]), single[i]), f"lane {i} differs from its single launch"
+        if stats:
+            assert np.array_equal(kb.down(sts[i]), sstat[i])
+        ref = t(A[i]) @ t(W[i]).T + t(bias[i])
+        if rowvec:
+            ref = ref + t(rv[i]).repeat_interleave(128, 0)
+        ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+        if R[i] is not None:
+            ref = ref + t(R[i])
+        assert relerr(single[i], ref.numpy()) < 3e-3
+    # a scratch too small for two sets of partials: the call falls back to two launches -- same bits
+    if splits:
+        small = workspace(kb, need)
+        outs2 = [kb.zeros((M, N), np.float16) for _ in range(2)]
+        e0, e1 = epi(0, outs2[0], None), epi(1, outs2[1], None)
+        assert kb.lib.ea_gemm_f16_pair(ptr(A[0]), ptr(A[1]), K, ptr(W[0]), ptr(W[1]), K, M, N, K, C.byref(e0), C.byref(e1), ptr(small),
+                                       need, kb.stream) == 0
+        assert all(np.array_equal(kb.down(outs2[i]), single[i]) for i in range(2))
+
+
+@pytest.mark.parametrize("B,H,cin,cout,ksize,stride,emb,res,splits,gn", [
+    (2, 16, 64, 320, 3, 1, True, True, 1, "stats"),      # ResBlock in_layers conv: time embedding, GroupNorm partials out (unsplit)
+    (4, 8, 64, 320, 3, 1, False, True, 0, ""),           # hint residual in ONE lane (the ControlNet's first convolution)
+    (2, 16, 64, 320, 3, 2, False, False, 0, ""),         # Downsample (stride 2)
+    (2, 8, 128, 1280, 3, 1, True, False, 3, "next"),     # split-K + the reduction applies the consuming GroupNorm (twin reduce_gn)
+    (2, 8, 128, 1280, 3, 1, True, True, 3, ""),          # split-K, plain twin reduction
+    (2, 8, 64, 320, 1, 1, False, True, 0, ""),           # 1x1 (skip_connection)
+])
+def test_twin_conv_equals_two_single_launches(kb, B, H, cin, cout, ksize, stride, emb, res, splits, gn):
+    """ea_conv2d_f16_pair == two ea_conv2d_f16 launches bit for bit, incl. the GroupNorm partials / the consuming GroupNorm
+    applied by the (twin) split-K reduction, with per-lane optional operands."""
+    if splits:
+        tune(kb, splits=splits)
+    groups = 32
+    pad = 1 if ksize == 3 else 0
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    HW, M, K = Ho * Ho, B * Ho * Ho, ksize * ksize * cin
+    cpg = cout // groups
+    x = [f16(B, H, H, cin), f16(B, H, H, cin)]
+    W = [f16(cout, K, scale=0.05), f16(cout, K, scale=0.05)]
+    bias = [f32(cout), f32(cout)]
+    rv = [f32(B, cout) if emb else None for _ in range(2)]
+    R = [None, f16(M, cout) if res else None]
+    gamma, beta = [f32(cout), f32(cout)], [f32(cout), f32(cout)]
+    rows = kb.lib.ea_gemm_gn_stats_chunk_rows(M, cout, K, 1, HW, cpg) if gn == "stats" else 0
+    if gn == "stats":
+        assert rows > 0
+    if gn == "next":
+        assert kb.lib.ea_gemm_gn_next_ok(M, cout, K, 1, HW, cpg) == 1
+    need = max(kb.lib.ea_gemm_workspace_bytes(M, cout, K, 1), 4 * max(splits, 1) * M * cout)
+    ws = workspace(kb, 2 * need + 1024)
+
+    def make(i):
+        y = kb.zeros((M, cout), np.float16)
+        part = kb.zeros((B, HW // rows, groups, 2), np.float32) if rows else None
+        n = kb.zeros((M, cout), np.float16) if gn == "next" else None
+        e = epilogue(y, bias=bias[i], rowvec=rv[i], rows_per_group=HW, residual=R[i], gn_stats_out=part,
+                     gn_rows_per_sample=HW if gn else 0, gn_cpg=cpg if gn else 0,
+                     gn_next=(n, gamma[i], beta[i], 1e-5, True) if gn == "next" else None)
+        return y, part, n, e, conv_src(x[i], None, None, ksize, stride, pad, 0, Ho, Ho)
+    single = []
+    for i in range(2):
+        y, part, n, e, src = make(i)
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(W[i]), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        single.append([None if v is None else kb.down(v).copy() for v in (y, part, n)])
+    (y0, p0, n0, e0, s0), (y1, p1, n1, e1, s1) = make(0), make(1)
+    assert kb.lib.ea_conv2d_f16_pair(C.byref(s0), C.byref(s1), ptr(W[0]), ptr(W[1]), cout, C.byref(e0), C.byref(e1), ptr(ws),
+                                     ws_nbytes(ws), kb.stream) == 0
+    for i, got in enumerate(((y0, p0, n0), (y1, p1, n1))):
+        for g, w_ in zip(got, single[i]):
+            if w_ is not None:
+                assert np.array_equal(kb.down(g), w_), f"lane {i} differs from its single launch"
+        ref = F.conv2d(t(x[i]).permute(0, 3, 1, 2), t(W[i]).reshape(cout, ksize, ksize, cin).permute(0, 3, 1, 2), t(bias[i]), stride=stride,
+                       padding=pad)
+        if emb:
+            ref = ref + t(rv[i])[:, :, None, None]
+        ref = ref.permute(0, 2, 3, 1).reshape(M, cout)
+        if R[i] is not None:
+            ref = ref + t(R[i])
+        assert relerr(single[i][0], ref.numpy()) < 4e-3
+
+
+def test_twin_launch_of_unequal_plans_falls_back_to_two_launches(kb):
+    """Lanes whose epilogues select different kernel instantiations (fp32 output in one lane: no register-direct epilogue)
+    still compute the right thing -- as two launches."""
+    M, N, K = 256, 320, 128
+    A, W = [f16(M, K), f16(M, K)], [f16(N, K, scale=0.2), f16(N, K, scale=0.2)]
+    o0, o1 = kb.zeros((M, N), np.float16), kb.zeros((M, N), np.float32)
+    e0, e1 = epilogue(o0), epilogue(o1)
+    ws = workspace(kb, 1024)
+    assert kb.lib.ea_gemm_f16_pair(ptr(A[0]), ptr(A[1]), K, ptr(W[0]), ptr(W[1]), K, M, N, K, C.byref(e0), C.byref(e1), ptr(ws),
+                                   ws_nbytes(ws), kb.stream) == 0
+    assert relerr(kb.down(o0), (t(A[0]) @ t(W[0]).T).numpy()) < 2e-3
+    assert relerr(kb.down(o1), (t(A[1]) @ t(W[1]).T).numpy()) < 2e-3

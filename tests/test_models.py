@@ -108,6 +108,43 @@ def test_fused_denoiser_equals_apply_model(tiny):
     assert torch.equal(e1, e2), "the fused path must be run-to-run deterministic"
 
 
+@pytest.mark.parametrize("gn_next", [False, True])
+def test_twin_trunk_equals_the_two_network_evaluation(tiny, gn_next):
+    """ControlledDenoiser(twin=True): the ControlNet trunk and the UNet encoder in lock step, every contraction of the pair
+    as ONE twin launch (ea_*_pair) == the evaluation that runs the two networks one after the other, and the golden of
+    ControlLDM.apply_model -- plain batch and the CFG batch with the shared prefix (one copy of the latents)."""
+    from editanything_amd import ops
+    from editanything_amd.unet import ControlledDenoiser
+    cn, un, _ = tiny
+    d = g("ldm_tiny_eval.npz")
+    ops.configure(gn_next=gn_next)
+    try:
+        outs = {}
+        for twin in (False, True):
+            den = ControlledDenoiser(un, [cn], overlap=False, twin=twin)
+            with torch.no_grad():
+                den.prepare(t(d["ctx"]).to(DEV), [t(d["hint"]).to(DEV)], [float(s) for s in d["scales"]])
+                e = den.eps(t(d["x"]).to(DEV), t(d["t"]).to(DEV))
+                # CFG batch: identical latents / hint / timestep in both halves, different text
+                x = t(d["x"]).to(DEV)[:1]
+                ctx2 = torch.cat([t(d["ctx"])[:1] * 0.5, t(d["ctx"])[:1]]).to(DEV)
+                hint2 = t(d["hint"])[:1].repeat(2, 1, 1, 1).to(DEV)
+                ts2 = t(d["t"])[:1].repeat(2).to(DEV)
+                den.prepare(ctx2, [hint2], [float(s) for s in d["scales"]])
+                embs = [tb[:1].clone() for tb in den.time_embeddings(ts2[:1])]
+                assert den.will_share_prefix(2, embs)
+                e_cfg = den.eps(x, ts2, embs=embs, cfg_halves=True, cfg_single=True)
+            outs[twin] = (e, e_cfg)
+        check(outs[True][0], d["eps_ctrl"])
+        for a, b in zip(outs[True], outs[False]):
+            assert tuple(a.shape) == tuple(b.shape)
+            assert rel_l2(a, b) <= 2e-3, f"twin vs sequential rel-L2 {rel_l2(a, b):.3e}"
+        print("twin vs sequential: rel-L2", [f"{rel_l2(a, b):.2e}" for a, b in zip(outs[True], outs[False])],
+              "bit-identical", [bool(torch.equal(a, b)) for a, b in zip(outs[True], outs[False])])
+    finally:
+        ops.configure(gn_next=True)
+
+
 def test_vae_vs_reference_golden(tiny):
     _, _, vae = tiny
     d = g("ldm_tiny_vae.npz")

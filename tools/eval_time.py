@@ -35,8 +35,8 @@ setup = round(time.time() - t0, 1)
 ref = None
 for spec in (sys.argv[1:] or ["base"]):
     name, _, kv = spec.partition(":")
-    opts = {k: v for k, v in (p.split("=") for p in kv.split(",") if p)}
-    ops.CONFIG.ln_fold, ops.CONFIG.gn_epilogue, ops.CONFIG.gn_next = True, True, False
+    opts = {k: v for k, v in (p.split("=") for p in kv.replace("+", ",").split(",") if p)}
+    ops.CONFIG.ln_fold, ops.CONFIG.gn_epilogue, ops.CONFIG.gn_next = True, True, True
     ops.configure(**{k: int(v) for k, v in opts.items() if k in OPS_KEYS})
     den = ControlledDenoiser(un, [cn], **{k: bool(int(v)) for k, v in opts.items() if k not in OPS_KEYS})
     with torch.no_grad():
