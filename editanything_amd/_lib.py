@@ -32,6 +32,7 @@ class Epilogue(C.Structure):
         ("ln_stats", _vp), ("ln_parts", C.c_int32), ("ln_colsum", _vp), ("ln_eps", C.c_float), ("row_stats_out", _vp),
         ("gn_stats_out", _vp), ("gn_rows_per_sample", C.c_int32), ("gn_cpg", C.c_int32),
         ("gn_next_out", _vp), ("gn_next_gamma", _vp), ("gn_next_beta", _vp), ("gn_next_eps", C.c_float), ("gn_next_silu", C.c_int32),
+        ("acc_scale_k", C.c_int32), ("acc_scale", C.c_float),
     ]
 
 
@@ -72,6 +73,9 @@ SIGNATURES = {
     "ea_gemm_f16_pair": (_i, [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, C.POINTER(Epilogue), C.POINTER(Epilogue), _vp, _sz, _vp]),
     "ea_conv2d_f16_pair": (_i, [C.POINTER(ConvSrc), C.POINTER(ConvSrc), _vp, _vp, _i, C.POINTER(Epilogue), C.POINTER(Epilogue),
                                 _vp, _sz, _vp]),
+    "ea_split3_f32": (_i, [_vp, _vp, _ll, _i, _i, _vp]),
+    "ea_layernorm_split3_f32": (_i, [_vp, _vp, _vp, _f, _vp, _i, _i, _vp, _vp]),
+    "ea_attention_exact_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _ll, _ll, _ll, _ll, _f, _vp, _vp, _i, _vp]),
     "ea_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "ea_groupnorm_f16": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ea_groupnorm_silu_conv3x3": (_i, [C.POINTER(ConvSrc), _vp, _vp, _i, _f, _vp, _vp, _i, C.POINTER(Epilogue),

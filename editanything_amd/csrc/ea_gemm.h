@@ -85,6 +85,8 @@ struct EaGemmParams {
   int raster_gm;   // ea_gemm3: tile rows per group of the grouped (L2-aware) tile order
   unsigned long long* prof;   // ea_gemm3 -DEA_G3_PROF builds only (tools/g3_prof): per-wave phase cycle totals; NULL in the product
   float* partial;  // [batch*splits][M][N] fp32 when splits > 1
+  int acc_scale_kt;   // K-concatenated split operands (ea_epilogue.acc_scale_k / 64): before K tile `acc_scale_kt` is
+  float acc_scale;    // accumulated, the accumulators are multiplied by acc_scale.  0 = off
   EaEpilogue epi;
 };
 

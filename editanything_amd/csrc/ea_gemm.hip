@@ -414,7 +414,9 @@ static bool same_launch(const FastSel& a, const FastSel& b) {
 // Plans the launch of p: fills the plan-dependent fields of p (split-K, partial buffer at workspace + ws_off, epilogue
 // form, tile order) and `s`.
 static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t ws_off, FastSel& s) {
-  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
+  // (an accumulator rescale at a K position -- acc_scale_kt -- needs the whole K range in one workgroup: no split-K)
+  Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU && p.acc_scale_kt == 0, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
+  if (p.acc_scale_kt > 0 && (t.splits != 1 || (t.kind != 1 && t.kind != 9))) return EA_ERR_UNSUPPORTED;
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
@@ -617,6 +619,7 @@ static int launch_fast(EaGemmParams& p, void* workspace, size_t ws_bytes, void* 
 static int launch_gemm(EaGemmParams& p, void* workspace, size_t ws_bytes, void* stream) {
   read_env();
   if (!g_force_generic && fast_eligible(p)) return launch_fast(p, workspace, ws_bytes, stream);
+  if (p.acc_scale_kt > 0) return EA_ERR_UNSUPPORTED;     // the K-position accumulator rescale lives in the LDS-DMA kernel only
   if (p.epi.act == EA_ACT_GEGLU && p.epi.geglu_block != 64) return EA_ERR_UNSUPPORTED;
   if (p.epi.ln_stats || p.epi.gn_stats_out || p.epi.gn_next_out) return EA_ERR_UNSUPPORTED;
   const int allow_split = (p.epi.act != EA_ACT_GEGLU);
@@ -779,6 +782,11 @@ static int setup_gemm(EaGemmParams& p, const void* A, int lda, const void* W, in
   p.M = M; p.N = N; p.K = K;
   p.batch = batch;
   p.strideA = strideA; p.strideW = strideW; p.strideC = strideC; p.strideR = strideR;
+  if (epi->acc_scale_k) {   // K-concatenated split operands
+    if (epi->acc_scale_k < 0 || epi->acc_scale_k >= K || (epi->acc_scale_k % EA_BK)) return EA_ERR_BAD_SHAPE;
+    p.acc_scale_kt = epi->acc_scale_k / EA_BK;
+    p.acc_scale = epi->acc_scale;
+  }
   return EA_OK;
 }
 

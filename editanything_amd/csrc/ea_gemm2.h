@@ -451,6 +451,16 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
       compute_tile(kt & 1, false, true);
 #else
       if (kt + 1 < nk && !EA_DBG(11) && !EA_DBG(12)) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
+      if (MT == 16 && p.acc_scale_kt > 0 && kt_begin + kt == p.acc_scale_kt) {
+        // K-concatenated split operands (ea_epilogue.acc_scale_k): the correction products are in, scale them (exactly:
+        // a power of two) before the hi x hi product is accumulated on top
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] *= p.acc_scale;
+      }
       if (!EA_DBG(10)) compute_tile(kt & 1);                         // debug 10: staging only
 #endif
     }

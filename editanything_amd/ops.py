@@ -288,7 +288,7 @@ def row_stats_buffer(M, N, like):
 
 
 def _gemm_prep(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
-               rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
+               rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None, acc_scale=None):
     """Checks, output allocation and the epilogue block of one dense contraction (one lane of a twin launch)."""
     _check_dev(a, w)
     _dense(a, residual, out)
@@ -308,20 +308,25 @@ def _gemm_prep(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype
     if ln_fold is not None:
         stats, colsum, eps = ln_fold
         e.ln_stats, e.ln_parts, e.ln_colsum, e.ln_eps = _p(stats), stats.shape[0], _p(colsum), float(eps)
+    if acc_scale is not None:
+        e.acc_scale_k, e.acc_scale = int(acc_scale[0]), float(acc_scale[1])
     nbytes = 2 * (M * K + N * K) + out.element_size() * M * n_out + (residual.element_size() * M * n_out if residual is not None else 0)
     return dict(a=a, w=w, M=M, N=N, K=K, out=out, e=e, flops=2.0 * M * N * K, nbytes=nbytes,
                 label=f"gemm M{M} N{N} K{K} act{act}{' res' if residual is not None else ''}")
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, residual=None, out=None, out_dtype=torch.float16, scale=1.0, rowvec=None,
-         rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None):
+         rows_per_group=1, row_scale=None, bias_per_row=False, row_stats=None, ln_fold=None, acc_scale=None):
     """out[M, N'] = epilogue(a[M, K] @ w[N, K]^T).  `a` may be any [..., K] contiguous tensor.
     row_stats: a `row_stats_buffer` to fill with the output rows' (sum, sum of squares) partials.
     ln_fold = (stats, colsum, eps): LayerNorm over a's rows folded into the contraction -- `w` carries gamma, `bias`
     carries W beta + b, `stats` are the partials the launch that produced `a` wrote.
+    acc_scale = (k, factor): K-concatenated split operands (sam_exact.py) -- the accumulators are multiplied by `factor` after
+    the first k columns of K.
     With `Pair` operands (two lanes of one shape): ONE twin launch, returns a Pair."""
     kw = dict(bias=bias, act=act, residual=residual, out=out, out_dtype=out_dtype, scale=scale, rowvec=rowvec,
-              rows_per_group=rows_per_group, row_scale=row_scale, bias_per_row=bias_per_row, row_stats=row_stats, ln_fold=ln_fold)
+              rows_per_group=rows_per_group, row_scale=row_scale, bias_per_row=bias_per_row, row_stats=row_stats, ln_fold=ln_fold,
+              acc_scale=acc_scale)
     if _has_pair((a, w)) or _has_pair(kw):
         g0, g1 = _gemm_prep(_lane(a, 0), _lane(w, 0), **_lane(kw, 0)), _gemm_prep(_lane(a, 1), _lane(w, 1), **_lane(kw, 1))
         if (g0["M"], g0["N"], g0["K"], g0["w"].stride(0)) != (g1["M"], g1["N"], g1["K"], g1["w"].stride(0)):
@@ -713,6 +718,48 @@ def sam_upscale_tail(u0, ln_g, ln_b, eps, w1, b1, hyper, B, h, w, m0=0, nm=4, ou
                                         _stream())
     L.check(st, "ea_sam_upscale_tail_f16")
     return masks
+
+
+def split3(x, act=ACT_NONE, out=None):
+    """fp32 [..., K] (act = ACT_GELU: exact erf GELU first) -> fp16 [..., 3K] rows [hi | lo | hi] (ea_split3_f32): the A operand
+    of an exact Linear (sam_exact.ExactLinear)."""
+    _check_dev(x)
+    _dense(x, out)
+    K = x.shape[-1]
+    M = x.numel() // K
+    if out is None:
+        out = torch.empty(x.shape[:-1] + (3 * K,), dtype=torch.float16, device=x.device)
+    L.check(_lib().ea_split3_f32(_p(x), _p(out), M, K, act, _stream()), "ea_split3_f32")
+    return out
+
+
+def layernorm_split3(x, gamma, beta, eps, out=None, rows=None):
+    """LayerNorm over the last dim of fp32 [M, C] fused in front of `split3`; `rows` (int32, device): row m lands in row
+    rows[m] of the pre-allocated `out` [R, 3C] (window_partition's layout; unwritten pad rows keep their zeros)."""
+    _check_dev(x, gamma)
+    _dense(x, out, rows)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    if out is None:
+        out = torch.empty((M, 3 * Cc), dtype=torch.float16, device=x.device)
+    L.check(_lib().ea_layernorm_split3_f32(_p(x), _p(gamma), _p(beta), float(eps), _p(out), M, Cc, _p(rows), _stream()),
+            "ea_layernorm_split3_f32")
+    return out
+
+
+def attention_exact(q, k, v, heads, dim_head, scale, bias_h=None, bias_w=None, S=0):
+    """fp32-accurate softmax(scale q k^T + bias) v (ea_attention_exact_f32): q / k / v fp32 [B, N, >= heads * dim_head] views
+    with one (batch, row) stride (slices of the fused qkv projection), bias tables fp32 [B * heads, N, S]. -> fp32 [B, N, heads * dim_head]."""
+    _check_dev(q, k, v)
+    B, N = q.shape[0], q.shape[1]
+    if not (q.stride() == k.stride() == v.stride()) or q.stride(-1) != 1:
+        raise ValueError("attention_exact: q / k / v must share their strides (slices of one projection)")
+    _dense(bias_h, bias_w)
+    out = torch.empty((B, N, heads * dim_head), dtype=torch.float32, device=q.device)
+    st = _lib().ea_attention_exact_f32(_p(q), _p(k), _p(v), _p(out), B, heads, N, dim_head, q.stride(0), q.stride(1), out.stride(0),
+                                       out.stride(1), float(scale), _p(bias_h), _p(bias_w), int(S), _stream())
+    L.check(st, f"ea_attention_exact_f32 B{B} H{heads} N{N} D{dim_head}")
+    return out
 
 
 def softmax_rows(x, scale):

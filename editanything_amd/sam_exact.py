@@ -7,13 +7,20 @@ compared with the fp32 oracle pixel for pixel (away from exact threshold ties: a
 moves a logit by ~1e-6).  `sam2image.create_demo(..., sam_precision="fp32")` selects it.
 
 MI355X mapping.  There is no fp32-input fast path on the matrix cores (the f32 MFMA runs at the vector rate, 157 TF), so
-the encoder's Linears -- 99 % of its FLOPs -- run as THREE fp16 MFMA GEMMs on split operands:
+every product of the encoder is built from fp16 MFMAs on SPLIT operands:
     x = x_hi + 2^-11 x_lo,  W = W_hi + 2^-11 W_lo        (hi = fp16(v), lo = fp16(2^11 (v - hi)): 22 mantissa bits, the
     x W^T ~= x_hi W_hi^T + 2^-11 (x_hi W_lo^T + x_lo W_hi^T)   low parts scaled so they never fall into fp16 denormals)
-through `ea_gemm_f16` with fp32 output and fp32 residual accumulation (products exact, fp32 accumulate; the dropped
-lo x lo term and the 22-bit split are ~2^-22 relative) -- ~1/3 of the fp16 rate, ~2x the f32-MFMA rate.  LayerNorm,
-GELU, the softmax(QK^T + rel-pos)V of the attention and the whole (small) decoder are plain fp32 torch expressions on the
-device, as upstream writes them.
+(products exact, fp32 accumulate; the dropped lo x lo term and the 22-bit split are ~2^-22 relative).  Since round 4 this is a
+kernel path (csrc/ea_exact.hip), not torch expressions:
+  * a Linear is ONE `ea_gemm_f16` launch over K-concatenated operands [x_hi | x_lo | x_hi] x [W_lo | W_hi | W_hi] whose fp32
+    accumulators are multiplied by 2^-11 after the first 2K columns (`ea_epilogue.acc_scale_k`), bias and the fp32 residual
+    added in the epilogue -- ~1/3 of the fp16 rate, ~2x the f32-MFMA rate;
+  * LayerNorm and the exact (erf) GELU are fused into the kernels that split the next Linear's operand
+    (`ea_layernorm_split3_f32` -- which also writes window_partition's layout -- and `ea_split3_f32`);
+  * softmax(q k^T / sqrt(d) + rel-pos) v is `ea_attention_exact_f32`: both products on split operands (the probabilities
+    are split too), the softmax in fp32, online -- no score matrix in memory.
+The decomposed rel-pos tables (two small fp32 einsums) and the whole (small) prompt / mask decoder stay fp32 torch expressions
+on the device, as upstream writes them.
 """
 import math
 
@@ -35,41 +42,61 @@ def _split(t):
 
 
 class ExactLinear:
-    """y = x W^T + b in fp32 accuracy on the fp16 matrix cores (three split-operand GEMMs)."""
+    """y = x W^T + b (+ fp32 residual) in fp32 accuracy on the fp16 matrix cores, ONE launch: A = [x_hi | x_lo | x_hi]
+    (ops.split3 / ops.layernorm_split3), W = [W_lo | W_hi | W_hi], the accumulators multiplied by 2^-11 after the first 2K
+    columns (ea_epilogue.acc_scale_k).  Shapes the LDS-DMA kernel does not take (K % 64 != 0, N < 64, M < 32) run the same
+    three products as three launches."""
 
     def __init__(self, w, b, dev):
         w = w.to(dev, torch.float32)
-        self.w_hi, self.w_lo = _split(w)
+        w_hi, w_lo = _split(w)
+        self.K = w.shape[1]
+        self.w3 = torch.cat([w_lo, w_hi, w_hi], dim=1).contiguous()          # [N, 3K]
         self.b = None if b is None else b.to(dev, torch.float32).contiguous()
         self.out_features = w.shape[0]
 
-    def __call__(self, x):
-        shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).float().contiguous()
-        x_hi, x_lo = _split(x2)
-        y = ops.gemm(x_hi, self.w_lo, None, scale=1.0 / _LO, out_dtype=torch.float32)                 # 2^-11 x_hi W_lo^T
-        y = ops.gemm(x_lo, self.w_hi, None, scale=1.0 / _LO, residual=y, out_dtype=torch.float32)     # + 2^-11 x_lo W_hi^T
-        y = ops.gemm(x_hi, self.w_hi, self.b, residual=y, out_dtype=torch.float32)                    # + x_hi W_hi^T + b
-        return y.view(shp[:-1] + (self.out_features,))
+    def __call__(self, x=None, a3=None, residual=None):
+        """x: fp32 [..., K]  |  a3: the already split fp16 [M, 3K] operand.  residual: fp32 [M, N], added in the epilogue."""
+        K, N = self.K, self.out_features
+        shp = None
+        if a3 is None:
+            shp = x.shape
+            a3 = ops.split3(x.reshape(-1, K).float().contiguous())
+        M = a3.shape[0]
+        if K % 64 == 0 and N >= 64 and M >= 32:
+            y = ops.gemm(a3, self.w3, self.b, residual=residual, out_dtype=torch.float32, acc_scale=(2 * K, 1.0 / _LO))
+        else:
+            x_hi, x_lo = a3[:, :K], a3[:, K:2 * K]
+            w_lo, w_hi = self.w3[:, :K], self.w3[:, K:2 * K]
+            xh, xl = x_hi.contiguous(), x_lo.contiguous()
+            y = ops.gemm(xh, w_lo, None, scale=1.0 / _LO, out_dtype=torch.float32)                     # 2^-11 x_hi W_lo^T
+            y = ops.gemm(xl, w_hi, None, scale=1.0 / _LO, residual=y, out_dtype=torch.float32)         # + 2^-11 x_lo W_hi^T
+            y = ops.gemm(xh, w_hi, self.b, residual=y, out_dtype=torch.float32)                        # + x_hi W_hi^T + b
+            if residual is not None:
+                y = y + residual
+        return y if shp is None else y.view(shp[:-1] + (N,))
 
 
-def _rel_pos_bias(q, rel_h, rel_w, S):
-    """add_decomposed_rel_pos: q [B, S*S, d] (unscaled) -> bias [B, S*S, S, S] = rel_h[..., None] + rel_w[..., None, :]."""
-    B, _, d = q.shape
+def _rel_pos_tables(q, rel_h, rel_w, S):
+    """add_decomposed_rel_pos in fp32: q [Bw, N, h, d] (unscaled, a view of the fused projection) ->
+    (bias_h, bias_w) [Bw * h, N, S]: bias[q][key] = bias_h[q][key / S] + bias_w[q][key % S]."""
+    Bw, N, h, d = q.shape
     idx = torch.arange(S, device=q.device)
     rel = idx[:, None] - idx[None, :] + (S - 1)
     Rh, Rw = rel_h[rel], rel_w[rel]                       # [S, S, d]
-    r_q = q.reshape(B, S, S, d)
-    bh = torch.einsum("bhwc,hkc->bhwk", r_q, Rh)
-    bw = torch.einsum("bhwc,wkc->bhwk", r_q, Rw)
-    return (bh[:, :, :, :, None] + bw[:, :, :, None, :]).reshape(B, S * S, S, S)
+    r_q = q.reshape(Bw, S, S, h, d)
+    bh = torch.einsum("bxyhc,xkc->bhxyk", r_q, Rh).reshape(Bw * h, N, S)
+    bw = torch.einsum("bxyhc,ykc->bhxyk", r_q, Rw).reshape(Bw * h, N, S)
+    return bh.contiguous(), bw.contiguous()
 
 
 class _BlockExact:
     def __init__(self, sd, p, dev, dim, heads, window, grid):
         self.heads, self.d, self.window = heads, dim // heads, window
         self.S = window if window > 0 else grid
-        f = lambda k: sd[p + k].to(dev, torch.float32)
+        if self.d not in (64, 80):
+            raise NotImplementedError(f"fp32-accurate attention: head dimension {self.d} (ViT-B / L: 64, ViT-H: 80)")
+        f = lambda k: sd[p + k].to(dev, torch.float32).contiguous()
         self.n1, self.n2 = (f("norm1.weight"), f("norm1.bias")), (f("norm2.weight"), f("norm2.bias"))
         self.qkv = ExactLinear(sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], dev)
         self.proj = ExactLinear(sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], dev)
@@ -78,34 +105,34 @@ class _BlockExact:
         self.lin1 = ExactLinear(sd[p + "mlp.lin1.weight"], sd[p + "mlp.lin1.bias"], dev)
         self.lin2 = ExactLinear(sd[p + "mlp.lin2.weight"], sd[p + "mlp.lin2.bias"], dev)
 
-    def forward(self, x):
+    def forward(self, x, maps):
+        """x: fp32 [B, H, W, D] residual stream (contiguous).  Block.forward of segment_anything: LayerNorm -> (windowed)
+        attention with decomposed rel-pos -> + residual -> LayerNorm -> MLP(GELU) -> + residual; every Linear an ExactLinear,
+        LayerNorm / GELU fused into the operand splits, the attention one fp32-accurate kernel."""
         B, H, W, D = x.shape
         ws, S, h, d = self.window, self.S, self.heads, self.d
-        xn = F.layer_norm(x, (D,), self.n1[0], self.n1[1], 1e-6)
+        xf = x.view(-1, D)
         if ws > 0:
-            ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
-            xn = F.pad(xn, (0, 0, 0, pw, 0, ph))
-            Hp, Wp = H + ph, W + pw
-            xn = xn.view(B, Hp // ws, ws, Wp // ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, D)
+            # norm1 writes straight into window_partition()'s layout (pad tokens are zeros AFTER the norm, as upstream pads)
+            rows, buf3, nwin, rows64 = maps(B, H, W, ws, D)
+            a3 = ops.layernorm_split3(xf, self.n1[0], self.n1[1], 1e-6, out=buf3, rows=rows)
+            Bw, N = nwin, ws * ws
         else:
-            xn = xn.view(B, H * W, D)
-        Bw, N, _ = xn.shape
-        qkv = self.qkv(xn).reshape(Bw, N, 3, h, d).permute(2, 0, 3, 1, 4).reshape(3, Bw * h, N, d)
-        q, k, v = qkv[0], qkv[1], qkv[2]
-        out = torch.empty_like(q)
-        step = max(1, (1 << 28) // (N * N * 4))             # bound the fp32 score matrix to ~256 MiB per chunk
-        for i in range(0, Bw * h, step):
-            qs = q[i:i + step]
-            attn = (qs * (d ** -0.5)) @ k[i:i + step].transpose(-2, -1)
-            attn = (attn.view(-1, N, S, S) + _rel_pos_bias(qs, self.rel_h, self.rel_w, S)).view(-1, N, N)
-            out[i:i + step] = torch.softmax(attn, dim=-1) @ v[i:i + step]
-        a = out.view(Bw, h, N, d).permute(0, 2, 1, 3).reshape(Bw, N, D)
-        pr = self.proj(a)
+            a3 = ops.layernorm_split3(xf, self.n1[0], self.n1[1], 1e-6)
+            Bw, N = B, H * W
+        qkv = self.qkv(a3=a3).view(Bw, N, 3 * D)                                       # [.., 3, h, d] fused projection, fp32
+        q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+        bh, bw = _rel_pos_tables(q.reshape(Bw, N, h, d), self.rel_h, self.rel_w, S)
+        a = ops.attention_exact(q, k, v, h, d, d ** -0.5, bh, bw, S)                    # fp32 [Bw, N, D]
+        a3 = ops.split3(a.view(-1, D))
         if ws > 0:
-            pr = pr.view(B, Hp // ws, Wp // ws, ws, ws, D).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, D)[:, :H, :W, :]
-        x = x + pr.reshape(B, H, W, D)
-        y = self.lin2(F.gelu(self.lin1(F.layer_norm(x, (D,), self.n2[0], self.n2[1], 1e-6))))
-        return x + y
+            pr = self.proj(a3=a3)                                                      # window rows
+            x = (xf + pr.index_select(0, rows64)).view(B, H, W, D)                # window_unpartition + residual
+        else:
+            x = self.proj(a3=a3, residual=xf).view(B, H, W, D)
+        xf = x.view(-1, D)
+        h1 = self.lin1(a3=ops.layernorm_split3(xf, self.n2[0], self.n2[1], 1e-6))
+        return self.lin2(a3=ops.split3(h1, act=ops.ACT_GELU), residual=xf).view(B, H, W, D)
 
 
 def _ln2d(x, w, b, eps=1e-6):
@@ -133,6 +160,22 @@ class ImageEncoderViTExact:
         self.ln1, self.ln2 = (f("neck.1.weight"), f("neck.1.bias")), (f("neck.3.weight"), f("neck.3.bias"))
         self.mean = torch.tensor(PIXEL_MEAN, device=dev).view(1, 3, 1, 1)
         self.std = torch.tensor(PIXEL_STD, device=dev).view(1, 3, 1, 1)
+        self._wmaps = {}
+
+    def _window_maps(self, B, H, W, ws, D):
+        """(token -> window-row map int32 [B*H*W], zero-initialised split-operand buffer fp16 [nwin*ws*ws, 3D], nwin), cached
+        per shape: the pad rows of the buffer are never written, so they stay zero (= the padded tokens after norm1)."""
+        key = (B, H, W, ws, D)
+        if key not in self._wmaps:
+            ny, nx = (H + ws - 1) // ws, (W + ws - 1) // ws
+            b = torch.arange(B).view(B, 1, 1)
+            y = torch.arange(H).view(1, H, 1)
+            xx = torch.arange(W).view(1, 1, W)
+            rows = ((b * ny + y // ws) * nx + xx // ws) * (ws * ws) + (y % ws) * ws + (xx % ws)
+            buf = torch.zeros(B * ny * nx * ws * ws, 3 * D, dtype=torch.float16, device=self.device)
+            rows = rows.reshape(-1).to(self.device)
+            self._wmaps[key] = (rows.to(torch.int32), buf, B * ny * nx, rows.long())
+        return self._wmaps[key]
 
     def preprocess(self, image):
         x = torch.as_tensor(np.ascontiguousarray(image))
@@ -147,9 +190,9 @@ class ImageEncoderViTExact:
         B = x.shape[0]
         g, ps, D = self.grid, self.cfg["patch_size"], self.cfg["embed_dim"]
         patches = x.to(self.device).view(B, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, g * g, 3 * ps * ps)
-        h = self.patch(patches).view(B, g, g, D) + self.pos
+        h = (self.patch(patches).view(B, g, g, D) + self.pos).contiguous()
         for blk in self.blocks:
-            h = blk.forward(h)
+            h = blk.forward(h, self._window_maps)
         n = self.neck0(h).permute(0, 3, 1, 2)                              # 1x1 conv, no bias
         n = _ln2d(n, *self.ln1)
         # 3x3, 256 -> 256 (0.3 % of the encoder's FLOPs) as im2col + the split-operand GEMM: an fp32 F.conv2d of this shape

@@ -111,6 +111,13 @@ typedef struct ea_epilogue {
   const float* gn_next_beta;    /* [N] */
   float gn_next_eps;
   int32_t gn_next_silu;
+  /* K-CONCATENATED SPLIT OPERANDS (the fp32-accurate SAM mode, sam_exact.py: an exact Linear as ONE launch).  With
+   * A = [x_hi | x_lo | x_hi] (ea_split3_f32) and W = [W_lo | W_hi | W_hi] the contraction accumulates the two correction
+   * products first; after `acc_scale_k` columns of K (a multiple of 64, 0 < acc_scale_k < K) the fp32 accumulators are
+   * multiplied by `acc_scale` (2^-11: exact), then the hi x hi product is added:  x W^T = 2^-11 (x_hi W_lo^T + x_lo W_hi^T)
+   * + x_hi W_hi^T.  Unsplit launches of the LDS-DMA kernel only (EA_ERR_UNSUPPORTED otherwise).  acc_scale_k = 0: off. */
+  int32_t acc_scale_k;
+  float acc_scale;
 } ea_epilogue;
 
 /* NHWC activation source for a convolution: channel-concat of x1 (c1 ch) and
@@ -185,6 +192,23 @@ int ea_gemm_f16_pair(const void* A0, const void* A1, int lda, const void* W0, co
                      const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream);
 int ea_conv2d_f16_pair(const ea_conv_src* src0, const ea_conv_src* src1, const void* W0, const void* W1, int Cout,
                        const ea_epilogue* epi0, const ea_epilogue* epi1, void* workspace, size_t ws_bytes, void* stream);
+
+/* ---- fp32-ACCURATE SAM (the reference never halves SAM: sam2image.py:69-70, editany_lora.py:87-94) on the fp16 matrix cores:
+ * v = hi + 2^-11 lo (hi = fp16(v), lo = fp16(2^11 (v - hi))), products from three fp16 MFMAs with fp32 accumulation.
+ * ea_split3_f32: x fp32 [M][K] (act = EA_ACT_GELU: exact erf GELU first, segment_anything MLPBlock) -> fp16 [M][3K] rows
+ * [hi | lo | hi], the A operand of a contraction with ea_epilogue.acc_scale_k = 2K.
+ * ea_layernorm_split3_f32: LayerNorm (fp32, segment_anything Block.norm1 / norm2, eps 1e-6) fused in front of that split;
+ * out_rows (nullable): row m lands in row out_rows[m] of `out` (negative = dropped) -- window_partition's layout.
+ * ea_attention_exact_f32: out = softmax(scale q k^T + bias_h[q][kh] + bias_w[q][kw]) v (segment_anything Attention.forward
+ * with add_decomposed_rel_pos), q / k / v / out fp32, element (b, i, h, d) at ptr + b*s_b + i*s_n + h*D + d; D in {64, 80};
+ * bias tables fp32 [B*H][N][S] (key j -> (j / S, j % S), S <= 64), both NULL = no bias.  Both products run on split
+ * operands (the probabilities are split too), the softmax in fp32, online: no score matrix in memory. */
+int ea_split3_f32(const float* x, void* out, long long M, int K, int act, void* stream);
+int ea_layernorm_split3_f32(const float* x, const float* gamma, const float* beta, float eps, void* out, int M, int C,
+                            const int* out_rows, void* stream);
+int ea_attention_exact_f32(const float* q, const float* k, const float* v, float* out, int B, int H, int N, int D,
+                           long long s_b, long long s_n, long long o_sb, long long o_sn, float scale,
+                           const float* bias_h, const float* bias_w, int S, void* stream);
 
 /* GroupNorm (+ optional SiLU) on NHWC fp16, statistics in fp32.
  * workspace: ea_groupnorm_workspace_bytes(B, HW, C, groups). */

@@ -1550,3 +1550,97 @@ def test_twin_launch_of_unequal_plans_falls_back_to_two_launches(kb):
                                    ws_nbytes(ws), kb.stream) == 0
     assert relerr(kb.down(o0), (t(A[0]) @ t(W[0]).T).numpy()) < 2e-3
     assert relerr(kb.down(o1), (t(A[1]) @ t(W[1]).T).numpy()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- fp32-accurate SAM kernels
+def _split_np(v):
+    hi = v.astype(np.float16)
+    lo = ((v - hi.astype(np.float32)) * 2048.0).astype(np.float16)
+    return hi, lo
+
+
+@pytest.mark.parametrize("M,N,K,res,act", [(200, 320, 128, False, 0), (128, 256, 256, True, 0), (72, 160, 64, False, 2)])
+def test_exact_linear_in_one_launch(kb, M, N, K, res, act):
+    """sam_exact.ExactLinear as ONE contraction: A = ea_split3_f32(x) = [x_hi | x_lo | x_hi], W = [W_lo | W_hi | W_hi],
+    accumulators multiplied by 2^-11 after 2K columns (ea_epilogue.acc_scale_k) -> x W^T + b (+ fp32 residual) to fp32
+    accuracy (<= 2e-6 of float64, magnitudes over four decades), incl. the exact-GELU form of the split."""
+    x = f32(M, K) * np.exp(RNG.uniform(-4, 4, size=(M, 1))).astype(np.float32)
+    W = f32(N, K, scale=0.3)
+    b = f32(N)
+    R = f32(M, N) if res else None
+    a3 = kb.zeros((M, 3 * K), np.float16)
+    assert kb.lib.ea_split3_f32(ptr(x), ptr(a3), M, K, act, kb.stream) == 0
+    xa = x.astype(np.float64)
+    if act == 2:
+        from scipy.special import erf
+        xa = 0.5 * xa * (1.0 + erf(xa / np.sqrt(2.0)))
+    got3 = kb.down(a3).astype(np.float64)
+    assert np.array_equal(got3[:, :K], got3[:, 2 * K:])
+    rec = got3[:, :K] + got3[:, K:2 * K] / 2048.0
+    assert np.abs(rec - xa).max() <= 3e-7 * max(1.0, np.abs(xa).max()) and relerr(rec, xa) < 3e-7
+    w_hi, w_lo = _split_np(W)
+    W3 = np.ascontiguousarray(np.concatenate([w_lo, w_hi, w_hi], axis=1))
+    out = kb.zeros((M, N), np.float32)
+    e = epilogue(out, bias=b, residual32=R)
+    e.acc_scale_k, e.acc_scale = 2 * K, 1.0 / 2048.0
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(a3), 3 * K, ptr(W3), 3 * K, M, N, 3 * K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    ref = xa @ W.astype(np.float64).T + b
+    if res:
+        ref = ref + R
+    err = np.abs(kb.down(out).astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, err
+    # a position that is not a multiple of the K tile, or a split launch, is refused -- never silently wrong
+    e.acc_scale_k = 2 * K + 8
+    assert kb.lib.ea_gemm_f16(ptr(a3), 3 * K, ptr(W3), 3 * K, M, N, 3 * K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) != 0
+
+
+def test_layernorm_split3(kb):
+    """ea_layernorm_split3_f32 == float64 LayerNorm to fp32 accuracy, rows scattered through an output row map (pad rows of
+    the window_partition layout are never written)."""
+    M, Cdim = 37, 1280
+    x = f32(M, Cdim) * 3.0 + 0.7
+    g, b = f32(Cdim), f32(Cdim)
+    rows = (np.arange(M) * 2 + 1).astype(np.int32)
+    rows[5] = -1
+    out = kb.zeros((2 * M + 2, 3 * Cdim), np.float16)
+    assert kb.lib.ea_layernorm_split3_f32(ptr(x), ptr(g), ptr(b), 1e-6, ptr(out), M, Cdim, ptr(rows), kb.stream) == 0
+    o = kb.down(out).astype(np.float64)
+    xd = x.astype(np.float64)
+    ref = (xd - xd.mean(1, keepdims=True)) / np.sqrt(xd.var(1, keepdims=True) + 1e-6) * g + b
+    written = np.zeros(2 * M + 2, bool)
+    for m in range(M):
+        if rows[m] < 0:
+            continue
+        written[rows[m]] = True
+        rec = o[rows[m], :Cdim] + o[rows[m], Cdim:2 * Cdim] / 2048.0
+        assert np.abs(rec - ref[m]).max() < 2e-6 * np.abs(ref).max()
+        assert np.array_equal(o[rows[m], :Cdim], o[rows[m], 2 * Cdim:])
+    assert not o[~written].any()
+
+
+@pytest.mark.parametrize("B,H,N,D,S", [(1, 2, 196, 80, 14), (2, 1, 100, 64, 10), (1, 1, 70, 80, 0), (1, 1, 256, 64, 16)])
+def test_attention_exact(kb, B, H, N, D, S):
+    """ea_attention_exact_f32 (split-operand MFMAs for q k^T AND p v, fp32 online softmax, decomposed rel-pos bias) ==
+    float64 softmax attention to fp32 accuracy; q / k / v are slices of one fused [B, N, 3, H, D] fp32 projection."""
+    qkv = f32(B, N, 3, H, D) * 2.0
+    scale = D ** -0.5
+    bh = bw = None
+    if S:
+        bh, bw = f32(B * H, N, S), f32(B * H, N, S)
+    out = kb.zeros((B, N, H * D), np.float32)
+    base = kb.up(qkv) if kb.name == "gpu" else qkv
+    addr = base.data_ptr() if kb.name == "gpu" else ptr(qkv)
+    st = kb.lib.ea_attention_exact_f32(addr, addr + 4 * H * D, addr + 8 * H * D, ptr(out), B, H, N, D, N * 3 * H * D, 3 * H * D,
+                                       N * H * D, H * D, scale, ptr(bh), ptr(bw), S, kb.stream)
+    assert st == 0
+    q, k, v = (qkv[:, :, i].transpose(0, 2, 1, 3).astype(np.float64) for i in range(3))          # [B, H, N, D]
+    s = np.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    if S:
+        kk = np.arange(N)
+        s = s + bh.reshape(B, H, N, S).astype(np.float64)[..., kk // S] + bw.reshape(B, H, N, S).astype(np.float64)[..., kk % S]
+    pm = np.exp(s - s.max(-1, keepdims=True))
+    pm /= pm.sum(-1, keepdims=True)
+    ref = np.einsum("bhqk,bhkd->bhqd", pm, v).transpose(0, 2, 1, 3).reshape(B, N, H * D)
+    err = np.abs(kb.down(out).astype(np.float64) - ref).max() / np.abs(ref).max()
+    assert err < 3e-6, err
