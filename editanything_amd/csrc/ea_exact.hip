@@ -121,25 +121,33 @@ struct ExAttnParams {
   int S;
 };
 
-// Workgroup = 4 waves x 32 queries; key tiles of 32 staged in LDS as fp32.  Everything is computed TRANSPOSED so that a lane
-// owns ONE query: S^T = K Q^T (v_mfma_f32_32x32x16_f16: lane (q = lane % 32, half = lane / 32) holds the 16 keys
+// Workgroup = 4 waves x 32 queries; key tiles of 32.  Everything is computed TRANSPOSED so that a lane owns ONE query:
+// S^T = K Q^T (v_mfma_f32_32x32x16_f16: lane (q = lane % 32, half = lane / 32) holds the 16 keys
 // key(r) = (r & 3) + 8 (r >> 2) + 4 half of its query -- row max and row sum are 16 in-lane values + one cross-half shuffle),
 // O^T = V^T P^T with the keys of a k-step taken in exactly that order on both operands (a sum over keys does not care).
+// A K / V tile is split into hi / lo ONCE per workgroup, on its way from registers (the next tile's global loads are in
+// flight while the current one is computed) into LDS: K as [key][d] rows, V transposed as [d][key position] with the keys
+// in the order the P^T operand holds them, so every MFMA fragment of the loop is one 16-byte LDS read.
 template <int D>
-__global__ __launch_bounds__(256) void ea_attn_exact_kernel(ExAttnParams p) {
+__global__ __launch_bounds__(256, 2) void ea_attn_exact_kernel(ExAttnParams p) {
   constexpr int KS = D / 16;          // k-steps of S^T
   constexpr int DT = (D + 31) / 32;   // 32-row tiles of O^T (value dimension, zero-padded)
-  constexpr int LDK = D + 4;          // LDS row stride in floats
+  constexpr int LDK = D + 8;          // K rows: halfs per row (16-byte aligned rows, skewed banks)
+  constexpr int LDV = 40;             // V^T rows: 32 key positions + 8 halfs
+  constexpr int C4 = D / 4;           // float4 pieces per row
+  constexpr int NLD = (32 * C4 + 255) / 256;   // pieces per thread
   static_assert(D % 16 == 0, "head dimension");
   EA_SMEM(smem);
-  float* Ks = reinterpret_cast<float*>(smem);
-  float* Vs = Ks + 32 * LDK;
-  float* Tb = Vs + 32 * LDK;          // [128][2 S] bias rows of this workgroup's queries
+  f16* KsH = reinterpret_cast<f16*>(smem);
+  f16* KsL = KsH + 32 * LDK;
+  f16* VtH = KsL + 32 * LDK;          // [32 DT][LDV]
+  f16* VtL = VtH + 32 * DT * LDV;
+  float* Tw = reinterpret_cast<float*>(VtL + 32 * DT * LDV);   // [128][2 (S + 1)]: bias_h | bias_w rows of this workgroup's queries
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, half = lane >> 5;
   const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
   const int N = p.N, S = p.S;
-  const int qw = blockIdx.x * 128;                 // first query of the workgroup
+  const int qw = blockIdx.x * 128;                    // first query of the workgroup
   const int qi = ex_min(qw + wave * 32 + l31, N - 1); // this lane's query (clamped: rows past N are computed and dropped)
   const float* qb = p.q + (long long)b * p.s_b + (long long)h * D;
   const float* kb = p.k + (long long)b * p.s_b + (long long)h * D;
@@ -160,45 +168,79 @@ __global__ __launch_bounds__(256) void ea_attn_exact_kernel(ExAttnParams p) {
       }
     }
   }
+  // S % 32 == 0 (the global 64 x 64 grid): the 32 keys of a tile lie in ONE key row, so bias_h is one value per (query,
+  // tile) -- read from global (the lane's own row, L1-resident) and only bias_w needs LDS: two workgroups fit a CU
+  const bool hsame = S > 0 && (S & 31) == 0;
+  const int TS = hsame ? S + 1 : 2 * (S + 1) + 1;     // odd row stride: the lanes of a wave read their own rows conflict-free
+  const int WOFF = hsame ? 0 : S + 1;
+  const float* bhrow = p.bias_h ? p.bias_h + ((long long)bh * N + qi) * S : nullptr;
   if (p.bias_h) {
     for (int idx = tid; idx < 128 * 2 * S; idx += 256) {
       const int ql = idx / (2 * S), c = idx - ql * 2 * S;
-      const long long row = (long long)bh * N + ex_min(qw + ql, N - 1);
-      Tb[idx] = c < S ? p.bias_h[row * S + c] : p.bias_w[row * S + (c - S)];
+      const long long row = ((long long)bh * N + ex_min(qw + ql, N - 1)) * S;
+      if (c >= S) Tw[ql * TS + WOFF + (c - S)] = p.bias_w[row + (c - S)];
+      else if (!hsame) Tw[ql * TS + c] = p.bias_h[row + c];
     }
   }
+  // zero the value rows past D once (D = 80: rows 80..95 of the third O^T tile)
+  for (int idx = tid; idx < (32 * DT - D) * LDV; idx += 256) { VtH[D * LDV + idx] = (f16)0.0f; VtL[D * LDV + idx] = (f16)0.0f; }
   f32x16 om[DT], oc[DT];
 #pragma unroll
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { om[t][r] = 0.0f; oc[t][r] = 0.0f; }
   float m_run = -1.0e30f, l_run = 0.0f;
-  const float* tb = Tb + (wave * 32 + l31) * 2 * S;
+  const float* tw = Tw + (wave * 32 + l31) * TS;
+  // uniform part of the (key / S, key % S) walk: key(r) = kt + (r & 3) + 8 (r >> 2) + 4 half
+  const int q32 = S ? 32 / S : 0, r32 = S ? 32 - q32 * S : 0;
+  int khb = 0, kwb = 0;                               // kt / S, kt % S
 
+  f32x4 kreg[NLD], vreg[NLD];
+  auto fetch = [&](int kt) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < 32 * C4) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        const long long off = (long long)ex_min(kt + r, N - 1) * p.s_n + 4 * c4;
+        kreg[u] = *reinterpret_cast<const f32x4*>(kb + off);
+        vreg[u] = *reinterpret_cast<const f32x4*>(vb + off);
+      }
+    }
+  };
+  fetch(0);
   for (int kt = 0; kt < N; kt += 32) {
-    __syncthreads();                                   // the previous tile's readers are done (and Tb is written)
-    for (int idx = tid; idx < 32 * (D / 4); idx += 256) {
-      const int r = idx / (D / 4), c4 = idx - r * (D / 4);
-      const long long off = (long long)ex_min(kt + r, N - 1) * p.s_n + 4 * c4;
-      *reinterpret_cast<f32x4*>(Ks + r * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(kb + off);
-      *reinterpret_cast<f32x4*>(Vs + r * LDK + 4 * c4) = *reinterpret_cast<const f32x4*>(vb + off);
+    __syncthreads();                                   // the previous tile's readers are done (first pass: Tw / the zero rows are written)
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int idx = tid + 256 * u;
+      if (idx < 32 * C4) {
+        const int r = idx / C4, c4 = idx - r * C4;
+        // position of key r in the P^T operand order: r = (j & 3) + 8 (rr >> 2) + 4 half with rr = 8 t + j  ->  (2 t + half) * 8 + j
+        const int hv = (r >> 2) & 1, rr = (r & 3) + 4 * (r >> 3), pos = (2 * (rr >> 3) + hv) * 8 + (rr & 7);
+        f16x4 kh4, kl4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          f16 x, y;
+          ex_split(kreg[u][j], x, y); kh4[j] = x; kl4[j] = y;
+          ex_split(vreg[u][j], x, y);
+          VtH[(4 * c4 + j) * LDV + pos] = x;
+          VtL[(4 * c4 + j) * LDV + pos] = y;
+        }
+        *reinterpret_cast<f16x4*>(KsH + r * LDK + 4 * c4) = kh4;
+        *reinterpret_cast<f16x4*>(KsL + r * LDK + 4 * c4) = kl4;
+      }
     }
     __syncthreads();
+    if (kt + 32 < N) fetch(kt + 32);                   // in flight under this tile's MFMAs
     // ---- S^T = K Q^T on split operands
     f32x16 sm, sc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sm[r] = 0.0f; sc[r] = 0.0f; }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(Ks + l31 * LDK + 16 * ks + 8 * half);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(Ks + l31 * LDK + 16 * ks + 8 * half + 4);
-      f16x8 khi, klo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f16 x, y;
-        ex_split(a[j], x, y); khi[j] = x; klo[j] = y;
-        ex_split(c[j], x, y); khi[4 + j] = x; klo[4 + j] = y;
-      }
+      const f16x8 khi = *reinterpret_cast<const f16x8*>(KsH + l31 * LDK + 16 * ks + 8 * half);
+      const f16x8 klo = *reinterpret_cast<const f16x8*>(KsL + l31 * LDK + 16 * ks + 8 * half);
       sm = ea_mfma_32x32x16(khi, qhi[ks], sm);
       sc = ea_mfma_32x32x16(khi, qlo[ks], sc);
       sc = ea_mfma_32x32x16(klo, qhi[ks], sc);
@@ -206,18 +248,28 @@ __global__ __launch_bounds__(256) void ea_attn_exact_kernel(ExAttnParams p) {
     // ---- scores of this lane's query against its 16 keys of the tile: scale, bias, mask, online softmax (fp32)
     float s[16];
     float tmax = -1.0e30f;
+    const float bh_tile = hsame ? bhrow[ex_min(khb, S - 1)] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int koff = (r & 3) + 8 * (r >> 2) + 4 * half;
       float x = (sm[r] + sc[r] * EX_ILO) * p.scale;
       if (p.bias_h) {
-        const int kh = key / S;
-        x += tb[ex_min(kh, S - 1)] + tb[S + (key - kh * S)];
+        if (hsame) {
+          x += bh_tile + tw[kwb + koff];                       // kwb in {0, 32, ...}, koff < 32: no wrap
+        } else {
+          int kwu = kwb + (r & 3) + 8 * (r >> 2), khu = khb;   // wave-uniform part of (key / S, key % S): scalar arithmetic
+          while (kwu >= S) { kwu -= S; ++khu; }
+          int kw = kwu + 4 * half, kh = khu;                   // S > 4: one more wrap at most
+          if (kw >= S) { kw -= S; ++kh; }
+          x += tw[ex_min(kh, S - 1)] + tw[WOFF + kw];
+        }
       }
-      if (key >= N) x = -1.0e30f;
+      if (kt + koff >= N) x = -1.0e30f;
       s[r] = x;
       tmax = fmaxf(tmax, x);
     }
+    khb += q32; kwb += r32;
+    if (kwb >= S && S) { kwb -= S; ++khb; }
     tmax = fmaxf(tmax, ea_shfl_xor(tmax, 32));
     const float m_new = fmaxf(m_run, tmax);
     const float alpha = expf(m_run - m_new);
@@ -226,39 +278,28 @@ __global__ __launch_bounds__(256) void ea_attn_exact_kernel(ExAttnParams p) {
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { om[t][r] *= alpha; oc[t][r] *= alpha; }
-    f16 ph[16], pl[16];
+    f16x8 pbh[2], pbl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float pr = s[r] <= -1.0e29f ? 0.0f : expf(s[r] - m_new);
       l_run += pr;
-      ex_split(pr, ph[r], pl[r]);
+      f16 x, y;
+      ex_split(pr, x, y);
+      pbh[r >> 3][r & 7] = x;
+      pbl[r >> 3][r & 7] = y;
     }
     m_run = m_new;
-    // ---- O^T += V^T P^T, keys of k-step t in the order the score tile left them in this lane's registers
+    // ---- O^T += V^T P^T: k-step t takes the keys in the order they sit in this lane's score registers
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f16x8 pbh, pbl;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { pbh[j] = ph[8 * t + j]; pbl[j] = pl[8 * t + j]; }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int dv = 32 * dt + l31;
-        f16x8 vhi, vlo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int r = 8 * t + j;
-          const int kr = (r & 3) + 8 * (r >> 2) + 4 * half;
-          const float val = dv < D ? Vs[kr * LDK + dv] : 0.0f;
-          f16 x, y;
-          ex_split(val, x, y);
-          vhi[j] = x;
-          vlo[j] = y;
-        }
-        om[dt] = ea_mfma_32x32x16(vhi, pbh, om[dt]);
-        oc[dt] = ea_mfma_32x32x16(vhi, pbl, oc[dt]);
-        oc[dt] = ea_mfma_32x32x16(vlo, pbh, oc[dt]);
+        const f16x8 vhi = *reinterpret_cast<const f16x8*>(VtH + (32 * dt + l31) * LDV + (2 * t + half) * 8);
+        const f16x8 vlo = *reinterpret_cast<const f16x8*>(VtL + (32 * dt + l31) * LDV + (2 * t + half) * 8);
+        om[dt] = ea_mfma_32x32x16(vhi, pbh[t], om[dt]);
+        oc[dt] = ea_mfma_32x32x16(vhi, pbl[t], oc[dt]);
+        oc[dt] = ea_mfma_32x32x16(vlo, pbh[t], oc[dt]);
       }
-    }
   }
   const float l = l_run + ea_shfl_xor(l_run, 32);
   const float inv = 1.0f / l;
@@ -281,7 +322,7 @@ __global__ __launch_bounds__(256) void ea_attn_exact_kernel(ExAttnParams p) {
 
 template <int D>
 static int launch_exact(const ExAttnParams& p, void* stream) {
-  const int smem = (2 * 32 * (D + 4) + (p.bias_h ? 128 * 2 * p.S : 0)) * 4;
+  const int smem = (2 * 32 * (D + 8) + 2 * 32 * ((D + 31) / 32) * 40) * 2 + (p.bias_h ? 128 * ((p.S & 31) == 0 ? p.S + 1 : 2 * (p.S + 1) + 1) * 4 : 0);
   auto kfn = ea_attn_exact_kernel<D>;
   ea_allow_big_lds(kfn, smem);
   EA_LAUNCH(kfn, dim3((p.N + 127) / 128, p.B * p.H, 1), dim3(256), smem, stream, p);
@@ -321,7 +362,7 @@ extern "C" int ea_attention_exact_f32(const float* q, const float* k, const floa
   if ((s_n & 3) || (s_b & 3) || (o_sn & 3) || (o_sb & 3)) return EA_ERR_BAD_SHAPE;
   if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return EA_ERR_BAD_ARG;
   if ((bias_h == nullptr) != (bias_w == nullptr)) return EA_ERR_BAD_ARG;
-  if (bias_h && (S <= 0 || S > 64 || (long long)S * S < N)) return EA_ERR_BAD_SHAPE;
+  if (bias_h && (S <= 4 || S > 64 || (long long)S * S < N)) return EA_ERR_BAD_SHAPE;
   ExAttnParams p{q, k, v, out, B, H, N, s_b, s_n, o_sb, o_sn, scale, bias_h, bias_w, bias_h ? S : 0};
   if (D == 64) return launch_exact<64>(p, stream);
   if (D == 80) return launch_exact<80>(p, stream);

@@ -1619,7 +1619,7 @@ def test_layernorm_split3(kb):
     assert not o[~written].any()
 
 
-@pytest.mark.parametrize("B,H,N,D,S", [(1, 2, 196, 80, 14), (2, 1, 100, 64, 10), (1, 1, 70, 80, 0), (1, 1, 256, 64, 16)])
+@pytest.mark.parametrize("B,H,N,D,S", [(1, 2, 196, 80, 14), (2, 1, 100, 64, 10), (1, 1, 70, 80, 0), (1, 1, 256, 64, 16), (1, 1, 1024, 80, 32)])
 def test_attention_exact(kb, B, H, N, D, S):
     """ea_attention_exact_f32 (split-operand MFMAs for q k^T AND p v, fp32 online softmax, decomposed rel-pos bias) ==
     float64 softmax attention to fp32 accuracy; q / k / v are slices of one fused [B, N, 3, H, D] fp32 projection."""
