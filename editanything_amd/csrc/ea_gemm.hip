@@ -3,6 +3,9 @@
 #ifndef EA_TOOLS
 #define EA_TOOLS 0
 #endif
+#ifndef EA_EXP
+#define EA_EXP 0
+#endif
 #if EA_TOOLS
 #include "../../tools/kernels/ea_gemm3.h"   // the persistent-kernel experiment of round 3 (measured slower; tools build only)
 #endif
@@ -463,6 +466,24 @@ static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t
     // grouped: SAM MLP [16384 x 5120 x 1280] 305 -> 269 us, GEGLU [2048 x 10240 x 1280] 77 -> 63 us; the K = 320 GEGLU
     // projection, whose 1.6-MB weight is L2 resident, LOSES 6 % and keeps the row-major order)
     if (!(EA_TOOLS && g_tune.debug == 20) && tiles_n > 8 && tiles_m >= 16 && (long long)p.N * p.K * 2 > (3ll << 20)) p.raster_gm = 8;   // debug 20: row-major everywhere (A/B)
+#if !(EA_EXP & 32)
+    // XCD-PARTITIONED TILES for the weight-heavy launches of the 16 x 16 / 8 x 8 levels.  Row-major order deals every XCD a
+    // few row tiles x ALL column panels: each of the 8 L2s pulls the whole weight matrix (5-10x the algorithmic fabric-side
+    // bytes, profiles/r03_pmc_traffic.json).  Grouped order with gm row tiles per group makes an XCD's chunk gm rows x
+    // (chunk / gm) column panels: a weight panel crosses the fabric tiles_m / gm times instead of 8, while the A rows of
+    // the group (re-read once per tap by a 3x3 convolution) still fit its 4-MiB L2 -- gm = all rows (pure column-major)
+    // at M = 512, 8 of 16 row tiles for conv3x3 16 x 16 1280 -> 1280 (a 2 x 4 XCD grid).
+    else if (!(EA_TOOLS && g_tune.debug == 20) && tiles_n >= 8 && tiles_m > 1 && p.batch == 1) {
+      const long long wbytes = (long long)p.N * p.K * 2;
+      const long long abytes = p.conv ? (long long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * (p.c1 + p.c2) * 2 : (long long)p.M * p.K * 2;
+      if (wbytes >= 2 * abytes) {
+        const long long a_tile = abytes / tiles_m > 0 ? abytes / tiles_m : 1;
+        long long gm = (5ll << 19) / a_tile;                 // ~2.5 MiB of A per XCD-resident row group
+        if (gm > tiles_m) gm = tiles_m;
+        if (gm > 1) p.raster_gm = (int)gm;
+      }
+    }
+#endif
   }
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows

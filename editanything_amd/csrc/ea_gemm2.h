@@ -112,7 +112,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
   // integer division runs on the vector ALU: mark the quotients wave-uniform so everything derived from them
   // (K position, descriptors, scalar offsets) stays in SGPRs -- otherwise every DMA is wrapped in a waterfall loop (T20)
   int tm = ea_uniform(tile / tiles_n), tn = tile - tm * tiles_n;
-  if (p.raster_gm > 1) {   // wide-N launches: grouped order, so an XCD's resident tiles share W column panels too
+  if (p.raster_gm > 1) {   // grouped order: an XCD's contiguous chunk of tiles (ea_xcd_remap) covers few W column panels x raster_gm row tiles
     int unused;
     ea_grouped_item(tile, ntile / tiles_n, tiles_n, p.raster_gm, tm, tn, unused);
     tm = ea_uniform(tm);
