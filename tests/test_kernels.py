@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from emu_util import conv_src, epilogue, ptr, relerr
 
 
-TOOLS_ONLY_VARIANTS = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13}   # opt-in instantiations: EA_TOOLS builds only (ea_gemm2.h)
+TOOLS_ONLY_VARIANTS = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 22, 23, 24}   # opt-in instantiations: EA_TOOLS builds only (ea_gemm2.h; 20-23: tools/kernels/ea_gemm3.h)
 
 
 def tune(kb, **fields):
