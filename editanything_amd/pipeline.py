@@ -523,7 +523,7 @@ class StableDiffusionControlNetInpaintPipeline:
                 # are per-call state, so it is not cached across calls); the noise level comes from a static tensor.
                 a_t = float(sch.alphas_cumprod[int(timesteps[i])])
                 ref_ctx["coef"].copy_(torch.tensor([a_t ** 0.5, (1.0 - a_t) ** 0.5], dtype=torch.float32))
-                if self.use_graph and not step_noise and not in_loop_blend:
+                if self.use_graph and not step_noise and not in_loop_blend and ref_state.graph_safe:
                     if ref_ctx["graph"] is None:
                         ref_ctx["graph"] = self._capture(st, ref_ctx)
                     ref_ctx["graph"].replay()

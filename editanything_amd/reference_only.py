@@ -173,6 +173,14 @@ class ReferenceOnly:
             self.controlnet.ref = None
         self.mode = None
 
+    @property
+    def graph_safe(self):
+        """Can a step under this control be captured into a HIP graph?  Only when every feature-map size the networks present
+        was pre-seeded by `_prepare_masks` -- latent sizes divisible by 8 (the stride-2 convolutions of other sizes produce
+        ceil()-sized levels, whose first `_mask_sel` would synchronise inside the capture): such calls run eagerly."""
+        h8, w8 = self.ref_mask.shape[-2:]
+        return h8 % 8 == 0 and w8 % 8 == 0
+
     def _prepare_masks(self):
         """Mask selections for every feature-map size the networks can present (latent size / 1, 2, 4, 8), for both masks,
         up front: `torch.nonzero` synchronises, and a size first seen inside a HIP-graph capture would abort it."""

@@ -205,6 +205,11 @@ def test_device_generate_vs_oracle(device_decoder):
     assert checked > 0 and matched >= 0.9 * checked, (matched, checked)
     for g in got:
         assert g["area"] == int(g["segmentation"].sum()) and g["segmentation"].dtype == np.bool_
+    # decode_batch (this implementation's memory knob: prompts per decoder call) does not change a result: prompts are independent
+    small = SamAutomaticMaskGenerator(None, device_decoder, decode_batch=5, **cfg).generate(img, image_embedding=emb)
+    assert len(small) == len(got)
+    for a, b in zip(small, got):
+        assert a["point_coords"] == b["point_coords"] and a["bbox"] == b["bbox"] and np.array_equal(a["segmentation"], b["segmentation"])
 
 
 @gpu
