@@ -209,9 +209,9 @@ def test_device_generate_vs_oracle(device_decoder):
     small = SamAutomaticMaskGenerator(None, device_decoder, decode_batch=5, **cfg).generate(img, image_embedding=emb)
     # (to the rounding of a differently planned launch: the same prompts survive, with the same masks up to threshold ties)
     assert abs(len(small) - len(got)) <= 1
-    by_point = {tuple(np.round(np.ravel(g["point_coords"]), 3)): g for g in got}
-    same = [(a, by_point.get(tuple(np.round(np.ravel(a["point_coords"]), 3)))) for a in small]
-    assert sum(b is not None and _iou(a["segmentation"], b["segmentation"]) >= 0.99 for a, b in same) >= len(small) - 1
+    hit = sum(any(np.allclose(a["point_coords"], b["point_coords"], atol=1e-3) and _iou(a["segmentation"], b["segmentation"]) >= 0.99
+                  for b in got) for a in small)
+    assert hit >= len(small) - 1, (hit, len(small))
 
 
 @gpu
