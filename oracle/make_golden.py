@@ -554,8 +554,48 @@ def gen_pipeline():
                         hint2=inp["hint2"].numpy(), smap=inp["smap"].numpy(), **out)
 
 
+def tile_inputs():
+    """Inputs of the tile-refinement golden: three seeded 128 x 128 uint8 images (each is its own conditioning image, as in
+    editany_lora.py:885-936), one mask, the tiny prompt embeddings."""
+    from PIL import Image
+    d = np.load(os.path.join(GOLD, "ldm_tiny_ddim.npz"))
+    rng = np.random.default_rng(3)
+    imgs = rng.integers(0, 256, size=(3, 8, 8, 3)).astype(np.uint8).repeat(16, 1).repeat(16, 2)
+    mask = np.zeros((128, 128), np.uint8)
+    mask[24:104, 40:120] = 255
+    kw = dict(prompt_embeds=torch.from_numpy(d["ctx"])[:1], negative_prompt_embeds=torch.from_numpy(d["un_ctx"])[:1],
+              num_inference_steps=4, height=128, width=128, controlnet_conditioning_scale=1.0, alignment_ratio=0.75,
+              guidance_scale=7.5, output_type="latent")
+    return imgs, Image.fromarray(mask), kw
+
+
+def gen_tile():
+    """Tile-ControlNet refinement as the reference runs it (editany_lora.py:885-936): ONE pipeline call per sample, all
+    drawing from the same generator (per call: initial latents, then the VAE posterior noise) -- the reference's own
+    `__call__` executed from source; the product's batched call must reproduce the stacked results."""
+    from PIL import Image
+    from oracle import ref_pipeline
+    nets = pipe_nets()
+    imgs, mask, kw = tile_inputs()
+    pipe = ref_pipeline.inpaint_pipeline([nets["cn"]], nets["unet"], nets["vae"])
+    gen = torch.Generator("cpu").manual_seed(77)
+    outs = []
+    with torch.no_grad():
+        for i in range(len(imgs)):
+            im = Image.fromarray(imgs[i])
+            outs.append(pipe(image=im, mask_image=mask, controlnet_conditioning_image=im, num_images_per_prompt=1, generator=gen, **kw).images)
+    lat = torch.cat(outs).numpy()
+    assert np.isfinite(lat).all() and np.abs(lat[0] - lat[1]).max() > 0.1
+    np.savez_compressed(os.path.join(GOLD, "pipe_tile.npz"), latents=lat)
+    print("tile refinement golden:", lat.shape)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if "--tile" in sys.argv:
+        ref_import.load()
+        gen_tile()
+        sys.exit(0)
     if "--sam-boxes" in sys.argv:
         gen_sam_boxes()
         sys.exit(0)

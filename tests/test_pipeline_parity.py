@@ -149,6 +149,33 @@ def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny):
     assert all(np.array_equal(a, o.images) for o in b)
 
 
+def test_batched_tile_refinement_vs_the_reference_one_call_per_sample(mg, tiny):
+    """editany_lora.py:885-936 refines the samples one pipeline call at a time, every call drawing from the same generator
+    (initial latents, then the VAE posterior noise).  tests/golden/pipe_tile.npz holds what the reference's OWN `__call__`
+    (oracle/ref_pipeline.py, executed from source; oracle/make_golden.py --tile) produces for three such calls; the product
+    refines the three samples as ONE batched call fed the same draws (`editany_lora.draw_call_noise`) and must land on
+    them: in-loop blending (alignment_ratio 0.75), CFG, PIL image = its own conditioning image."""
+    from PIL import Image
+    from editanything_amd import editany_lora as el
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+    imgs, mask, kw = mg.tile_inputs()
+    ref = np.load(os.path.join(GOLD, "pipe_tile.npz"))["latents"]
+    pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, "unet", ["cn"], True)
+    n = len(imgs)
+    gen = torch.Generator("cpu").manual_seed(77)
+    lat, vn = el.draw_call_noise(gen, n, (1, 4, 16, 16), DEV)
+    bkw = dict(kw, prompt_embeds=kw["prompt_embeds"].repeat(n, 1, 1), negative_prompt_embeds=kw["negative_prompt_embeds"].repeat(n, 1, 1))
+    got = pipe(image=imgs, mask_image=mask, controlnet_conditioning_image=imgs, num_images_per_prompt=1, latents=lat, vae_noise=vn,
+               generator=gen, **bkw).images
+    assert tuple(got.shape) == ref.shape and not torch.isnan(got).any()
+    assert rel_l2(got, ref) <= 1.5e-2, f"batched tile refinement vs the reference's sequential calls: rel-L2 {rel_l2(got, ref):.3e}"
+    # ... and the product's own one-call-per-sample form (generator shared across calls) lands there too
+    gen = torch.Generator("cpu").manual_seed(77)
+    seq = torch.cat([pipe(image=Image.fromarray(imgs[i]), mask_image=mask, controlnet_conditioning_image=Image.fromarray(imgs[i]),
+                          num_images_per_prompt=1, generator=gen, **kw).images for i in range(n)])
+    assert rel_l2(seq, ref) <= 1.5e-2
+
+
 @pytest.mark.parametrize("nets", [["cn"], ["cn", "cn2"]])
 def test_shared_cfg_prefix_equals_the_doubled_batch(mg, tiny, nets):
     """eps(cfg_halves=True): conv_in, the first ResBlock and the first transformer's self-attention computed on ONE copy
