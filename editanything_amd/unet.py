@@ -437,26 +437,33 @@ class ControlNet(_UNetBase):
         feats.append(h)
         return feats
 
-    def add_features(self, feats, skips, mid, scales):
-        """Zero-convs of precomputed `_features` accumulated into the UNet skips / middle tensor (see add_control)."""
+    def add_features(self, feats, skips, mid, scales, pair=True):
+        """Zero-convs of precomputed `_features` accumulated into the UNet skips / middle tensor (see add_control).
+        Neighbouring zero-convs of one shape (the two or three outputs of a resolution level) go out as ONE twin launch
+        (`ops.Pair`: two problems in one grid) -- 13 small launches become 8."""
         targets = list(skips) + [mid]
-        for f, (w, b), tgt, s in zip(feats, self.zero, targets, scales):
+        items = list(zip(feats, self.zero, targets, scales))
+        i = 0
+        while i < len(items):
+            f, (w, b), tgt, s = items[i]
+            if pair and i + 1 < len(items) and not torch.is_tensor(s):
+                f2, (w2, b2), tgt2, s2 = items[i + 1]
+                if not torch.is_tensor(s2) and float(s2) == float(s) and f2.shape == f.shape and w2.shape == w.shape:
+                    ops.conv2d(ops.Pair(f, f2), ops.Pair(w, w2), ops.Pair(b, b2), ksize=1, pad=0, scale=float(s),
+                               residual=ops.Pair(tgt, tgt2), out=ops.Pair(tgt, tgt2))
+                    i += 2
+                    continue
             if torch.is_tensor(s):
                 ops.conv2d(f, w, b, ksize=1, pad=0, row_scale=s, residual=tgt, out=tgt)
             else:
                 ops.conv2d(f, w, b, ksize=1, pad=0, scale=float(s), residual=tgt, out=tgt)
+            i += 1
 
-    def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales, shared=False):
+    def add_control(self, x_nhwc, emb_all, kvs, guided_hint, skips, mid, scales, shared=False, pair=True):
         """Fused path: skips[i] += scales[i] * zero_conv_i(h_i); mid += scales[-1] * middle_block_out(h_mid)
         (cldm.py:300-303 + :338 + :34-41 in one epilogue per tensor).  `scales[i]` may be a float or a per-pixel
         fp32 row-scale tensor (ControlNetModel2 scale map, utils/stable_diffusion_controlnet.py:777-802)."""
-        feats = self._features(x_nhwc, emb_all, kvs, guided_hint, shared)
-        targets = list(skips) + [mid]
-        for f, (w, b), tgt, s in zip(feats, self.zero, targets, scales):
-            if torch.is_tensor(s):
-                ops.conv2d(f, w, b, ksize=1, pad=0, row_scale=s, residual=tgt, out=tgt)
-            else:
-                ops.conv2d(f, w, b, ksize=1, pad=0, scale=float(s), residual=tgt, out=tgt)
+        self.add_features(self._features(x_nhwc, emb_all, kvs, guided_hint, shared), skips, mid, scales, pair)
 
     def forward(self, x, hint, timesteps, context, **kwargs):
         """Reference-API path: returns the list of len(input_blocks)+1 residual tensors (NCHW fp32, unscaled)."""
@@ -471,7 +478,7 @@ class ControlledDenoiser:
     (text K/V of every attention layer, ControlNet hint features) are prepared once, then `eps(x, t)` is the
     per-step hot function: UNet encoder -> ControlNet (accumulating into the skips) -> UNet decoder."""
 
-    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True, twin=False):
+    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True, twin=False, pair_zero_convs=True):
         """overlap: the ControlNet trunk runs beside the UNet encoder on a second stream (False: one stream, in order).
         share_cfg_prefix: `eps(cfg_halves=True)` computes the part the two CFG halves share once.
         twin: the (first) ControlNet's trunk and the UNet encoder run in LOCK STEP on one stream, every contraction of the
@@ -490,6 +497,7 @@ class ControlledDenoiser:
         self.split = 1
         self.share_cfg_prefix = bool(share_cfg_prefix)
         self.twin = bool(twin)
+        self.pair_zero_convs = bool(pair_zero_convs)    # neighbouring zero-convs of one shape as one twin launch (ControlNet.add_features)
         self._strm = []
 
     def static_state(self):
@@ -603,15 +611,15 @@ class ControlledDenoiser:
             c = ctx[0]
             cn0, x_cn, emb_c, kv0, gh0, sc0 = c["jobs"][0]
             hs, mid, feats = self._encode_twin(cn0, c["xin"], x_cn, c["emb_u"], emb_c, c["kv_u"], kv0, gh0, shared)
-            cn0.add_features(feats, hs, mid, sc0)
+            cn0.add_features(feats, hs, mid, sc0, self.pair_zero_convs)
             for cn, x_cn, emb_c, kv, gh, sc in c["jobs"][1:]:
-                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared)
+                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared, self.pair_zero_convs)
             return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         if not concurrent:
             c = ctx[0]
             hs, mid = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared)
             for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]:
-                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared)
+                cn.add_control(x_cn, emb_c, kv, gh, hs, mid, sc, shared, self.pair_zero_convs)
             return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         cur = torch.cuda.current_stream()
         streams = self._streams(split)
@@ -642,7 +650,7 @@ class ControlledDenoiser:
 
         def finish(c):
             for (cn, x_cn, emb_c, kv, gh, sc), f in zip(c["jobs"], c.get("feats", [])):
-                cn.add_features(f, c["hs"], c["mid"], sc)
+                cn.add_features(f, c["hs"], c["mid"], sc, self.pair_zero_convs)
             return u.decode(c["mid"], c["hs"], c["emb_u"], c["kv_u"])
         for g in range(1, split):
             streams[g][0].wait_stream(cur)
