@@ -31,8 +31,8 @@ GF_UNET, GF_CN, GF_VAE_DEC, GF_VAE_ENC, GF_SAM_H = 804.3, 283.7, 2514.5, 1116.7,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--ddim-steps", type=int, default=20)
     ap.add_argument("--sam", default="vit_h")
@@ -202,7 +202,9 @@ def main():
     # output_type "np_device": keep the decoded batch on the device (the host copy of 4 images is not part of the path)
     orig_decode = pipe.decode_latents
     pipe.decode_latents = lambda lat: (pipe.vae.decode_nhwc(lat / pipe.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
-    pipelined = not args.no_pipeline and not args.no_graph
+    # the software pipeline is filled and drained inside the timed region (one batch's SAM + VAE encode up front, one decode
+    # at the end: ~56 ms) and returns ~9 ms per step: below 8 steps the batches simply run one after the other
+    pipelined = not args.no_pipeline and not args.no_graph and args.steps >= 8
     runner = serving.PipelinedRunner(pipe, threaded=args.pipeline_thread == "on",
                                      side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority]) if pipelined else None
     hi_stream = torch.cuda.Stream(priority=-1) if (pipelined and args.loop_priority == "high") else None
