@@ -357,17 +357,9 @@ def test_pipeline_e2e_c2_20_steps_vs_fp32_oracle(sd21):
     assert psnr >= 35.0, psnr
 
 
-def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
-    """The TIMED configuration (bench.py: 4 images per call, network batch 8, 20 steps, HIP-graph replay): image 0 of a
-    batch of four carries the golden's inputs and noise -- one generator per image, image 0's seeded like the golden (x_T,
-    then the VAE posterior noise, whose first row is the batch-1 draw) -- and must reach the SAME bar against the fp32
-    oracle's batch-1 result (samples are independent: cldm/cldm.py has no cross-sample operation).  Images 1..3 carry other
-    images / controls / prompts / seeds: they exercise the batched launch set and must not leak into image 0."""
-    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
-    from editanything_amd.scheduler import DDIMScheduler
-    e2e, nets, _ = sd21
-    g = np.load(os.path.join(GOLD, "e2e_c2.npz"))
-    pipe = StableDiffusionControlNetInpaintPipeline(nets["vae"], nets["unet"], nets["cn"], DDIMScheduler(), device=DEV, use_graph=True)
+def _batch4_call(e2e, seed_rows=(2025, 1, 2, 3)):
+    """The timed configuration's call (bench.py: 4 images per call, network batch 8, 20 steps): image 0 carries the golden's
+    inputs and noise, images 1..3 other images / controls / prompts / seeds."""
     inp = e2e.inputs()
     rng = np.random.default_rng(99)
     B = 4
@@ -379,10 +371,27 @@ def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
         hint[b, 0], hint[b, 1] = torch.from_numpy((ids % 256).astype(np.float32)), torch.from_numpy((ids // 256).astype(np.float32))
     ctx = torch.cat([inp["ctx"]] + [torch.from_numpy((rng.standard_normal((1, 77, 1024)) * 0.5).astype(np.float32)) for _ in range(B - 1)])
     un = torch.cat([inp["un_ctx"]] + [torch.from_numpy((rng.standard_normal((1, 77, 1024)) * 0.5).astype(np.float32)) for _ in range(B - 1)])
-    gens = [torch.Generator("cpu").manual_seed(s) for s in (2025, 1, 2, 3)]
-    lat = pipe(prompt_embeds=ctx, negative_prompt_embeds=un, image=image, mask_image=inp["mask"].repeat(B, 1, 1, 1),
-               controlnet_conditioning_image=hint, height=512, width=512, num_inference_steps=20, guidance_scale=7.5,
-               output_type="latent", generator=gens).images.float().cpu()
+    return dict(prompt_embeds=ctx, negative_prompt_embeds=un, image=image, mask_image=inp["mask"].repeat(B, 1, 1, 1),
+                controlnet_conditioning_image=hint, height=512, width=512, num_inference_steps=20, guidance_scale=7.5,
+                output_type="latent", generator=[torch.Generator("cpu").manual_seed(s) for s in seed_rows])
+
+
+def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
+    """The TIMED configuration (bench.py: 4 images per call, network batch 8, 20 steps, HIP-graph replay): image 0 of a
+    batch of four carries the golden's inputs and noise -- one generator per image, image 0's seeded like the golden (x_T,
+    then the VAE posterior noise, whose first row is the batch-1 draw) -- and must reach the SAME bar against the fp32
+    oracle's batch-1 result (samples are independent: cldm/cldm.py has no cross-sample operation).  Images 1..3 carry other
+    images / controls / prompts / seeds: they exercise the batched launch set and must not leak into image 0.
+    Then the same call as the MIDDLE request of three through the software pipeline (serving.PipelinedRunner: how bench.py
+    runs its steps): bit-identical latents."""
+    from editanything_amd import serving
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+    from editanything_amd.scheduler import DDIMScheduler
+    e2e, nets, _ = sd21
+    g = np.load(os.path.join(GOLD, "e2e_c2.npz"))
+    pipe = StableDiffusionControlNetInpaintPipeline(nets["vae"], nets["unet"], nets["cn"], DDIMScheduler(), device=DEV, use_graph=True)
+    B = 4
+    lat = pipe(**_batch4_call(e2e)).images.float().cpu()
     assert lat.shape[0] == B and torch.isfinite(lat).all()
     ref = torch.from_numpy(g["latents"])
     cos = float(torch.nn.functional.cosine_similarity(lat[0].flatten(), ref.flatten(), dim=0))
@@ -394,6 +403,12 @@ def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
     assert psnr >= 35.0, psnr
     for b in range(1, B):
         assert float(torch.nn.functional.cosine_similarity(lat[b].flatten(), ref.flatten(), dim=0)) < 0.9      # other samples really differ
+    runner = serving.PipelinedRunner(pipe)
+    outs = runner.run([_batch4_call(e2e, (5, 6, 7, 8)), _batch4_call(e2e), _batch4_call(e2e, (9, 10, 11, 12))])
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1].images.float().cpu(), lat), "the software pipeline must not change a request's result"
+    assert not torch.equal(outs[0].images.float().cpu(), lat)
+    runner.close()
 
 
 def test_sd21_eval_network_batch_8_vs_frozen_oracle(sd21):
