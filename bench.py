@@ -49,6 +49,8 @@ def parse():
                     help="timed region only (for profiler traces): no sequential A/B, phase pass, extras, roofline leg, calibration")
     ap.add_argument("--side-priority", choices=["torch", "low", "normal", "high"], default="low",
                     help="experiment switch: HIP priority of the software pipeline's side stream (torch = a torch.cuda.Stream())")
+    ap.add_argument("--side-cus", type=int, default=0,
+                    help="experiment switch: confine the software pipeline's side stream to the first N compute units (CU mask)")
     ap.add_argument("--pipeline-thread", choices=["on", "off"], default="on",
                     help="experiment switch: off = the side stream's stages are issued by the thread that issues the loops")
     ap.add_argument("--loop-priority", choices=["default", "high"], default="default",
@@ -206,7 +208,8 @@ def main():
     # at the end: ~56 ms) and returns ~9 ms per step: below 8 steps the batches simply run one after the other
     pipelined = not args.no_pipeline and not args.no_graph and args.steps >= 8
     runner = serving.PipelinedRunner(pipe, threaded=args.pipeline_thread == "on",
-                                     side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority]) if pipelined else None
+                                     side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority],
+                                     side_cus=args.side_cus) if pipelined else None
     hi_stream = torch.cuda.Stream(priority=-1) if (pipelined and args.loop_priority == "high") else None
 
     def run_steps(first_seed, k):

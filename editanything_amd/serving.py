@@ -32,7 +32,7 @@ SIDE_TAG = 16      # scratch number of the side stream (0 / 1 and 2g / 2g+1 belo
 _keep = []         # HIP streams made by make_stream (never destroyed: graphs / events may reference them)
 
 
-def make_stream(device, priority):
+def make_stream(device, priority, cu_count=0):
     """A non-blocking HIP stream of an explicit HIP priority (-1 high, 0 normal, 1 low), wrapped for torch.
 
     Why not torch.cuda.Stream(): HIP multiplexes its streams onto a few hardware queues PER PRIORITY LEVEL (4 by default),
@@ -44,15 +44,21 @@ def make_stream(device, priority):
     hip = ctypes.CDLL("libamdhip64.so")
     h = ctypes.c_void_p()
     with torch.cuda.device(device):
-        rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = hipStreamNonBlocking
+        if cu_count:
+            # experiment (bench.py --side-cus): confine the side stream to the first `cu_count` compute units
+            words = (cu_count + 31) // 32
+            mask = (ctypes.c_uint32 * words)(*[0xFFFFFFFF if 32 * (i + 1) <= cu_count else (1 << (cu_count - 32 * i)) - 1 for i in range(words)])
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+        else:
+            rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), ctypes.c_uint(1), ctypes.c_int(priority))   # 1 = hipStreamNonBlocking
     if rc != 0:
-        raise RuntimeError(f"hipStreamCreateWithPriority(priority={priority}) failed: {rc}")
+        raise RuntimeError(f"HIP stream creation (priority={priority}, cu_count={cu_count}) failed: {rc}")
     _keep.append(h)
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
 class PipelinedRunner:
-    def __init__(self, pipe, side_stream=None, threaded=True, side_priority=1):
+    def __init__(self, pipe, side_stream=None, threaded=True, side_priority=1, side_cus=0):
         """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
         the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
         packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:
@@ -65,7 +71,7 @@ class PipelinedRunner:
         self._pool = None
         with torch.cuda.device(self.device):
             if side_stream is None:
-                side_stream = torch.cuda.Stream() if side_priority is None else make_stream(self.device, side_priority)
+                side_stream = torch.cuda.Stream() if side_priority is None else make_stream(self.device, side_priority, side_cus)
             self.side = side_stream
         self._on_side(lambda: ops.workspace(self.device)).result()     # allocated here, eagerly -- never inside a capture
         self.latency_events = None                # set to a list: (front start, back end) event pairs per request
