@@ -38,9 +38,10 @@ def parse():
     ap.add_argument("--sam", default="vit_h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run the batches strictly one after the other (SAM -> prepare -> loop -> decode on one stream) "
-                         "instead of software-pipelined over consecutive batches (serving.PipelinedRunner)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="EXPERIMENT (off by default, results not trustworthy: profiles/r04_pipelined_race.jsonl): software-pipeline "
+                         "the batches over two streams (serving.PipelinedRunner overlap=True) instead of running them strictly one "
+                         "after the other (SAM -> prepare -> loop -> decode on one stream)")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
                          "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
@@ -206,8 +207,8 @@ def main():
     pipe.decode_latents = lambda lat: (pipe.vae.decode_nhwc(lat / pipe.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
     # the software pipeline is filled and drained inside the timed region (one batch's SAM + VAE encode up front, one decode
     # at the end: ~56 ms) and returns ~9 ms per step: below 8 steps the batches simply run one after the other
-    pipelined = not args.no_pipeline and not args.no_graph and args.steps >= 8
-    runner = serving.PipelinedRunner(pipe, threaded=args.pipeline_thread == "on",
+    pipelined = args.pipeline and not args.no_graph and args.steps >= 8
+    runner = serving.PipelinedRunner(pipe, overlap=True, threaded=args.pipeline_thread == "on",
                                      side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority],
                                      side_cus=args.side_cus) if pipelined else None
     hi_stream = torch.cuda.Stream(priority=-1) if (pipelined and args.loop_priority == "high") else None
@@ -301,12 +302,16 @@ def main():
                                "device (no D2H copy / PIL conversion in the timed region); the part of an evaluation in "
                                "front of the first cross-attention (conv_in, first ResBlock, first self-attention) is "
                                "computed once for the two identical CFG halves"
-                               + ("; the `steps` batches run through a two-stream software pipeline (serving.PipelinedRunner): "
-                                  "SAM encode + VAE encode + per-call invariants of batch i+1 and the VAE decode of batch i-1 are "
-                                  "issued on a side stream underneath the 20-step loop of batch i; the pipeline starts EMPTY "
-                                  "and is DRAINED inside the timed region; `sequential` = the same batches one after the "
-                                  "other, measured in the same process" if runner is not None else
-                                  "; batches strictly one after the other on one stream"),
+                               + ("; EXPERIMENT --pipeline: the `steps` batches run through a two-stream software pipeline "
+                                  "(serving.PipelinedRunner overlap=True): SAM encode + VAE encode + per-call invariants of batch i+1 "
+                                  "and the VAE decode of batch i-1 are issued on a side stream underneath the 20-step loop of batch i; "
+                                  "the pipeline starts EMPTY and is DRAINED inside the timed region; `sequential` = the same batches "
+                                  "one after the other, measured in the same process.  NOT the shipped configuration: the loop's "
+                                  "result is not reproducible beside a busy second stream (profiles/r04_pipelined_race.jsonl)"
+                                  if runner is not None else
+                                  "; batches strictly one after the other on one stream (a two-stream software pipeline over "
+                                  "consecutive batches exists -- serving.PipelinedRunner, --pipeline: +1.7 ... +2.8 % -- and is OFF: "
+                                  "results of the captured loop change beside a busy second stream, profiles/r04_pipelined_race.jsonl)"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),

@@ -125,10 +125,11 @@ class Demo:
         return [full_segmask] + results, prompt
 
     def process_many(self, requests):
-        """A queue of `process` requests (each a tuple / dict of its arguments) through the software pipeline
-        (serving.PipelinedRunner): SAM encode + mask generation + control of request i+1 and the VAE decode of request
-        i-1 are issued on a side stream underneath the denoising loop of request i.  Returns `process`' return value per
-        request, in order -- the same values `process` gives one request at a time."""
+        """A queue of `process` requests (each a tuple / dict of its arguments) through the staged runner
+        (serving.PipelinedRunner): every request is front (SAM encode + mask generation + control + VAE encode) -> loop -> back
+        (VAE decode).  Returns `process`' return value per request, in order -- the same values `process` gives one request at
+        a time.  (The runner's two-stream form -- the next request's front and the previous one's back underneath the current
+        loop -- is an opt-in experiment, `PipelinedRunner(pipe, overlap=True)`: see serving.py for why it is off.)"""
         from .serving import PipelinedRunner
         reqs = [r if isinstance(r, dict) else dict(zip(self.process.__code__.co_varnames[1:], r)) for r in requests]
         paths = {config_dict.get(r["condition_model"], r["condition_model"]) for r in reqs}

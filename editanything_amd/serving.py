@@ -20,6 +20,14 @@ stage ever reads a buffer another in-flight request writes.  The side stream has
 
 Latency: a request leaves the runner one denoising loop after the sequential path would have finished it at the
 latest (its decode waits for nothing but its own loop); throughput is what moves -- bench.py reports both.
+
+**STATUS (end of round 4): `overlap` is OFF by default -- the runner then runs the three stages of every request in order on
+the caller's stream (same results as `pipe(**kw)`, no second stream, no thread).**  With `overlap=True` the throughput gain was
+measured (+1.7 ... +2.8 % at the benchmark's shape), and then a stress test found that the captured loop's RESULT changes when
+certain work runs beside it on a second HIP stream (up to 0.09 on O(1) latents in 14 of 20 runs; plain calls are bit-
+deterministic): not a hand-over bug (audited), not uninitialised memory, not scratch sharing, not stream priority, and a torch
+elementwise chain on the second stream is enough to trigger it (profiles/r04_pipelined_race.jsonl, tools/diag_pipeline_det.py).
+Until that is understood nothing runs beside a captured loop in the shipped configuration.
 """
 import concurrent.futures
 import time
@@ -58,7 +66,7 @@ def make_stream(device, priority, cu_count=0):
 
 
 class PipelinedRunner:
-    def __init__(self, pipe, side_stream=None, threaded=True, side_priority=1, side_cus=0):
+    def __init__(self, pipe, overlap=False, side_stream=None, threaded=True, side_priority=1, side_cus=0):
         """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
         the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
         packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:
@@ -67,8 +75,13 @@ class PipelinedRunner:
         thread) and lives as long as the runner, so graphs captured on it stay valid."""
         self.pipe = pipe
         self.device = pipe.device
-        self.threaded = threaded
+        self.overlap = bool(overlap)
+        self.threaded = threaded and self.overlap
         self._pool = None
+        self.latency_events = self.host_trace = self.timeline = self.keep_calls = None
+        if not self.overlap:
+            self.side = None
+            return
         with torch.cuda.device(self.device):
             if side_stream is None:
                 side_stream = torch.cuda.Stream() if side_priority is None else make_stream(self.device, side_priority, side_cus)
@@ -77,6 +90,7 @@ class PipelinedRunner:
         self.latency_events = None                # set to a list: (front start, back end) event pairs per request
         self.host_trace = None                    # set to a list: (request, seconds spent issuing its loop)
         self.timeline = None                      # set to a dict: (stage, request) -> (start event, end event), device timeline
+        self.keep_calls = None                    # set to a list: the call objects of a run are retained (diagnostics)
 
     def _span(self, key):
         """Context manager recording a timed event pair on the current stream into `timeline` (no-op when it is None)."""
@@ -163,6 +177,20 @@ class PipelinedRunner:
         outs = [None] * n
         if n == 0:
             return outs
+        if not self.overlap:              # in order, on the caller's stream: front -> loop -> back per request
+            for i, req in enumerate(requests):
+                e0 = None
+                if self.latency_events is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                call = self.pipe.front(**(req() if callable(req) else req))
+                self.pipe.loop(call)
+                outs[i] = self.pipe.back(call)
+                if e0 is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    self.latency_events.append((e0, e1))
+            return outs
         main = torch.cuda.current_stream(self.device)
         start = torch.cuda.Event()
         start.record(main)                        # inputs the caller produced on its stream
@@ -170,6 +198,8 @@ class PipelinedRunner:
         prev = None                               # (call, loop-done event) of the request whose decode is still owed
         for i in range(n):
             call, ev_front = nxt.result()
+            if self.keep_calls is not None:
+                self.keep_calls.append(call)
             capture = not self.pipe.has_graph(call)
             if capture:
                 # first call of a shape: the step is captured inside `loop` -- nothing else may run on the device then
