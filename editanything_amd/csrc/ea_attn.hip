@@ -723,6 +723,12 @@ __global__ __launch_bounds__(64 * NW, G == 1 ? 2 : 1) void ea_attn_dma_kernel(At
   attn_wait_dma<0>();
   attn_barrier();
   qk(0, sA);
+  // Iteration 0 requests K(3) into K slot 0, which EVERY wave has just read here: all of them must be past these reads before
+  // any of them issues that request.  (Round 4: without this barrier a wave that ran ahead could overwrite K(0) under a slower
+  // wave's reads -- never seen alone, where the four waves leave the barrier above in step and the DMA takes longer than the
+  // eight fragment reads, but a few launches in 10^4 once another stream's waves shared the SIMDs: the "results of the captured
+  // loop change beside a busy second stream" of profiles/r04_pipelined_race.jsonl, found by tools/diag_kernel_race.py.)
+  if (nkt > 3) attn_barrier();
   if (nfull == 0) advance_max(0, sA, std::true_type{});
   else advance_max(0, sA, std::false_type{});
 

@@ -277,7 +277,23 @@ class StableDiffusionControlNetInpaintPipeline:
         return img.cpu().float().numpy()
 
     # ------------------------------------------------------------------ the step
+    def _advance_inputs(self, st):
+        """Self-advancing step (cached-graph path): the step's per-iteration inputs -- timestep, sampler coefficients, every
+        ResBlock's time-embedding row -- are row `st["step"]` of tables that live in static buffers, gathered by a DEVICE
+        index, and the index is incremented at the end of the step: all of it part of the captured graph, so a denoising
+        loop is N back-to-back replays with no host-issued launch between them."""
+        tab, idx = st["tab"], st["step"]
+        st["t"].copy_(tab["t"].index_select(0, idx).expand_as(st["t"]))
+        st["coef"].copy_(tab["coef"].index_select(0, idx)[0])
+        for dst, tb in zip(st["embs"], tab["embs"]):
+            dst.copy_(tb.index_select(0, idx))
+        if st.get("unipc") is not None:
+            st["unipc"]["coefC"].copy_(tab["coefC"].index_select(0, idx)[0])
+            st["unipc"]["coefP"].copy_(tab["coefP"].index_select(0, idx)[0])
+
     def _step(self, st):
+        if st.get("tab") is not None:
+            self._advance_inputs(st)
         lat = st["lat"]
         if st["cfg"] and st["extra"] is None and self.denoiser.will_share_prefix(st["t"].shape[0], st.get("embs")):
             # the evaluation reads ONE copy of the CFG batch's identical halves: `cat([latents] * 2)` (…inpaint.py:1540-1547)
@@ -308,6 +324,8 @@ class StableDiffusionControlNetInpaintPipeline:
             ops.lincomb([u["lat_c"], u["m0"], u["m1"]], u["coefP"], out=st["lat_out"], mask=st["blend_mask"],
                         alt=(st["x_orig"], st["noise_orig"]))
         lat.copy_(st["lat_out"])
+        if st.get("tab") is not None:
+            st["step"].add_(1)
 
     # ------------------------------------------------------------------ __call__
     @torch.no_grad()
@@ -440,7 +458,7 @@ class StableDiffusionControlNetInpaintPipeline:
         gkey = None
         if self.use_graph and not step_noise and not in_loop_blend and c.ref_state is None and \
                 all(not torch.is_tensor(v) for sc in per_net for v in sc):
-            gkey = (type(sch).__name__, n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
+            gkey = (type(sch).__name__, len(timesteps), n_img, height, width, do_cfg, unet_in, x_orig is not None, extra is not None, tuple(embeds.shape),
                     tuple(tuple(h.shape) for h in hints), tuple(tuple(sc) for sc in per_net))
         if unipc:
             c.coef_table, c.coef_c_table, c.coef_p_table = sch.coef_tables(guidance_scale, self.device)
@@ -497,21 +515,36 @@ class StableDiffusionControlNetInpaintPipeline:
                 z = lambda: torch.zeros_like(st["lat"])
                 st["unipc"] = dict(m_t=z(), m0=z(), m1=z(), last=z(), lat_c=z(), scratch=z(),
                                    coefC=c.coef_c_table[0].clone(), coefP=c.coef_p_table[0].clone())
-        # every step's time-embedding rows were computed in one shot; step i copies row i into the static [1, sum(Cout)] buffers
+        # every step's time-embedding rows were computed in one shot; step i reads row i through the static [1, sum(Cout)] buffers
         emb_tables = c.emb_tables
         if st.get("embs") is None:
             st["embs"] = [tb[:1].clone() for tb in emb_tables]
+        self_advance = gkey is not None      # cached-graph path: the captured step gathers its own row and counts (`_advance_inputs`)
+        if self_advance:
+            t_tab = torch.as_tensor(timesteps.astype(np.int64), device=self.device)
+            new_tab = dict(t=t_tab, coef=c.coef_table, embs=list(emb_tables))
+            if unipc:
+                new_tab.update(coefC=c.coef_c_table, coefP=c.coef_p_table)
+            if st.get("tab") is None:
+                st["tab"] = {k: ([t.clone() for t in v] if isinstance(v, list) else v.clone()) for k, v in new_tab.items()}
+                st["step"] = torch.zeros(1, dtype=torch.long, device=self.device)
+            else:
+                for k, v in new_tab.items():
+                    for dst, src in zip(st["tab"][k] if isinstance(v, list) else [st["tab"][k]], v if isinstance(v, list) else [v]):
+                        dst.copy_(src)
+            st["step"].zero_()
         mix_gen = generator if not isinstance(generator, list) else generator[0]
         if mixing:   # …inpaint.py:1968-1975: the kept region starts from the re-noised original, the rest from pure noise
             self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[0])]), 0.0, True, mix_gen)
         for i in range(nsteps):
-            st["t"].fill_(int(timesteps[i]))
-            st["coef"].copy_(c.coef_table[i])
-            if unipc:
-                st["unipc"]["coefC"].copy_(c.coef_c_table[i])
-                st["unipc"]["coefP"].copy_(c.coef_p_table[i])
-            for dst, tb in zip(st["embs"], emb_tables):
-                dst.copy_(tb[i:i + 1])
+            if not self_advance:
+                st["t"].fill_(int(timesteps[i]))
+                st["coef"].copy_(c.coef_table[i])
+                if unipc:
+                    st["unipc"]["coefC"].copy_(c.coef_c_table[i])
+                    st["unipc"]["coefP"].copy_(c.coef_p_table[i])
+                for dst, tb in zip(st["embs"], emb_tables):
+                    dst.copy_(tb[i:i + 1])
             st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
                 if step_noise else None
             blend_now = in_loop_blend and i < nsteps * c.alignment_ratio and i + 1 < nsteps
@@ -674,6 +707,8 @@ class StableDiffusionControlNetInpaintPipeline:
         if unipc_saved is not None:                 # the multistep history the warm-up pushed
             for k, v in unipc_saved.items():
                 st["unipc"][k].copy_(v)
+        if st.get("tab") is not None:               # ... and the step index it advanced
+            st["step"].zero_()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             step()

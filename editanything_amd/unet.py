@@ -363,11 +363,17 @@ class ControlledUnetModel(_UNetBase):
         self._finalize_emb()
         self._index_attn()
 
-    def encode(self, x_nhwc, emb_all, kvs, shared=False):
-        """shared: x_nhwc is ONE copy of a CFG batch's identical halves (kvs / the result are full batch)."""
+    def encode(self, x_nhwc, emb_all, kvs, shared=False, h0=None):
+        """shared: x_nhwc is ONE copy of a CFG batch's identical halves (kvs / the result are full batch).
+        h0: the output of input_blocks[0] (conv_in), when the caller already ran it (`ControlledDenoiser.eps` does, before it
+        forks its streams)."""
         hs = []
         h = x_nhwc
         for i, mods in enumerate(self.input_blocks):
+            if i == 0 and h0 is not None:
+                h = h0
+                hs.append(torch.cat([h, h]) if shared else h)
+                continue
             if shared and i == 0:
                 h = self._run(mods, h, None, emb_all, kvs)
                 hs.append(torch.cat([h, h]))
@@ -420,11 +426,16 @@ class ControlNet(_UNetBase):
             h = ops.conv2d(h, w, b, stride=s, act=ops.ACT_SILU if i != 7 else ops.ACT_NONE)
         return h
 
-    def _features(self, x_nhwc, emb_all, kvs, guided_hint, shared=False):
-        """shared: x_nhwc and guided_hint hold ONE copy of a CFG batch's identical halves."""
+    def _features(self, x_nhwc, emb_all, kvs, guided_hint, shared=False, h0=None):
+        """shared: x_nhwc and guided_hint hold ONE copy of a CFG batch's identical halves.
+        h0: the output of input_blocks[0] (conv_in + guided hint), when the caller already ran it."""
         feats = []
         h = x_nhwc
         for i, mods in enumerate(self.input_blocks):
+            if i == 0 and h0 is not None:
+                h = h0
+                feats.append(torch.cat([h, h]) if shared else h)
+                continue
             if shared and i == 0:
                 h = self._run(mods, h, None, emb_all, kvs, residual=guided_hint)
                 feats.append(torch.cat([h, h]))
@@ -623,23 +634,34 @@ class ControlledDenoiser:
             return u.decode(mid, hs, c["emb_u"], c["kv_u"])
         cur = torch.cuda.current_stream()
         streams = self._streams(split)
+        # ---- phase 0, on the caller's stream, BEFORE the fork: every network's first convolution (conv_in, 4 input channels: the
+        # one layer of an evaluation that the LDS-DMA contraction kernel does not take -- K is not a multiple of 64 -- and that runs
+        # on the register-staged generic kernel).  Round 4 found that generic kernel perturbing GroupNorm launches of ANOTHER stream
+        # that share the chip with it (tools/diag_kernel_race.py, profiles/r04_pipelined_race.jsonl: a GroupNorm partial sum off by a
+        # few terms, 30-50 % of evaluations beside a stream of generic launches; cause not understood); nothing of it was ever seen
+        # inside an evaluation, but with the two launches here no generic launch has a concurrent neighbour by construction.
+        for c in ctx:
+            c["h0_u"] = u._run(u.input_blocks[0], c["xin"], None, c["emb_u"], c["kv_u"])
+            c["h0_c"] = [cn._run(cn.input_blocks[0], x_cn, None, emb_c, kv, residual=gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
         # ---- phase 1: encoders and ControlNet trunks (group 0's encoder stays on the caller's stream)
         for g, c in enumerate(ctx):
             enc_s, cn_s = streams[g]
             if c["jobs"] and self.cn_overlap:
                 cn_s.wait_stream(cur)
                 with torch.cuda.stream(cn_s), ops.aux_workspace(2 * g + 1):
-                    c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+                    c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared, h0=h0)
+                                  for (cn, x_cn, emb_c, kv, gh, sc), h0 in zip(c["jobs"], c["h0_c"])]
             if g > 0:
                 enc_s.wait_stream(cur)
                 with torch.cuda.stream(enc_s), ops.aux_workspace(2 * g):
-                    c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"])
+                    c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"], h0=c["h0_u"])
                     if c["jobs"] and not self.cn_overlap:
-                        c["feats"] = [cn._features(x_cn, emb_c, kv, gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+                        c["feats"] = [cn._features(x_cn, emb_c, kv, gh, h0=h0)
+                                      for (cn, x_cn, emb_c, kv, gh, sc), h0 in zip(c["jobs"], c["h0_c"])]
         c = ctx[0]
-        c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared)
+        c["hs"], c["mid"] = u.encode(c["xin"], c["emb_u"], c["kv_u"], shared, h0=c["h0_u"])
         if c["jobs"] and not self.cn_overlap:
-            c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
+            c["feats"] = [cn._features(x_cn, emb_c, kv, gh, shared, h0=h0) for (cn, x_cn, emb_c, kv, gh, sc), h0 in zip(c["jobs"], c["h0_c"])]
         for g in range(split):
             if g > 0:
                 cur.wait_stream(streams[g][0])

@@ -1,0 +1,389 @@
+"""Which launch of a ControlNet + UNet evaluation changes its RESULT when unrelated work runs beside it on a second HIP stream?
+(round 4: the captured denoising loop is bit-deterministic alone and not beside a busy second stream -- profiles/r04_pipelined_race.jsonl.)
+
+  phase C  one evaluation (SD2.1, network batch 8, 64x64 latents; single-stream form), eagerly and as a HIP-graph replay, N times each
+           beside a thread that streams a 64 MiB fp32 elementwise + reduction chain on another stream: runs whose output differs
+           from the undisturbed one (eager != 0 -> a launch is timing-sensitive by itself; only graph != 0 -> ordering inside the graph)
+  phase B  every top-level `ops.*` call of that evaluation is recorded with CLONES of its tensor arguments and replayed by itself:
+           twice undisturbed (reference; arguments the call writes are found and re-cloned per run), then N times beside the same
+           interference; calls whose outputs differ are listed with their argument shapes.
+
+    python tools/diag_kernel_race.py [runs=8] [work=elementwise|copy|none]
+"""
+import json
+import os
+import sys
+import threading
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from editanything_amd import arch, ops, synth  # noqa: E402
+from editanything_amd.unet import ControlledDenoiser, ControlledUnetModel, ControlNet  # noqa: E402
+
+opts = dict(a.split("=") for a in sys.argv[1:])
+RUNS = int(opts.get("runs", 8))
+EVAL_RUNS = int(opts.get("evals", 24))
+WORK = opts.get("work", "elementwise")
+dev = "cuda"
+un = ControlledUnetModel(arch.SD21_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_UNET), 12), dev)
+cn = ControlNet(arch.SD21_CONTROLNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_CONTROLNET, True), 11), dev)
+g = torch.Generator("cpu").manual_seed(0)
+lat = torch.randn(4, 4, 64, 64, generator=g).to(dev)
+hint = (torch.rand(4, 3, 512, 512, generator=g) * 255).to(dev)
+hint = torch.cat([hint, hint])
+ctx = (torch.randn(8, 77, 1024, generator=g) * 0.5).to(dev)
+ts = torch.full((8,), 501, dtype=torch.long, device=dev)
+af = torch.randn(4096, 4096, device=dev)
+ag = torch.empty_like(af)
+side = torch.cuda.Stream()
+with ops.aux_workspace(16):
+    ops.workspace(dev)
+a20 = (torch.randn(20, 1280) * 0.1).half().to(dev)
+w12 = (torch.randn(1280, 1280) * 0.05).half().to(dev)
+xc = (torch.randn(2, 256, 256, 128) * 0.5).half().to(dev)
+wc = (torch.randn(128, 9 * 128) * 0.02).half().to(dev)
+xg = (torch.randn(2, 256, 256, 128) * 0.5).half().to(dev)
+gg, gb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+
+
+def _own():      # this library's own launches, as the software pipeline's side stream issues them (VAE-sized convolution, GroupNorm, tiny GEMMs)
+    with ops.aux_workspace(16):
+        for _ in range(8):
+            ops.gemm(a20, w12)
+        ops.conv2d(xc, wc)
+        ops.groupnorm(xg, gg, gb)
+
+
+def _tiny(a=None):
+    with ops.aux_workspace(16):
+        for _ in range(16):
+            ops.gemm(a20 if a is None else a, w12)
+
+
+def _tuned(a, **tune):      # tuning is per host thread: set on the thread that launches (the interference thread)
+    from editanything_amd import _lib
+    _lib.set_tuning(None, **tune)
+    _tiny(a)
+
+
+a64 = (torch.randn(64, 1280) * 0.1).half().to(dev)
+a24 = (torch.randn(24, 1280) * 0.1).half().to(dev)
+
+
+def _conv():
+    with ops.aux_workspace(16):
+        ops.conv2d(xc, wc)
+
+
+def _gn():
+    with ops.aux_workspace(16):
+        ops.groupnorm(xg, gg, gb)
+
+
+def _gn_small():      # a GroupNorm whose statistics workgroups have the victim's own geometry (240 threads, 15 KiB of LDS)
+    with ops.aux_workspace(16):
+        ops.groupnorm(xs320, gs320, gs320)
+
+
+xs320 = (torch.randn(8, 64, 64, 320) * 0.5).half().to(dev)
+gs320 = torch.ones(320, device=dev)
+works = {"own": _own, "conv": _conv, "gn": _gn, "gn_small": _gn_small, "tinygemm": lambda: _tiny(), "tinygemm64": lambda: _tiny(a64), "tinygemm24": lambda: _tiny(a24),
+         "generic64": lambda: _tuned(a64, force_generic=1), "generic64_nosplit": lambda: _tuned(a64, force_generic=1, splits=1),
+         "tiny24_nosplit": lambda: _tuned(a24, splits=1), "fast64_split2": lambda: _tuned(a64, splits=2), "elementwise": lambda: (af * 1.0001 + 0.5).sum(), "copy": lambda: ag.copy_(af), "none": lambda: None}
+
+
+class Interference:
+    def __enter__(self):
+        self.stop = threading.Event()
+
+        def bg():
+            torch.cuda.set_device(0)
+            with torch.no_grad(), torch.cuda.stream(side):
+                while not self.stop.is_set():
+                    for _ in range(4):
+                        works[WORK]()
+                    side.synchronize()
+        self.th = threading.Thread(target=bg)
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join()
+        torch.cuda.synchronize()
+
+
+def tensors(obj, acc):
+    if torch.is_tensor(obj):
+        acc.append(obj)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            tensors(o, acc)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            tensors(o, acc)
+    elif isinstance(obj, ops.Pair):
+        tensors(obj.a, acc)
+        tensors(obj.b, acc)
+    elif isinstance(obj, ops.Normed):
+        acc.append(obj.t)
+    return acc
+
+
+def mapt(obj, fn):
+    if torch.is_tensor(obj):
+        return fn(obj)
+    if isinstance(obj, list):
+        return [mapt(o, fn) for o in obj]
+    if isinstance(obj, tuple):
+        return tuple(mapt(o, fn) for o in obj)
+    if isinstance(obj, dict):
+        return {k: mapt(o, fn) for k, o in obj.items()}
+    if isinstance(obj, ops.Pair):
+        return ops.Pair(mapt(obj.a, fn), mapt(obj.b, fn))
+    return obj
+
+
+def same(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and bool((a.contiguous().view(torch.uint8) == b.contiguous().view(torch.uint8)).all())
+
+
+den = ControlledDenoiser(un, [cn], overlap=bool(int(opts.get("overlap", 0))))
+with torch.no_grad():
+    den.prepare(ctx, [hint])
+    embs = [e[:1].clone() for e in den.time_embeddings(ts[:1])]
+    run = lambda: den.eps(lat, ts, embs=embs, cfg_halves=True, cfg_single=True)
+    want = run().clone()
+    torch.cuda.synchronize()
+    assert same(run(), want), "the undisturbed evaluation is not deterministic"
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        run()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        gout = run()
+    graph.replay()
+    torch.cuda.synchronize()
+    res = {"phase": "C", "work": WORK, "runs": RUNS, "graph_equals_eager_undisturbed": same(gout, want)}
+    gwant = gout.clone()
+    with Interference():
+        res["evals"] = EVAL_RUNS
+        res["eager_runs_that_differ"] = sum(int(not same(run(), want)) for _ in range(EVAL_RUNS))
+        bad = 0
+        for _ in range(EVAL_RUNS):
+            graph.replay()
+            torch.cuda.synchronize()
+            bad += int(not same(gout, gwant))
+        res["graph_replays_that_differ"] = bad
+    print(json.dumps(res), flush=True)
+    if opts.get("stop_after") == "C":
+        sys.exit(0)
+
+    # ---- phase G (gnwatch=1): every GroupNorm call of the evaluation with its inputs before and after, its partial sums and its output
+    if int(opts.get("gnwatch", 0)):
+        o_gn = ops.groupnorm
+        watch = [None]
+
+        def gn_w(x1, gamma, beta, eps=1e-5, silu=True, groups=32, x2=None, x2_add=None, out=None, stats=None):
+            if watch[0] is None or threading.current_thread() is not threading.main_thread() or stats is not None or isinstance(x1, ops.Pair):
+                return o_gn(x1, gamma, beta, eps, silu, groups, x2, x2_add, out, stats)
+            pre = [x1.clone(), None if x2 is None else x2.clone()]
+            r = o_gn(x1, gamma, beta, eps, silu, groups, x2, x2_add, out, stats)
+            ws = ops.workspace(x1.device)
+            B, C = x1.shape[0], x1.shape[-1] + (0 if x2 is None else x2.shape[-1])
+            HW = x1.numel() // (B * x1.shape[-1])
+            r_ = max(1, min(32, 256 // (C // 8), HW))                 # gn_plan (ea_norm.hip): rows per pass, chunks per sample
+            nch = max(1, min(HW // (r_ * 4), max(1, 2048 // B), 128))
+            cpx = (HW + nch - 1) // nch
+            nch = (HW + cpx - 1) // cpx
+            part = ws[:B * nch * groups * 8].clone().view(torch.float32)
+            post = [x1.clone(), None if x2 is None else x2.clone()]
+            watch[0].append(dict(nch=nch, cpx=cpx, shape=tuple(x1.shape), c2=0 if x2 is None else x2.shape[-1], pre=pre, post=post, part=part, out=r.clone(), groups=groups))
+            return r
+        ops.groupnorm = gn_w
+        watch[0] = []
+        run()
+        torch.cuda.synchronize()
+        ref_w = watch[0]
+        found = []
+        with Interference():
+            for it in range(EVAL_RUNS):
+                watch[0] = []
+                run()
+                torch.cuda.synchronize()
+                for gi, (a, b) in enumerate(zip(ref_w, watch[0])):
+                    if same(a["out"], b["out"]):
+                        continue
+                    rec = {"run": it, "gn_call": gi, "x1": a["shape"], "c2": a["c2"]}
+                    for k in ("pre", "post"):
+                        for j in (0, 1):
+                            if a[k][j] is not None:
+                                rec["%s_x%d_differs" % (k, j + 1)] = not same(a[k][j], b[k][j])
+                    B, G = a["shape"][0], a["groups"]
+                    pa, pb = a["part"].view(B, a["nch"], G, 2), b["part"].view(B, a["nch"], G, 2)
+                    rec["chunks_per_sample"], rec["pixels_per_chunk"] = a["nch"], a["cpx"]
+                    idx = (pa.view(torch.int32) != pb.view(torch.int32)).any(-1).nonzero()
+                    rec["partials_that_differ"] = idx.shape[0]
+                    rec["which (b, chunk, group)"] = idx[:12].tolist()
+                    if idx.shape[0]:
+                        i0 = tuple(idx[0].tolist())
+                        rec["first_ref_sum_sq"] = pa[i0].tolist()
+                        rec["first_got_sum_sq"] = pb[i0].tolist()
+                    found.append(rec)
+                    break
+        ops.groupnorm = o_gn
+        print(json.dumps({"phase": "G", "evals": EVAL_RUNS, "gn_calls_per_eval": len(ref_w), "runs_with_a_differing_groupnorm": len(found), "first": found[:10]}), flush=True)
+        sys.exit(0)
+
+    # ---- phase B: record
+    NAMES = [n for n in ("gemm", "gemm_batched", "conv2d", "groupnorm", "groupnorm_silu_conv3x3", "layernorm", "layernorm_rows", "ln_gemm",
+                         "attention", "add_f16", "nchw_to_nhwc", "nhwc_to_nchw", "silu_f32", "dup_rows", "cols", "gather_add_rows", "lincomb")
+             if hasattr(ops, n)]
+    calls, depth = [], [0]
+    orig = {n: getattr(ops, n) for n in NAMES}
+
+    record = [False]
+    trace = [None]            # phase F: a list -> (name, clones of the returned tensors) per top-level call, no synchronisation
+
+    def wrap(name, fn):
+        def w(*a, **k):
+            if threading.current_thread() is not threading.main_thread():     # the interference thread's own calls
+                return fn(*a, **k)
+            if trace[0] is not None:
+                depth[0] += 1
+                try:
+                    ret = fn(*a, **k)
+                finally:
+                    depth[0] -= 1
+                trace[0].append((name, [t.clone() for t in tensors(ret, [])], [tuple(t.shape) for t in tensors((a, k), [])][:5]))
+                return ret
+            if depth[0] == 0 and not record[0]:          # phase D: a device synchronisation after every top-level call
+                depth[0] += 1
+                try:
+                    return fn(*a, **k)
+                finally:
+                    depth[0] -= 1
+                    torch.cuda.synchronize()
+            if depth[0] == 0:
+                keep1d = lambda t: t if t.dim() == 1 else t.clone()      # gamma / beta / bias: never written (and `Normed` keys on gamma's address)
+                calls.append((name, mapt(a, keep1d), mapt(k, keep1d)))
+            depth[0] += 1
+            try:
+                return fn(*a, **k)
+            finally:
+                depth[0] -= 1
+        return w
+    if int(opts.get("decompose", 0)):      # the one-call GroupNorm + convolution as its two wrapped halves (so phase F sees the norm's output)
+        def gsc(x1, gamma, beta, w, bias, eps=1e-5, groups=32, x2=None, x2_add=None, stride=1, pad=1, ups=False, residual=None,
+                rowvec=None, scale=1.0, out_dtype=torch.float16, gn_in=None, gn_out_groups=0, gn_next=None):
+            n = ops.groupnorm(x1, gamma, beta, eps, True, groups, x2, x2_add, stats=gn_in)
+            return ops.conv2d(n, w, bias, 3, stride, pad, ups, residual=residual, rowvec=rowvec, scale=scale, out_dtype=out_dtype,
+                              gn_groups=gn_out_groups, gn_next=gn_next)
+        orig["groupnorm_silu_conv3x3"] = gsc
+    for n in NAMES:
+        setattr(ops, n, wrap(n, orig[n]))
+    with Interference():      # ---- phase D: the eager evaluation with every launch (group) finished before the next is issued
+        bad = sum(int(not same(run(), want)) for _ in range(EVAL_RUNS))
+    print(json.dumps({"phase": "D", "evals": EVAL_RUNS, "eager_runs_with_a_sync_after_every_call_that_differ": bad}), flush=True)
+    # ---- phase F: the eager evaluation, every top-level call's output cloned in stream order; the FIRST call whose output differs
+    trace[0] = []
+    run()
+    torch.cuda.synchronize()
+    ref_trace, first_bad = trace[0], []
+    with Interference():
+        for it in range(EVAL_RUNS):
+            trace[0] = []
+            out = run()
+            torch.cuda.synchronize()
+            if not same(out, want) or True:
+                for ci, ((n0, t0, sh), (n1, t1, _)) in enumerate(zip(ref_trace, trace[0])):
+                    if not all(same(x, y) for x, y in zip(t0, t1)):
+                        nbad = [int((x.contiguous().view(torch.uint8) != y.contiguous().view(torch.uint8)).sum()) for x, y in zip(t0, t1)]
+                        prev = ref_trace[ci - 1][0] if ci else None
+                        x, y = t0[0], t1[0]
+                        shape_of_damage = None
+                        if x.dim() == 4 and x.dtype == torch.float16:
+                            dm = (x != y)
+                            idx = dm.nonzero()
+                            px = idx[:, 1] * x.shape[2] + idx[:, 2]
+                            shape_of_damage = {"samples": sorted(set(idx[:, 0].tolist())), "channels": [int(idx[:, 3].min()), int(idx[:, 3].max())],
+                                               "distinct_channels": int(idx[:, 3].unique().numel()), "pixels": [int(px.min()), int(px.max())],
+                                               "distinct_pixels": int(px.unique().numel()), "elements": int(dm.sum()),
+                                               "max_abs_diff": float((x.float() - y.float()).abs().max()),
+                                               "got_nonfinite": int((~torch.isfinite(y.float())).sum()),
+                                               "ref_abs_mean": float(x.float().abs().mean())}
+                        first_bad.append({"run": it, "first_differing_call": ci, "op": n0, "args": sh, "bytes_that_differ": nbad,
+                                          "out_shapes": [tuple(x.shape) for x in t0], "previous_op": prev, "final_differs": not same(out, want), "damage": shape_of_damage})
+                        break
+    trace[0] = None
+    print(json.dumps({"phase": "F", "evals": EVAL_RUNS, "runs_with_a_differing_call": len(first_bad), "first": first_bad[:12]}), flush=True)
+    if opts.get("stop_after") == "F":
+        sys.exit(0)
+    record[0] = True
+    run()
+    torch.cuda.synchronize()
+    for n in NAMES:
+        setattr(ops, n, orig[n])
+    print(json.dumps({"phase": "B", "recorded_calls": len(calls)}), flush=True)
+
+    def outputs(name, a, k, mutable):
+        """Run the call on fresh clones of the arguments it writes; -> every tensor it returned or wrote."""
+        fresh = {id(t): t.clone() for t in mutable}
+        sub = lambda t: fresh.get(id(t), t)
+        a2, k2 = mapt(a, sub), mapt(k, sub)
+        ret = orig[name](*a2, **k2)
+        return tensors(ret, []) + [fresh[id(t)] for t in mutable]
+
+    plans, skipped = [], []
+    for ci, (name, a, k) in enumerate(calls):
+        args = tensors((a, k), [])
+        pristine = [t.clone() for t in args]
+        try:
+            orig[name](*a, **k)                      # finds the arguments the call writes (then restored)
+        except AssertionError:                       # a consumer of a `Normed` hand-over keyed on the (now cloned) gamma: no launch
+            skipped.append((ci, name))
+            continue
+        torch.cuda.synchronize()
+        mutable = [t for t, p0 in zip(args, pristine) if not same(t, p0)]
+        for t, p0 in zip(args, pristine):
+            if not same(t, p0):
+                t.copy_(p0)
+        del pristine
+        r0 = [t.clone() for t in outputs(name, a, k, mutable)]
+        r1 = outputs(name, a, k, mutable)
+        torch.cuda.synchronize()
+        det = len(r0) == len(r1) and all(same(x, y) for x, y in zip(r0, r1))
+        plans.append((name, a, k, mutable, r0, det))
+    print(json.dumps({"phase": "B", "skipped_no_launch": len(skipped), "calls_not_deterministic_undisturbed": [(i, p[0]) for i, p in enumerate(plans) if not p[5]]}), flush=True)
+    flagged = []
+    with Interference():
+        for i, (name, a, k, mutable, r0, det) in enumerate(plans):
+            if not det:
+                continue
+            bad = 0
+            for _ in range(RUNS):
+                r = outputs(name, a, k, mutable)
+                torch.cuda.synchronize()
+                bad += int(not all(same(x, y) for x, y in zip(r0, r)))
+            if bad:
+                desc = [tuple(t.shape) for t in tensors((a, k), [])][:6]
+                scal = {kk: vv for kk, vv in k.items() if isinstance(vv, (int, float, bool, str))}
+                flagged.append({"call": i, "op": name, "runs_that_differ": bad, "tensor_args": desc, "scalars": scal})
+                print(json.dumps(flagged[-1]), flush=True)
+    print(json.dumps({"phase": "B", "work": WORK, "runs_per_call": RUNS, "calls": len(plans), "calls_that_differ": len(flagged),
+                      "by_op": {n: sum(1 for f in flagged if f["op"] == n) for n in sorted({f["op"] for f in flagged})}}), flush=True)
+
+    # ---- phase E: all recorded calls back to back (own cloned inputs: no data flow between them), one synchronisation at the end
+    hits = {}
+    with Interference():
+        for it in range(int(opts.get("passes", 20))):
+            outs = [outputs(name, a, k, mutable) for name, a, k, mutable, r0, det in plans]
+            torch.cuda.synchronize()
+            for i, (o, pl) in enumerate(zip(outs, plans)):
+                if not all(same(x, y) for x, y in zip(pl[4], o)):
+                    hits.setdefault(i, [pl[0], 0, plans[i - 1][0] if i else None])[1] += 1
+            del outs
+    print(json.dumps({"phase": "E", "passes": int(opts.get("passes", 20)), "calls_that_differed": {str(i): v for i, v in sorted(hits.items())}}), flush=True)

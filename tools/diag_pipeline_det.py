@@ -57,7 +57,7 @@ with torch.no_grad():
     p2 = pipe(**call(1)).images.clone()
     out = {"options": opts, "plain_vs_plain": [d(p0, p1), d(p1, p2)]}
     for threaded in (True, False):
-        r = serving.PipelinedRunner(pipe, threaded=threaded)
+        r = serving.PipelinedRunner(pipe, overlap=True, threaded=threaded)
         a = r.run([call(1)])[0].images.clone()
         b3 = r.run([call(2), call(1), call(3)])
         torch.cuda.synchronize()
@@ -67,7 +67,7 @@ with torch.no_grad():
     q = pipe(**call(2)).images.clone()
     out["plain_call2_vs_runner_first"] = d(q, b3[0].images)
     # stage by stage: what `front` prepares on the side stream (worker thread) against the same on the caller's stream
-    r = serving.PipelinedRunner(pipe, threaded=True)
+    r = serving.PipelinedRunner(pipe, overlap=True, threaded=True)
     c_side, _ = r._front(call(1)).result()
     torch.cuda.synchronize()
     c_main = pipe.front(**call(1))
@@ -88,7 +88,7 @@ if opts.get("stress"):
             if not mode.startswith("mode:"):
                 continue
             mode = mode[5:]
-            r = serving.PipelinedRunner(pipe, threaded="unthreaded" not in mode, side_priority=None if "torchstream" in mode else (0 if "prio0" in mode else (-1 if "priohigh" in mode else 1)))
+            r = serving.PipelinedRunner(pipe, overlap=True, threaded="unthreaded" not in mode, side_priority=None if "torchstream" in mode else (0 if "prio0" in mode else (-1 if "priohigh" in mode else 1)))
             if "front_on_main" in mode:       # only the decode of the previous request overlaps the loop
                 orig_front = r._front
                 def front_main(req, after=None, _o=orig_front):
@@ -135,7 +135,7 @@ if opts.get("history"):
 if opts.get("audit"):
     with torch.no_grad():
         ref = {s: pipe(**call(s)).images.clone() for s in (1, 2, 3)}
-        r = serving.PipelinedRunner(pipe, side_priority=0)
+        r = serving.PipelinedRunner(pipe, overlap=True, side_priority=0)
         snaps = []
         o_loop, o_back = pipe.loop, pipe.back
 
@@ -231,3 +231,42 @@ if opts.get("interfere"):
                 bad += int(d(c0.final, want) > 0)
             res[name] = bad
             print(json.dumps({"side_workload": name, "runs": int(opts["interfere"]), "loops_with_a_different_result": bad}), flush=True)
+
+# ---- which STAGE's result differs under the software pipeline?  Every tensor `front` produced (on the side stream, beside another
+# request's loop) and the loop's final latents, against the same request's stages run alone.
+if opts.get("stagecheck"):
+    def flat(c_):
+        out = {k: getattr(c_, k) for k in ("lat", "noise0", "x_orig", "blend_mask", "coef_table", "final")}
+        inv = c_.invariants
+        for i, t in enumerate(inv["kv_u"]):
+            out["kv_u%d" % i] = t
+        for j, l in enumerate(inv["kv_c"]):
+            for i, t in enumerate(l):
+                out["kv_c%d_%d" % (j, i)] = t
+        for i, t in enumerate(inv["hints"]):
+            out["hint%d" % i] = t
+        for i, t in enumerate(c_.emb_tables):
+            out["emb%d" % i] = t
+        return {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+    with torch.no_grad():
+        ref = {}
+        for s_ in (1, 2, 3):
+            c_ = pipe.front(**call(s_))
+            pipe.loop(c_)
+            torch.cuda.synchronize()
+            ref[s_] = flat(c_)
+        r = serving.PipelinedRunner(pipe, overlap=True, side_priority=0)
+        counts, nbad = {}, 0
+        for it in range(int(opts["stagecheck"])):
+            r.keep_calls = []
+            r.run([call(2), call(1), call(3)])
+            torch.cuda.synchronize()
+            for c_, s_ in zip(r.keep_calls, (2, 1, 3)):
+                got = flat(c_)
+                bad = [k for k in got if d(got[k], ref[s_][k]) > 0]
+                nbad += bool(bad)
+                for k in bad:
+                    kk = k.rstrip("0123456789_")
+                    counts[kk] = counts.get(kk, 0) + 1
+        print(json.dumps({"stagecheck_runs": int(opts["stagecheck"]), "requests_with_a_difference": nbad, "tensors_that_differed": counts}))
+        r.close()
