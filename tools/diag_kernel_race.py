@@ -69,6 +69,17 @@ def _tuned(a, **tune):      # tuning is per host thread: set on the thread that 
 
 a64 = (torch.randn(64, 1280) * 0.1).half().to(dev)
 a24 = (torch.randn(24, 1280) * 0.1).half().to(dev)
+a256 = (torch.randn(256, 1280) * 0.1).half().to(dev)
+qa = (torch.randn(8, 1024, 640) * 0.5).half().to(dev)
+x8 = (torch.randn(4, 64, 64, 8) * 0.5).half().to(dev)          # conv_in: 4 latent channels padded to 8, 320 outputs (the generic kernel)
+w8 = (torch.randn(320, 72) * 0.05).half().to(dev)
+
+
+def _convin():
+    with ops.aux_workspace(16):
+        for _ in range(8):
+            ops.conv2d(x8, w8)
+
 
 
 def _conv():
@@ -90,6 +101,9 @@ xs320 = (torch.randn(8, 64, 64, 320) * 0.5).half().to(dev)
 gs320 = torch.ones(320, device=dev)
 works = {"own": _own, "conv": _conv, "gn": _gn, "gn_small": _gn_small, "tinygemm": lambda: _tiny(), "tinygemm64": lambda: _tiny(a64), "tinygemm24": lambda: _tiny(a24),
          "generic64": lambda: _tuned(a64, force_generic=1), "generic64_nosplit": lambda: _tuned(a64, force_generic=1, splits=1),
+         "fast128x160": lambda: _tuned(a256, variant=1, splits=1), "generic256": lambda: _tuned(a256, force_generic=1, splits=1),
+         "attention": lambda: [ops.attention(qa, qa, qa, 10, 64) for _ in range(4)],
+         "conv_in": lambda: _convin(),
          "tiny24_nosplit": lambda: _tuned(a24, splits=1), "fast64_split2": lambda: _tuned(a64, splits=2), "elementwise": lambda: (af * 1.0001 + 0.5).sum(), "copy": lambda: ag.copy_(af), "none": lambda: None}
 
 
