@@ -79,8 +79,14 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
   const long long pix0 = (long long)b * p.HW;
-  // every trip loads 4 pixels unconditionally (rows past the chunk end re-read its last pixel) and masks the sums
-  for (int px = p_begin + pr; px < p_end; px += 4 * p.R) {
+  // every trip loads 4 pixels unconditionally (rows past the chunk end re-read its last pixel) and masks the sums.
+  // The trip count is the SAME for every thread (the bound does not involve `pr`; a thread whose pixels are all past the end runs
+  // a fully masked trip: + 0 to every sum): the loop then carries no per-lane EXEC updates.  Round 4: with the per-thread bound
+  // `px < p_end` the last instructions of an iteration were the sum-of-squares updates, directly followed by the EXEC update that
+  // retires the lanes that are done -- and beside another stream's generic-kernel launches lanes 48..63 of a wave occasionally
+  // lost exactly those last updates (sums intact, sums of squares a few terms short: profiles/r04_pipelined_race.jsonl).
+  for (int base = p_begin; base < p_end; base += 4 * p.R) {
+    const int px = base + pr;
     f16x8 x[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -157,9 +163,11 @@ __global__ void ea_gn_apply_kernel(GnParams p) {
     if (nsub < 1) nsub = 1;
     for (int t = tid; t < nsub * p.groups; t += blockDim.x) {
       const int g = t % p.groups, sub = t / p.groups;
-      // chunks sub, sub + nsub, ... in that order, four loads in flight per trip (clamped index, masked sum)
+      // chunks sub, sub + nsub, ... in that order, four loads in flight per trip (clamped index, masked sum); the trip count
+      // does not depend on the thread (see ea_gn_stats_kernel: no per-lane EXEC update behind the accumulation)
       float gs = 0.0f, gq = 0.0f;
-      for (int ch = sub; ch < p.nchunk; ch += 4 * nsub) {
+      for (int ch0 = 0; ch0 < p.nchunk; ch0 += 4 * nsub) {
+        const int ch = ch0 + sub;
         float ps[4], pq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -25,11 +25,10 @@ latest (its decode waits for nothing but its own loop); throughput is what moves
 the caller's stream (same results as `pipe(**kw)`, no second stream, no thread).**  With `overlap=True` the throughput gain was
 measured (+1.7 ... +2.8 % at the benchmark's shape), and then a stress test found the captured loop's RESULT changing when work runs
 beside it on a second HIP stream (up to 0.1 on O(1) latents in 60-75 % of runs; plain calls are bit-deterministic).  The hunt
-(tools/diag_kernel_race.py, profiles/r04_pipelined_race.jsonl) found two causes: a missing barrier in the d = 64
-LDS-DMA attention kernel (a real WAR race, fixed), and launches of the GENERIC contraction kernel (M < 32 GEMMs, convolutions with
-channel counts that are not multiples of 64: VAE conv_in / conv_out, the hint stack, the time-embedding MLP -- all of them in
-`front` / `back`) perturbing GroupNorm statistics launches of the other stream, mechanism not understood (8 of 25 stress runs still
-differ).  Until that is, nothing runs beside a captured loop in the shipped configuration.
+(tools/diag_kernel_race.py, profiles/r04_pipelined_race.jsonl) found two kernel bugs that only a busy neighbour
+exposes -- a missing barrier in the d = 64 LDS-DMA attention kernel, and sum-of-squares updates lost behind a per-lane EXEC update
+in the GroupNorm statistics loop -- and fixed both: 0 of 30 stress runs differ now.  The default stays off until that has soaked
+longer (the fixes landed with the round's GPU budget spent).
 """
 import concurrent.futures
 import time
