@@ -101,11 +101,14 @@ def test_inpaint_pipeline_decoded_image_vs_reference_golden(mg, gold, tiny):
     assert np.abs(np.asarray(pil[0]).astype(np.int32) - np.round(ref[0] * 255).astype(np.int32)).max() <= 6
 
 
-def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny, overlap):
     """serving.PipelinedRunner (the pipeline call as three stages, front / loop / back, over a queue of requests) computes,
     request by request, the bits `pipe(**kw)` computes -- five requests with different seeds / images / controls / prompts
     (front as a plain kwargs dict and as a callable that runs a SAM encode first), and request 0 still meets the reference
-    golden.  Shipped form: the stages of a request in order on the caller's stream (overlap=False)."""
+    golden.  overlap=False is the shipped form (the stages of a request in order on the caller's stream); overlap=True runs
+    front(i+1) / back(i-1) on a second stream, from a worker thread, underneath loop(i) (serving.py; the full-size stress of that
+    form is tools/diag_pipeline_det.py)."""
     from editanything_amd import serving
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
     from editanything_amd.sam import ImageEncoderViT
@@ -128,7 +131,7 @@ def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny):
     sam_want = enc.forward_graph(x_sam).clone()
     assert rel_l2(want[0], gold["inpaint_a_none"]) <= 1.5e-2
     pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
-    runner = serving.PipelinedRunner(pipe)
+    runner = serving.PipelinedRunner(pipe, overlap=overlap)
     embs = []
 
     def request(r, kw):
@@ -141,6 +144,7 @@ def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny):
         torch.cuda.synchronize()
         for r, (g, w) in enumerate(zip(got, want)):
             assert torch.equal(g.images, w), f"round {rounds} request {r}: rel-L2 {rel_l2(g.images, w):.3e}"
+    runner.close()
     assert len(pipe._graphs) == 1 and all(torch.equal(e, sam_want) for e in embs)
     # decoded output through the side stream's VAE decode
     kw = dict(reqs[1], output_type="np")
