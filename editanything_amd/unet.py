@@ -636,10 +636,10 @@ class ControlledDenoiser:
         streams = self._streams(split)
         # ---- phase 0, on the caller's stream, BEFORE the fork: every network's first convolution (conv_in, 4 input channels: the
         # one layer of an evaluation that the LDS-DMA contraction kernel does not take -- K is not a multiple of 64 -- and that runs
-        # on the register-staged generic kernel).  Round 4 found that generic kernel perturbing GroupNorm launches of ANOTHER stream
-        # that share the chip with it (tools/diag_kernel_race.py, profiles/r04_pipelined_race.jsonl: a GroupNorm partial sum off by a
-        # few terms, 30-50 % of evaluations beside a stream of generic launches; cause not understood); nothing of it was ever seen
-        # inside an evaluation, but with the two launches here no generic launch has a concurrent neighbour by construction.
+        # on the register-staged generic kernel, whose epilogue is a long VALU burst).  Round 4 found launches of that kernel on one
+        # stream exposing a lost-update bug in the GroupNorm statistics loop of ANOTHER stream sharing the SIMDs (DESIGN.md 8f-1;
+        # fixed in ea_norm.hip).  Nothing of it was ever seen inside an evaluation, and the loop is fixed; issuing the two launches
+        # here simply keeps the one VALU-heavy contraction of an evaluation from ever having a concurrent neighbour (cost: ~10 us).
         for c in ctx:
             c["h0_u"] = u._run(u.input_blocks[0], c["xin"], None, c["emb_u"], c["kv_u"])
             c["h0_c"] = [cn._run(cn.input_blocks[0], x_cn, None, emb_c, kv, residual=gh) for cn, x_cn, emb_c, kv, gh, sc in c["jobs"]]
