@@ -16,6 +16,14 @@ HEADERS = ["ea_platform.h", "ea_gemm.h", "ea_gemm2.h", "ea_prims.h", "ea_epi_tr.
 # experiment kernels compiled into the tools / emulation builds only (-DEA_TOOLS=1)
 TOOLS_HEADERS = [os.path.join(ROOT, "tools", "kernels", "ea_gemm3.h")]
 LIB = os.path.join(HERE, "libeditanything_hip.so")
+# Compile flags of the product library.  `-target-feature -packed-fp32-ops`: NO packed fp32 VALU instruction (v_pk_fma_f32 /
+# v_pk_mul_f32 / v_pk_add_f32 / v_pk_mov_b32) is ever emitted.  Round 5 (tools/probe_pk_swap.hip,
+# profiles/r05_gn_exec_repro.*): on gfx950 such an instruction with a cross-half source selection (op_sel: the low result reads
+# the HIGH half of src1 / src2 -- hipcc's code for a horizontal add, e.g. in the round-3 GroupNorm statistics loop) returns wrong
+# data in lanes 48..63 while another wave of the same SIMD has MFMAs in flight -- i.e. beside any matrix-core kernel of a second
+# stream.  tests/test_isa_hazards.py compiles every source with exactly these flags and fails on any instruction of the class.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 EMU_LIB = os.path.join(EMU_DIR, "libeditanything_emu.so")
 
@@ -42,8 +50,7 @@ def build_hip(force=False, verbose=True):
     objs = []
     for s in srcs:
         o = s[:-4] + ".o"
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-               "-c", s, "-o", o]
+        cmd = [_hipcc()] + HIP_FLAGS + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -85,6 +85,9 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
   // `px < p_end` the last instructions of an iteration were the sum-of-squares updates, directly followed by the EXEC update that
   // retires the lanes that are done -- and beside another stream's generic-kernel launches lanes 48..63 of a wave occasionally
   // lost exactly those last updates (sums intact, sums of squares a few terms short: profiles/r04_pipelined_race.jsonl).
+#if defined(EA_GN_STATS_LOOP) && EA_GN_STATS_LOOP
+#include "../../tools/kernels/ea_gn_stats_loops.h"   // reproducer builds only (tools/build_gn_repro.sh): the round-3 loop forms
+#else
   for (int base = p_begin; base < p_end; base += 4 * p.R) {
     const int px = base + pr;
     f16x8 x[4];
@@ -104,6 +107,7 @@ __global__ void ea_gn_stats_kernel(GnParams p) {
       }
     }
   }
+#endif
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     chs[pr * p.C + c0 + j] = s[j];

@@ -759,8 +759,9 @@ class StableDiffusionControlNetInpaintMixingPipeline(StableDiffusionControlNetIn
     pulled towards the re-noised original by alpha and the kept region is re-noised (first `alignment_ratio` of the
     steps) or left alone.  4-channel UNets only (the 9-channel inpainting UNet has no such blend, :2039)."""
 
-    def __call__(self, *args, alpha_weight=0.5, **kw):
-        return super().__call__(*args, alpha_weight=alpha_weight, **kw)
+    # the argument normalisation lives in `front`, the one entry both `__call__` and `serving.PipelinedRunner` go through
+    def front(self, *args, alpha_weight=0.5, **kw):
+        return super().front(*args, alpha_weight=alpha_weight, **kw)
 
 
 class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline):
@@ -769,8 +770,8 @@ class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline
 
     _guess_mode_cond_only = True    # utils/stable_diffusion_controlnet.py:579-600
 
-    def __call__(self, prompt=None, image=None, **kw):
+    def front(self, prompt=None, image=None, **kw):
         if "controlnet_conditioning_image" not in kw:
             kw["controlnet_conditioning_image"] = image
             image = None
-        return super().__call__(prompt=prompt, image=None, mask_image=None, **kw)
+        return super().front(prompt=prompt, image=None, mask_image=None, **kw)

@@ -1,12 +1,21 @@
-"""`-m gpu` regression test for the two round-4 kernel bugs that only a busy neighbour stream exposed (DESIGN.md 8f-1,
-profiles/r04_pipelined_race.jsonl): the missing barrier in the d = 64 LDS-DMA attention kernel and the sum-of-squares updates
-lost behind a per-lane EXEC update in the GroupNorm statistics loop.
+"""`-m gpu` regression tests: every shipped kernel path is BIT-STABLE beside a busy second stream.
 
-ONE ControlNet + UNet evaluation at the benchmark's size (SD2.1, network batch 8 = 4 images x CFG, 64 x 64 latents, synthetic
-weights), eagerly and as a HIP-graph replay, beside a second thread that keeps launching on a second stream exactly the work that
-showed the bugs -- this library's generic contraction kernel (`conv_in`-shaped convolutions, 20-row GEMMs) and a torch elementwise +
-reduction chain.  Every result must equal the undisturbed one BIT FOR BIT.  Before the fixes 40 - 70 % of such evaluations differed
-(max |diff| ~1e-3 per evaluation, 0.1 after a 20-step loop); the file sorts last so that a regression here does not hide other tests.
+History (profiles/r04_pipelined_race.jsonl, profiles/r05_gn_exec_repro.*): a gradio worker pool
+(sam2image.py:267) puts two streams on one GPU as a matter of course, and round 4 found two kernel bugs that only a busy
+neighbour exposes -- a missing barrier in the d = 64 LDS-DMA attention kernel, and GroupNorm sum-of-squares updates that
+came out wrong in lanes 48..63.  Round 5 traced the second one to the instruction level: on gfx950 a PACKED fp32 VALU
+operation whose low result reads the HIGH half of a source (`v_pk_fma_f32 ... op_sel:[0,0,1] op_sel_hi:[1,1,0]`, hipcc's
+code for a horizontal add) returns wrong data in the last 16 lanes while ANOTHER wave of the SIMD has MFMAs in flight
+(tools/probe_pk_swap.hip; up to 11 % of those lanes' results beside an MFMA loop, none alone).  The library is now built
+without packed fp32 instructions at all (csrc/build.py, tests/test_isa_hazards.py).
+
+Each test runs one kernel path of the product -- a ControlNet + UNet evaluation (eager and HIP-graph replay, one- and
+two-stream form), the SAM ViT-H encoder in fp16 and in the fp32-accurate mode, the VAE, the SAM prompt / mask decoder, the
+attention instantiations of BASELINE config 4 (d = 40 / 80 / 160) -- beside a thread that keeps a second stream busy with
+(i) this library's generic contraction kernel (`conv_in`-shaped convolutions, 20-row GEMMs: the round-4 trigger),
+(ii) matrix-core work (hipBLASLt GEMMs + this library's LDS-DMA kernel: the round-5 trigger), (iii) a torch elementwise +
+reduction chain, (iv) a second copy of the path under test.  Every result must equal the undisturbed one BIT FOR BIT.
+The file sorts last so that a regression here does not hide other tests.
 """
 import threading
 
@@ -17,11 +26,97 @@ from editanything_amd import arch, ops, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-EVALS = 24
+NEIGHBOURS = ("generic", "mfma", "chain", "self")
 
 
 def _same(a, b):
-    return bool((a.contiguous().view(torch.uint8) == b.contiguous().view(torch.uint8)).all())
+    if isinstance(a, (tuple, list)):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    return a.shape == b.shape and bool((a.contiguous().view(torch.uint8) == b.contiguous().view(torch.uint8)).all())
+
+
+def _clone(o):
+    return tuple(_clone(x) for x in o) if isinstance(o, (tuple, list)) else o.clone()
+
+
+class Neighbour:
+    """A host thread that keeps `kind` of work flowing on its own stream (own workspace tag) until the block exits."""
+    _ops = None
+
+    def __init__(self, kind, self_fn=None):
+        self.kind, self.self_fn = kind, self_fn
+        self.side = torch.cuda.Stream()
+        self.stop = threading.Event()
+        self.failed = []
+        self.launched = 0
+        if Neighbour._ops is None:
+            g = torch.Generator("cpu").manual_seed(77)
+            Neighbour._ops = dict(
+                x8=(torch.randn(4, 64, 64, 8, generator=g) * 0.5).half().to(DEV), w8=(torch.randn(320, 72, generator=g) * 0.05).half().to(DEV),
+                a20=(torch.randn(20, 1280, generator=g) * 0.1).half().to(DEV), w12=(torch.randn(1280, 1280, generator=g) * 0.05).half().to(DEV),
+                a2k=(torch.randn(2048, 1280, generator=g) * 0.1).half().to(DEV), af=torch.randn(2048, 2048, generator=g).to(DEV),
+                mm=(torch.randn(2048, 2048, generator=g) * 0.05).half().to(DEV))
+
+    def _work(self):
+        o = Neighbour._ops
+        if self.kind == "generic":
+            for _ in range(8):
+                ops.conv2d(o["x8"], o["w8"])
+                ops.gemm(o["a20"], o["w12"])
+        elif self.kind == "mfma":
+            for _ in range(4):
+                torch.matmul(o["mm"], o["mm"])
+                ops.gemm(o["a2k"], o["w12"])
+        elif self.kind == "chain":
+            (o["af"] * 1.0001 + 0.5).sum()
+        else:
+            self.self_fn()
+
+    def __enter__(self):
+        def bg():
+            try:
+                torch.cuda.set_device(0)
+                with torch.no_grad(), torch.cuda.stream(self.side), ops.aux_workspace(16):
+                    while not self.stop.is_set():
+                        for _ in range(4):
+                            self._work()
+                            self.launched += 1
+                        self.side.synchronize()
+            except BaseException as e:          # surfaced by the main thread
+                self.failed.append(e)
+        self.th = threading.Thread(target=bg)
+        self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        self.th.join()
+        torch.cuda.synchronize()
+        assert not self.failed, self.failed
+        assert self.launched > 0
+
+
+def _stable(name, run, runs, self_fn=None, kinds=NEIGHBOURS):
+    """run() beside every neighbour kind: `runs` results each, all equal to the undisturbed one."""
+    with torch.no_grad():
+        want = _clone(run())
+        torch.cuda.synchronize()
+        assert _same(run(), want), f"{name}: not deterministic undisturbed"
+        if self_fn is not None:
+            with ops.aux_workspace(16):
+                self_fn()                           # first call of the copy (allocations, planning) before any thread runs it
+            torch.cuda.synchronize()
+        for kind in kinds:
+            if kind == "self" and self_fn is None:
+                continue
+            with Neighbour(kind, self_fn):
+                bad = 0
+                for _ in range(runs):
+                    out = run()
+                    torch.cuda.synchronize()
+                    bad += int(not _same(out, want))
+            print(f"{name} beside {kind}: {bad} of {runs} results differ")
+            assert bad == 0, f"{name} beside {kind}: {bad} of {runs} results differ from the undisturbed one"
 
 
 def test_an_evaluation_is_bit_stable_beside_a_busy_second_stream():
@@ -34,29 +129,7 @@ def test_an_evaluation_is_bit_stable_beside_a_busy_second_stream():
     hint = torch.cat([hint, hint])
     ctx = (torch.randn(8, 77, 1024, generator=g) * 0.5).to(DEV)
     ts = torch.full((8,), 501, dtype=torch.long, device=DEV)
-    # the neighbour's work: generic-kernel launches (4-channel convolution, 20-row GEMM) and a torch chain
-    x8 = (torch.randn(4, 64, 64, 8, generator=g) * 0.5).half().to(DEV)
-    w8 = (torch.randn(320, 72, generator=g) * 0.05).half().to(DEV)
-    a20 = (torch.randn(20, 1280, generator=g) * 0.1).half().to(DEV)
-    w12 = (torch.randn(1280, 1280, generator=g) * 0.05).half().to(DEV)
-    af = torch.randn(2048, 2048, generator=g).to(DEV)
-    side = torch.cuda.Stream()
-    stop = threading.Event()
-    failed = []
-
-    def neighbour():
-        try:
-            torch.cuda.set_device(0)
-            with torch.no_grad(), torch.cuda.stream(side), ops.aux_workspace(16):
-                while not stop.is_set():
-                    for _ in range(4):
-                        ops.conv2d(x8, w8)
-                        ops.gemm(a20, w12)
-                    (af * 1.0001 + 0.5).sum()
-                    side.synchronize()
-        except BaseException as e:          # surfaced by the main thread
-            failed.append(e)
-
+    evals = 16
     for overlap in (False, True):           # the single-stream evaluation and the shipped two-stream form
         den = ControlledDenoiser(un, [cn], overlap=overlap)
         with torch.no_grad():
@@ -78,21 +151,72 @@ def test_an_evaluation_is_bit_stable_beside_a_busy_second_stream():
             torch.cuda.synchronize()
             gwant = gout.clone()
             assert _same(gwant, want)
-            stop.clear()
-            th = threading.Thread(target=neighbour)
-            th.start()
-            try:
-                eager_bad = sum(int(not _same(run(), want)) for _ in range(EVALS))
-                graph_bad = 0
-                for _ in range(EVALS):
-                    graph.replay()
-                    torch.cuda.synchronize()
-                    graph_bad += int(not _same(gout, gwant))
-            finally:
-                stop.set()
-                th.join()
-                torch.cuda.synchronize()
-            assert not failed, failed
-            print(f"overlap={overlap}: {eager_bad} of {EVALS} eager evaluations and {graph_bad} of {EVALS} graph replays differ beside the busy stream")
-            assert eager_bad == 0 and graph_bad == 0
+            for kind in ("generic", "mfma", "chain"):
+                with Neighbour(kind):
+                    eager_bad = sum(int(not _same(run(), want)) for _ in range(evals))
+                    graph_bad = 0
+                    for _ in range(evals):
+                        graph.replay()
+                        torch.cuda.synchronize()
+                        graph_bad += int(not _same(gout, gwant))
+                print(f"overlap={overlap} beside {kind}: {eager_bad} of {evals} eager evaluations and {graph_bad} of {evals} graph replays differ")
+                assert eager_bad == 0 and graph_bad == 0
         del graph, den
+
+
+def test_the_sam_encoder_fp16_and_fp32_accurate_is_bit_stable_beside_a_busy_second_stream():
+    """SAM ViT-H at full width, 8 blocks (two of them global): window attention, rel-pos tables, LayerNorm row maps, the
+    d = 80 attention instantiations, the split-operand exact Linears / exact attention (sam_exact.py)."""
+    from editanything_amd.sam import ImageEncoderViT
+    from editanything_amd.sam_exact import ImageEncoderViTExact
+    cfg = dict(arch.SAM_VIT_H, depth=8, global_attn_indexes=(3, 7))
+    sd = synth.synth_state_dict_torch(arch.sam_encoder_param_shapes(cfg), 5)
+    g = torch.Generator("cpu").manual_seed(1)
+    x = torch.randn(1, 3, 1024, 1024, generator=g).to(DEV)
+    enc, enc2 = ImageEncoderViT(cfg, sd, DEV), ImageEncoderViT(cfg, sd, DEV)
+    _stable("SAM encoder fp16", lambda: enc.forward(x), 6, self_fn=lambda: enc2.forward(x))
+    del enc, enc2
+    ex, ex2 = ImageEncoderViTExact(cfg, sd, DEV), ImageEncoderViTExact(cfg, sd, DEV)
+    _stable("SAM encoder fp32-accurate", lambda: ex.forward(x), 4, self_fn=lambda: ex2.forward(x))
+
+
+def test_the_vae_is_bit_stable_beside_a_busy_second_stream():
+    from editanything_amd.vae import AutoencoderKL
+    sd = synth.synth_state_dict_torch(arch.vae_param_shapes(arch.VAE_KL_F8), 7)
+    vae, vae2 = AutoencoderKL(arch.VAE_KL_F8, sd, DEV), AutoencoderKL(arch.VAE_KL_F8, sd, DEV)
+    g = torch.Generator("cpu").manual_seed(2)
+    z = torch.randn(1, 4, 64, 64, generator=g).to(DEV)
+    img = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).to(DEV)
+    _stable("VAE decode", lambda: vae.decode(z), 6, self_fn=lambda: vae2.decode(z))
+    _stable("VAE encode", lambda: vae.encode_moments(img), 6, self_fn=lambda: vae2.encode_moments(img))
+
+
+def test_the_sam_mask_decoder_is_bit_stable_beside_a_busy_second_stream():
+    """Prompt encoder + two-way transformer + upscaling tail for 256 point prompts (ea_sam.hip's three kernels)."""
+    from editanything_amd.amg import SamPromptDecoder
+    sd = synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), 9)
+    dec, dec2 = SamPromptDecoder(sd, DEV), SamPromptDecoder(sd, DEV)
+    g = torch.Generator("cpu").manual_seed(3)
+    emb = (torch.randn(1, 256, 64, 64, generator=g) * 0.5).to(DEV)
+    pts = (torch.rand(256, 1, 2, generator=g) * 1024).to(DEV)
+    lab = torch.ones(256, 1, device=DEV)
+
+    def mk(d):
+        tokens = d.image_tokens(emb)
+        return lambda: d.predict_masks(tokens, (64, 64), d.embed_points(pts, lab), True)
+    with torch.no_grad():
+        run, run2 = mk(dec), mk(dec2)
+    _stable("SAM mask decoder", run, 6, self_fn=run2)
+
+
+@pytest.mark.parametrize("heads,d,n", [(8, 40, 9216), (8, 80, 2304), (8, 160, 576)])
+def test_the_config4_attention_instantiations_are_bit_stable_beside_a_busy_second_stream(heads, d, n):
+    """SD1.5 head dimensions at 96 x 96 latents (BASELINE config 4): self-attention and the 77-token cross-attention."""
+    g = torch.Generator("cpu").manual_seed(4)
+    q = (torch.randn(2, n, heads * d, generator=g) * 0.5).half().to(DEV)
+    k = (torch.randn(2, n, heads * d, generator=g) * 0.5).half().to(DEV)
+    v = (torch.randn(2, n, heads * d, generator=g) * 0.5).half().to(DEV)
+    kc = (torch.randn(2, 77, heads * d, generator=g) * 0.5).half().to(DEV)
+    vc = (torch.randn(2, 77, heads * d, generator=g) * 0.5).half().to(DEV)
+    run = lambda: (ops.attention(q, k, v, heads, d), ops.attention(q, kc, vc, heads, d))
+    _stable(f"attention d={d}", run, 6, self_fn=run)

@@ -66,7 +66,9 @@ dec.predict_masks(st["tokens"], st["emb_hw"], dec.embed_points(p[:, None, :], to
 torch.cuda.synchronize()
 recs_p, ops.PROFILE = ops.PROFILE, None
 agg = {}
-for fl, e0, e1, label in recs_p:
+for fl, e0, e1, label, _nbytes in recs_p:
+    if label.startswith("mark "):
+        continue
     a = agg.setdefault(label, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3; a[2] += fl
 tot = sum(v[1] for v in agg.values())
 print(f"C-ABI launches of one {amg.DECODE_BATCH}-prompt decoder batch: {tot / 1e3:.2f} ms")

@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_exp
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DEA_ATTN_EXP=$m \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Xclang -target-feature -Xclang -packed-fp32-ops -DEA_ATTN_EXP=$m \
     -shared editanything_amd/csrc/ea_attn.hip editanything_amd/csrc/ea_norm.hip -o gpurun_exp/libea_attn_exp$m.so 2> gpurun_exp/build_attn_exp$m.log &
 done
 wait

@@ -10,7 +10,7 @@ set -e
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_exp
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -DEA_EXP=$m -DEA_TOOLS=1 -I editanything_amd/csrc \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-only -Xclang -target-feature -Xclang -packed-fp32-ops -DEA_EXP=$m -DEA_TOOLS=1 -I editanything_amd/csrc \
     -shared editanything_amd/csrc/ea_gemm.hip -o gpurun_exp/libea_exp$m.so 2> gpurun_exp/build_exp$m.log &
 done
 wait

@@ -1,6 +1,12 @@
-import os, sys, torch, numpy as np
+"""Graph replay vs eager determinism of a tiny two-ControlNet pipeline, with the LayerNorm fold on or off.
+
+    python tools/diag_det.py [ln_fold=1|0]      (ops.configure; the EA_* environment switches are gone since round 4)
+"""
+import os, sys, torch
 sys.path.insert(0, os.getcwd())
-from editanything_amd import arch, synth, models
+from editanything_amd import arch, synth, models, ops
+LN_FOLD = bool(int(dict(a.split("=") for a in sys.argv[1:]).get("ln_fold", 1)))
+ops.configure(ln_fold=LN_FOLD)
 ucfg, ccfg, vcfg = arch.TINY_UNET, arch.TINY_CONTROLNET, arch.TINY_VAE
 usd = synth.synth_state_dict_torch(arch.unet_param_shapes(ucfg), 11)
 vsd = synth.synth_state_dict_torch(arch.vae_param_shapes(vcfg), 12)
@@ -18,4 +24,4 @@ for graph in (True, True, False, False):
     outs.append(p(**kw).images.float().cpu())
     outs.append(p(**kw).images.float().cpu())
 ref = outs[0]
-print("EA_LN_FOLD", os.environ.get("EA_LN_FOLD"), [float((o - ref).norm() / ref.norm()) for o in outs])
+print("ln_fold", LN_FOLD, [float((o - ref).norm() / ref.norm()) for o in outs])

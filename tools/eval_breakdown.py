@@ -25,7 +25,9 @@ def collect(fn, reps=3):
         fn()
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
-        for fl, e0, e1, label in recs:
+        for fl, e0, e1, label, _nbytes in recs:
+            if label.startswith("mark "):
+                continue
             a = agg.setdefault(label, [0, 0.0, 0.0])
             a[0] += 1
             a[1] += e0.elapsed_time(e1) * 1e3

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -231,6 +232,149 @@ __global__ __launch_bounds__(512, 1) void gemm8(const f16* __restrict__ A, const
   }
 }
 
+
+// ---- round 5: the same tile and halves, scheduled as the guide's template actually runs it: TWO barriers per phase
+// (load part | barrier | MFMA part | barrier) and the two wave rows STAGGERED by one barrier, so that on every SIMD one wave
+// sits in its 16-MFMA cluster (s_setprio 1) while its partner reads fragments and issues the next half tile -- the round-2
+// prototype above ran all eight waves through the same part at the same time (the matrix pipe idles during every load part).
+// Group g = wave row.  Global phase q = 4 t + p.  Load part L(q): fragment reads for M(q), DMA of half s(p) of tile t + 1
+// (s = A-h0, B-h0, B-h1, A-h1), then vmcnt(4): the half staged in L(q - 2) has landed for this wave.  A half staged in L(q)
+// is first read in L(q + 3) (L(q + 4) for A-h0) -- one barrier after the last wave's wait (the lagging group's L(q + 2)).
+// WAR: a half's last read (L(q - 4 + r), r <= 2, retired by the lgkmcnt(0) in front of that phase's MFMAs) lies >= 2 barriers
+// before its restaging in L(q).  B quadrant 0 stays in registers from phase 0 to phase 3.
+//   FL bit 0: no stagger (both groups in lockstep)   bit 1: no s_setprio   bit 2: sched_barrier(0) around the MFMA cluster
+template <int FL>
+__global__ __launch_bounds__(512, 1) void gemm8s(const f16* __restrict__ A, const f16* __restrict__ W, f16* __restrict__ C, int M, int N, int K,
+                                                 int tiles_n) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int q8 = nwg / 8, r8 = nwg % 8, xcd = orig % 8;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + orig / 8;
+  int tm, tn;
+  if (FL & 8) {            // grouped order: 8 row tiles x all column tiles per group (an XCD's chunk shares few A row panels)
+    const int tiles_m = nwg / tiles_n, gm = tiles_m >= 8 ? 8 : tiles_m, per = gm * tiles_n;
+    const int grp = wg / per, in = wg % per;
+    const int rows = (grp * gm + gm <= tiles_m) ? gm : tiles_m - grp * gm;
+    tm = __builtin_amdgcn_readfirstlane(grp * gm + in % rows); tn = __builtin_amdgcn_readfirstlane(in / rows);
+  } else { tm = wg / tiles_n; tn = wg % tiles_n; }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nkt = K / BK;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(A), 0, BUF_BYTES, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(W), 0, BUF_BYTES, 0x00020000);
+  unsigned a_voff[2][2], b_voff[2][2];
+  int a_lds[2][2], b_lds[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = 2 * wave + i;
+      const int ar = a_half_row(h, g), br = b_half_row(h, g);
+      const int rl = lane >> 3, slot = lane & 7;
+      a_voff[h][i] = ((unsigned)(m0 + ar + rl) * (unsigned)K + (unsigned)((slot ^ swz(ar + rl)) * 8)) * 2u;
+      b_voff[h][i] = ((unsigned)(n0 + br + rl) * (unsigned)K + (unsigned)((slot ^ swz(br + rl)) * 8)) * 2u;
+      a_lds[h][i] = ar * 128;
+      b_lds[h][i] = BM * 128 + br * 128;
+    }
+  auto stage_a = [&](int h, int t) {
+    char* buf = smem + (t & 1) * KT_BYTES;
+    const unsigned soff = (unsigned)t * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(ra, a_voff[h][i], soff, buf + a_lds[h][i]);
+  };
+  auto stage_b = [&](int h, int t) {
+    char* buf = smem + (t & 1) * KT_BYTES;
+    const unsigned soff = (unsigned)t * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16(rw, b_voff[h][i], soff, buf + b_lds[h][i]);
+  };
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int l15 = lane & 15, lq = lane >> 4;
+  f16x8 fa[4][2], fb[2][2][2];
+  auto read_a = [&](const char* buf, int qa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = wm * 128 + qa * 64 + i * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fa[i][ks] = *reinterpret_cast<const f16x8*>(buf + r * 128 + (((ks * 4 + lq) ^ swz(r)) << 4));
+    }
+  };
+  auto read_b = [&](const char* buf, int qb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wn * 64 + qb * 32 + j * 16 + l15;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) fb[qb][j][ks] = *reinterpret_cast<const f16x8*>(buf + BM * 128 + r * 128 + (((ks * 4 + lq) ^ swz(r)) << 4));
+    }
+  };
+  auto mma = [&](int qa, int qb) {
+    wait_lds();
+    if (FL & 4) __builtin_amdgcn_sched_barrier(0);
+    if (!(FL & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[qa * 4 + i][qb * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[qb][j][ks], fa[i][ks], acc[qa * 4 + i][qb * 2 + j], 0, 0, 0);
+    if (!(FL & 2)) __builtin_amdgcn_s_setprio(0);
+    if (FL & 4) __builtin_amdgcn_sched_barrier(0);
+  };
+  stage_a(0, 0);
+  stage_b(0, 0);
+  stage_b(1, 0);
+  stage_a(1, 0);
+  wait_dma<4>();
+  barrier();
+  if (!(FL & 1) && wm == 1) barrier();
+  auto tile = [&](int t, auto more_c) {
+    constexpr bool more = decltype(more_c)::value;
+    const char* buf = smem + (t & 1) * KT_BYTES;
+    read_a(buf, 0);
+    read_b(buf, 0);
+    if (more) { stage_a(0, t + 1); wait_dma<4>(); } else wait_dma<2>();
+    barrier();
+    mma(0, 0);
+    barrier();
+    read_b(buf, 1);
+    if (more) { stage_b(0, t + 1); wait_dma<4>(); } else wait_dma<0>();
+    barrier();
+    mma(0, 1);
+    barrier();
+    read_a(buf, 1);
+    if (more) { stage_b(1, t + 1); wait_dma<4>(); }
+    barrier();
+    mma(1, 1);
+    barrier();
+    if (more) { stage_a(1, t + 1); wait_dma<4>(); }
+    barrier();
+    mma(1, 0);
+    barrier();
+  };
+  for (int t = 0; t + 1 < nkt; ++t) tile(t, std::true_type{});     // no "is there a next tile" test inside a phase
+  tile(nkt - 1, std::false_type{});
+  if (!(FL & 1) && wm == 0) barrier();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + l15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + j * 16 + lq * 4;
+      f16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (f16)acc[i][j][e];
+      *reinterpret_cast<f16x4*>(C + (long long)m * N + n) = o;
+    }
+  }
+}
+
+
 template <int FLAGS>
 static double run_shape(int M, int N, int K, bool check) {
   std::vector<f16> ha((size_t)M * K), hw((size_t)N * K);
@@ -246,8 +390,9 @@ static double run_shape(int M, int N, int K, bool check) {
   CK(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
   const int tiles_m = M / BM, tiles_n = N / BN;
   const int smem = 2 * KT_BYTES;
-  CK(hipFuncSetAttribute((const void*)gemm8<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-  auto launch = [&]() { gemm8<FLAGS><<<tiles_m * tiles_n, 512, smem>>>(da, dw, dc, M, N, K, tiles_n); };
+  auto kfn = FLAGS >= 256 ? gemm8s<(FLAGS >= 256 ? FLAGS - 256 : 0)> : gemm8<(FLAGS >= 256 ? 0 : FLAGS)>;
+  CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  auto launch = [&]() { kfn<<<tiles_m * tiles_n, 512, smem>>>(da, dw, dc, M, N, K, tiles_n); };
   launch();
   CK(hipDeviceSynchronize());
   double max_err = 0.0;
@@ -301,13 +446,17 @@ static void sweep(int argc, char** argv) {
   run_shape<FLAGS>(8192, 8192, 8192, false);
   run_shape<FLAGS>(16384, 3840, 1280, true);      // SAM qkv
   run_shape<FLAGS>(16384, 1280, 5120, true);
+  run_shape<FLAGS>(16384, 5120, 1280, true);      // SAM MLP in
+  run_shape<FLAGS>(65536, 512, 4608, true);       // VAE conv3x3 128^2 512 -> 512 as a plain GEMM
+  run_shape<FLAGS>(8192, 5120, 640, true);        // level-1 GEGLU projection
   run_shape<FLAGS>(32768, 256, 2880, true);       // a level-0 3x3 convolution's K
   run_shape<FLAGS>(32768, 2560, 320, true);       // level-0 GEGLU projection
 }
 
 int main(int argc, char** argv) {
-  sweep<0>(argc, argv);
-  sweep<8>(argc, argv);
-  sweep<12>(argc, argv);
+  sweep<0>(argc, argv);         // round-2 prototype (one barrier per phase, lockstep)
+  sweep<256>(argc, argv);       // round 5: two barriers per phase, staggered wave rows, s_setprio
+  sweep<256 + 8>(argc, argv);   //   ... grouped tile order (8 row tiles x all column tiles per group)
+  sweep<256 + 2>(argc, argv);   //   ... no s_setprio
   return 0;
 }
