@@ -38,10 +38,11 @@ def parse():
     ap.add_argument("--sam", default="vit_h")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="EXPERIMENT (off by default, results not trustworthy: profiles/r04_pipelined_race.jsonl): software-pipeline "
-                         "the batches over two streams (serving.PipelinedRunner overlap=True) instead of running them strictly one "
-                         "after the other (SAM -> prepare -> loop -> decode on one stream)")
+    ap.add_argument("--pipeline", action="store_true", help="(default since round 5; kept so that older command lines still parse)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run the batches strictly one after the other on one stream (SAM -> prepare -> loop -> decode) instead of "
+                         "through the two-stream software pipeline (serving.PipelinedRunner, the serving default); the line "
+                         "always carries that measurement as `sequential`")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU walk through the multi-rank control flow (gloo): launch, weight broadcast, sharding, barriers, "
                          "max-over-ranks timing, rank-0 JSON line -- no GPU work, value is meaningless")
@@ -207,7 +208,7 @@ def main():
     pipe.decode_latents = lambda lat: (pipe.vae.decode_nhwc(lat / pipe.vae.scale_factor) / 2 + 0.5).clamp(0, 1)
     # the software pipeline is filled and drained inside the timed region (one batch's SAM + VAE encode up front, one decode
     # at the end: ~56 ms) and returns ~9 ms per step: below 8 steps the batches simply run one after the other
-    pipelined = args.pipeline and not args.no_graph and args.steps >= 8
+    pipelined = not args.no_pipeline and not args.no_graph and args.steps >= 8
     runner = serving.PipelinedRunner(pipe, overlap=True, threaded=args.pipeline_thread == "on",
                                      side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority],
                                      side_cus=args.side_cus) if pipelined else None
@@ -302,16 +303,15 @@ def main():
                                "device (no D2H copy / PIL conversion in the timed region); the part of an evaluation in "
                                "front of the first cross-attention (conv_in, first ResBlock, first self-attention) is "
                                "computed once for the two identical CFG halves"
-                               + ("; EXPERIMENT --pipeline: the `steps` batches run through a two-stream software pipeline "
-                                  "(serving.PipelinedRunner overlap=True): SAM encode + VAE encode + per-call invariants of batch i+1 "
-                                  "and the VAE decode of batch i-1 are issued on a side stream underneath the 20-step loop of batch i; "
-                                  "the pipeline starts EMPTY and is DRAINED inside the timed region; `sequential` = the same batches "
-                                  "one after the other, measured in the same process.  NOT the shipped configuration: the loop's "
-                                  "result is not reproducible beside a busy second stream (profiles/r04_pipelined_race.jsonl)"
+                               + ("; the `steps` batches run through the two-stream software pipeline that serves consecutive "
+                                  "requests (serving.PipelinedRunner, ON by default since round 5: SAM encode + VAE encode + per-call "
+                                  "invariants of batch i+1 and the VAE decode of batch i-1 are issued on a side stream underneath the "
+                                  "20-step loop of batch i; the pipeline starts EMPTY and is DRAINED inside the timed region); "
+                                  "`sequential` = the same batches one after the other on one stream, measured in the same process; "
+                                  "results are bit-identical either way (500-run soak: profiles/r05_pipeline_stress500.jsonl)"
                                   if runner is not None else
-                                  "; batches strictly one after the other on one stream (a two-stream software pipeline over "
-                                  "consecutive batches exists -- serving.PipelinedRunner, --pipeline: +1.7 ... +2.8 % -- and is OFF: "
-                                  "results of the captured loop change beside a busy second stream, profiles/r04_pipelined_race.jsonl)"),
+                                  "; batches strictly one after the other on one stream (--no-pipeline, --no-graph or fewer than 8 "
+                                  "steps: the software pipeline needs a few batches to fill)"),
                    "global_batch": args.batch * world, "parallelism": f"dp{world} (independent images, weight bcast only)",
                    "algorithmic_tflop_per_image": round(per_image_tf, 2),
                    "end_to_end_mfma_frac": round(value / world * per_image_tf / PEAK_FP16_TFLOPS, 4),
@@ -321,7 +321,8 @@ def main():
         result["sequential"] = seq
         result["pipelining_gain"] = round(value / world / seq["value"], 4)
     if rank == 0 and not args.quick:
-        result["calibration"] = calibration(dev)
+        result["config"]["calibration"] = calibration(dev)
+        result["config"]["value_x_mix_probe_ms"] = round(value / world * result["config"]["calibration"]["mix_probe_ms"], 2)
     if world == 1 and not args.no_extras and not args.quick:
         result.update(other_configs(args, dev, sds, pipe, sam))
         result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases, runner))
@@ -335,10 +336,20 @@ def main():
     eadist.barrier()
 
 
+# The workload's own launch mix as a box probe: the ten heaviest contraction classes of a step (profiles/r04_bench_line.json
+# roofline.classes, 45 % of its contraction time) -- (kind, shape, launches per step).  conv: (B, H, Cin, Cout); gemm: (M, N, K).
+MIX_PROBE = [("conv", (8, 8, 1280, 1280), 380), ("conv", (8, 32, 640, 640), 180), ("conv", (8, 16, 1280, 1280), 180),
+             ("gemm", (32768, 2560, 320), 140), ("gemm", (8192, 5120, 640), 140), ("gemm", (2048, 10240, 1280), 140),
+             ("gemm", (2048, 1280, 1280), 700), ("conv", (8, 64, 320, 320), 140), ("gemm", (2048, 1280, 5120), 140),
+             ("gemm", (32768, 320, 320), 620)]
+
+
 def calibration(dev):
-    """What lets a reader normalise `value` for the box it was measured on (boxes of this pool differ by up to 12 % on
-    one build): a device-to-device copy rate, the contraction kernel on one fixed cube, and the clocks /
-    power cap the box reports.  Untimed region; ~0.2 s."""
+    """What lets a reader normalise `value` for the box it was measured on (boxes of this pool differ by up to 12 % on one
+    build): `mix_probe_ms` = the ten heaviest contraction classes of THIS workload (MIX_PROBE), 20 launches
+    each on one stream, summed with their launches-per-step weights -- a step-shaped load, unlike the 4096^3 cube of round 4
+    whose ratio to `value` moved by 4-10 % between boxes -- plus a device-to-device copy rate and the clocks /
+    power the box reports.  Untimed region; ~0.3 s.  Goes INSIDE `config` (the driver keeps `config`)."""
     import subprocess
     from editanything_amd import ops
     out = {}
@@ -359,12 +370,28 @@ def calibration(dev):
     out["hbm_copy_gbps"] = round(2 * a.numel() * 4 / t / 1e9, 1)      # bytes read + bytes written
     del a, b
     g = torch.Generator("cpu").manual_seed(1)
-    x = (torch.randn(4096, 4096, generator=g) * 0.5).half().to(dev)
-    w = (torch.randn(4096, 4096, generator=g) * 0.5).half().to(dev)
-    o = torch.empty(4096, 4096, dtype=torch.float16, device=dev)
-    t = timed(lambda: ops.gemm(x, w, out=o), 20)
-    out["mfma_probe_tflops"] = round(2 * 4096 ** 3 / t / 1e12, 1)
-    out["mfma_probe"] = "ea_gemm_f16 4096 x 4096 x 4096, random fp16 operands, 20 launches"
+    mix_ms, mix_gf = 0.0, 0.0
+    for kind, shp, per_step in MIX_PROBE:
+        if kind == "gemm":
+            M, N, K = shp
+            x = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+            w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
+            o = torch.empty(M, N, dtype=torch.float16, device=dev)
+            fn = lambda: ops.gemm(x, w, out=o)
+            gf = 2.0 * M * N * K / 1e9
+        else:
+            B, H, ci, co = shp
+            x = (torch.randn(B, H, H, ci, generator=g) * 0.5).half().to(dev)
+            w = (torch.randn(co, 9 * ci, generator=g) * (9 * ci) ** -0.5).half().to(dev)
+            o = torch.empty(B, H, H, co, dtype=torch.float16, device=dev)
+            fn = lambda: ops.conv2d(x, w, out=o)
+            gf = 2.0 * B * H * H * co * 9 * ci / 1e9
+        mix_ms += per_step * timed(fn, 20) * 1e3
+        mix_gf += per_step * gf
+        del x, w, o
+    out["mix_probe_ms"] = round(mix_ms, 2)
+    out["mix_probe_tflops"] = round(mix_gf / mix_ms, 1)
+    out["mix_probe"] = "10 heaviest contraction classes of a step x launches per step, 20 launches each, one stream"
     try:
         r = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), "--showclocks", "--showpower", "--showmaxpower", "--json"],
                            capture_output=True, text=True, timeout=20)
@@ -372,7 +399,7 @@ def calibration(dev):
         keep = {}
         for k, v in card.items():
             kl = k.lower()
-            if any(t in kl for t in ("sclk", "mclk", "fclk", "power")):
+            if any(t in kl for t in ("sclk", "mclk", "power")):
                 keep[k] = v
         out["smi"] = keep
     except Exception as e:       # the tool or its JSON layout is not there: say so, never fail the bench

@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["ea_gemm.hip", "ea_norm.hip", "ea_attn.hip", "ea_elem.hip", "ea_sam.hip", "ea_exact.hip"]
-HEADERS = ["ea_platform.h", "ea_gemm.h", "ea_gemm2.h", "ea_prims.h", "ea_epi_tr.h", os.path.join(ROOT, "include", "editanything_hip.h")]
+HEADERS = ["ea_platform.h", "ea_gemm.h", "ea_gemm2.h", "ea_gemm8.h", "ea_prims.h", "ea_epi_tr.h", os.path.join(ROOT, "include", "editanything_hip.h")]
 # experiment kernels compiled into the tools / emulation builds only (-DEA_TOOLS=1)
 TOOLS_HEADERS = [os.path.join(ROOT, "tools", "kernels", "ea_gemm3.h")]
 LIB = os.path.join(HERE, "libeditanything_hip.so")

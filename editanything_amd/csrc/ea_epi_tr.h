@@ -16,7 +16,9 @@
 #include "ea_gemm.h"
 #include "ea_prims.h"
 
-template <int MI, int NI, int TRX, bool SYNC>
+// F32OUT (ea_gemm8.h only): compiles in the fp32-output form (p.epi_fast == 4: fp32 out, optional fp32 residual -- SAM's
+// residual stream, sam.py / sam_exact.py) -- a lane's quad IS 16 bytes of one fp32 output row, no pairing needed.
+template <int MI, int NI, int TRX, bool SYNC, bool F32OUT = false>
 __device__ __forceinline__ void ea_tr_epilogue(const EaGemmParams& p, f32x4 (&acc)[MI][NI], const int rowbase, const int colbase,
                                                const int tile_m0, const int batch, const int bz, const float (&ln_mu)[MI],
                                                const float (&ln_rs)[MI], char* scratch, const int wave_slot) {
@@ -138,10 +140,55 @@ __device__ __forceinline__ void ea_tr_epilogue(const EaGemmParams& p, f32x4 (&ac
     
     return;
   }
+  const float* rvp = e.rowvec ? e.rowvec + (long long)(tile_m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
+  if constexpr (F32OUT) {
+    if (p.epi_fast == 4) {
+      // ---- fp32 output (+ fp32 residual): same per-output order as the general epilogue (bias / row vector, activation,
+      // scale, residual), one 16-byte store per quad, 64 contiguous bytes per row per wave instruction.  Residual quads are
+      // fetched one row tile ahead of their use.
+      float* outf = (float*)e.out + cb0;
+      const float* res32 = e.residual32 ? e.residual32 + rb0 : nullptr;
+      if (rvp) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(rvp + ncl[j]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cb[j][r] += nok[j] ? t[r] : 0.0f;
+        }
+      }
+      f32x4 rq32[2][NI];
+      auto res_load = [&](int ii, int slot) {
+        int m = rowbase + ii * 16 + c16;
+        m = m < p.M ? m : p.M - 1;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) rq32[slot][j] = *reinterpret_cast<const f32x4*>(res32 + (long long)m * e.ldr + ncl[j]);
+      };
+      if (res32) res_load(0, 0);
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii) {
+        if (res32 && ii + 1 < MI) res_load(ii + 1, (ii + 1) & 1);
+        const int m = rowbase + ii * 16 + c16;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          f32x4 x = acc[ii][j] + cb[j];
+          if (e.act == EA_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = ea_silu(x[r]);
+          } else if (e.act == EA_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = ea_gelu_erf(x[r]);
+          }
+          x = x * e.scale;
+          if (res32) x += rq32[ii & 1][j];
+          if (m < p.M && nok[j]) *reinterpret_cast<f32x4*>(outf + (long long)m * e.ldc + ncl[j]) = x;
+        }
+      }
+      return;
+    }
+  }
   constexpr int JP = NI / 2;                    // column-tile pairs per row tile
   constexpr int IP = (NI & 1) ? MI / 2 : 0;     // row-tile pairs of the odd last column tile
   const f16* resp = e.residual ? e.residual + rb0 : nullptr;
-  const float* rvp = e.rowvec ? e.rowvec + (long long)(tile_m0 / e.rows_per_group) * e.rowvec_ld : nullptr;
   // where this lane's 8-column vectors go: column-pair vectors (ii, jp), then the odd tile's row-pair vectors (ip)
   int voff[MI * JP + IP + 1], roff[MI * JP + IP + 1];
 #pragma unroll

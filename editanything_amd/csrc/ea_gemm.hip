@@ -1,5 +1,6 @@
 // ea_gemm.hip -- C-ABI launchers for the MFMA contraction kernel (ea_gemm.h).
 #include "ea_gemm2.h"
+#include "ea_gemm8.h"
 #ifndef EA_TOOLS
 #define EA_TOOLS 0
 #endif
@@ -123,6 +124,21 @@ static bool fast_eligible(const EaGemmParams& p) {
 // wave-column blocks (= row-statistics parts) of an N-wide output: 80 columns with 160-wide tiles, else 64
 static int row_stat_parts(int N) { return (N % 160 == 0) ? N / 80 : (N + 63) / 64; }
 
+// ---- ea_gemm8.h (256 x 256 tiles, one 8-wave workgroup per CU): which launches take it.  Measured per class against the
+// 128 x 160 / 128 x 128 two-workgroups-per-CU tiles on one MI355X (profiles/r05_gemm8_probe_staggered.jsonl beside
+// r05_gemm_bench_shipped_same_box.jsonl, then through this library: profiles/r05_gemm8_shipped.jsonl): it wins where the
+// K loop is long enough to amortise a 64-KiB-per-tile prologue and a 128-KiB epilogue (K >= 1024) AND the tile count
+// fills whole rounds of the 256 CUs (a 320-tile launch runs two rounds for 1.25 rounds of work and loses).
+static bool gemm8_shape_ok(const EaGemmParams& p) {
+  if (p.K < 1024 || p.M < 2048 || p.N < 512) return false;
+  const long long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+  const double tiles = (double)tm * tn * p.batch;
+  const double rounds = tiles / 256.0;
+  if (rounds / ceil(rounds) < 0.9) return false;                              // partial last round
+  if ((double)p.M * p.N / ((double)tm * tn * 65536.0) < 0.93) return false;   // ragged edge tiles
+  return true;
+}
+
 // Tuning / A-B knobs (include/editanything_hip.h `ea_tuning`): set explicitly through ea_set_tuning() by tools and tests,
 // per host thread, all zero in production.  Nothing on the launch path reads the environment.
 //   force_generic   route everything to ea_gemm.h
@@ -132,6 +148,8 @@ static int row_stat_parts(int N) { return (N % 160 == 0) ? N / 80 : (N + 63) / 6
 //        5: 256 x bn, 4 waves 4x1 (64x160), 3-stage, 32x32x16
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
 //        9: 64 x bn, 2-stage   10 / 11 / 12: loader-wave forms   13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG
+//        30: ea_gemm8.h, 256 x 256, 8 waves 2x4 (wave tile 128x64), staggered 8-phase K tile (auto: gemm8_shape_ok)
+//        1 forced also keeps the automatic policy off ea_gemm8 (A/B)
 //   splits / bn     tuning sweeps: force the split-K factor / 128-wide column tiles
 //   no_register_direct   keep the LDS-slab epilogue where the register-direct one applies (A/B)
 //   debug           K-loop / epilogue ablations (ea_gemm2.h p.debug)
@@ -416,10 +434,29 @@ static bool same_launch(const FastSel& a, const FastSel& b) {
 
 // Plans the launch of p: fills the plan-dependent fields of p (split-K, partial buffer at workspace + ws_off, epilogue
 // form, tile order) and `s`.
+static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws_bytes, size_t ws_off, FastSel& s);
+
 static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t ws_off, FastSel& s) {
   // (an accumulator rescale at a K position -- acc_scale_kt -- needs the whole K range in one workgroup: no split-K)
   Plan2 t = plan_fast(p.M, p.N, p.K, p.batch, p.epi.act != EA_ACT_GEGLU && p.acc_scale_kt == 0, p.conv, p.epi.act == EA_ACT_GEGLU ? p.epi.geglu_block : 0);
-  if (p.acc_scale_kt > 0 && (t.splits != 1 || (t.kind != 1 && t.kind != 9))) return EA_ERR_UNSUPPORTED;
+  // ea_gemm8.h first where the shape policy (or a forced variant 30) asks for it; it exists with the register-direct epilogue
+  // only (plain / raw split-K forms, no fold, no statistics), so a launch that needs anything else keeps the plan above
+  const EaEpilogue& e0 = p.epi;
+  if ((g_variant == 30 || (g_variant == 0 && g_force_splits == 0 && !g_no_tr && gemm8_shape_ok(p))) && e0.act != EA_ACT_GEGLU &&
+      !e0.ln_stats && !e0.row_stats_out && !e0.gn_stats_out && !e0.gn_next_out && !(EA_TOOLS && g_tune.debug)) {
+    Plan2 t8 = t;
+    t8.kind = 30; t8.bm = 256; t8.bn = 256;
+    t8.tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (g_variant == 0) { t8.splits = 1; t8.ktiles_per_split = p.K / EA_BK; }
+    FastSel s8;
+    if (fast_select_plan(p, t8, workspace, ws_bytes, ws_off, s8) == EA_OK && s8.tr && !s8.lnx) { s = s8; return EA_OK; }
+    if (g_variant == 30) return EA_ERR_UNSUPPORTED;   // forced, but not eligible: say so
+  }
+  return fast_select_plan(p, t, workspace, ws_bytes, ws_off, s);
+}
+
+static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws_bytes, size_t ws_off, FastSel& s) {
+  if (p.acc_scale_kt > 0 && (t.splits != 1 || (t.kind != 1 && t.kind != 9 && t.kind != 30))) return EA_ERR_UNSUPPORTED;
   p.splits = t.splits;
   p.ktiles_per_split = t.ktiles_per_split;
   p.partial = nullptr;
@@ -449,6 +486,12 @@ static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t
         !e.residual32 && !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 &&
         (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 && p.debug != 9)
       p.epi_fast = 2;
+    // register-direct fp32 output (ea_gemm8.h only: ea_epi_tr.h F32OUT): fp32 out, optional fp32 residual
+    if (t.kind == 30 && t.splits == 1 && e.out_f32 && !e.residual && !e.row_scale && !e.bias_per_row && e.act != EA_ACT_GEGLU &&
+        (e.N & 3) == 0 && (e.ldc & 3) == 0 && (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 3) == 0 && span < 0x7fffffffLL &&
+        (!e.residual32 || ((e.ldr & 3) == 0 && (((uintptr_t)e.residual32) & 15) == 0 && (p.strideR & 3) == 0 && (long long)p.M * e.ldr < 0x7fffffffLL)) &&
+        (!e.rowvec || (p.batch == 1 && e.rows_per_group > 0 && (e.rows_per_group % t.bm) == 0)) && p.debug != 9)
+      p.epi_fast = 4;
     // register-direct GEGLU epilogue: 32-row packing on 128-wide tiles
     if (e.act == EA_ACT_GEGLU && e.geglu_block == 32) {
       if (!(t.bn == 128 && t.splits == 1 && (t.kind == 1 || t.kind == 9) && !e.out_f32 && !e.residual && !e.residual32 &&
@@ -487,10 +530,10 @@ static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t
   }
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
-  const bool tr_kind = t.kind == 1 || t.kind == 9 || (EA_TOOLS && t.kind == 24);
+  const bool tr_kind = t.kind == 1 || t.kind == 9 || t.kind == 30 || (EA_TOOLS && t.kind == 24);
   const bool tr_raw = t.splits > 1 && !g_no_tr && tr_kind && (p.N & 3) == 0 && p.debug != 9;
   const bool tr = tr_raw || p.epi_fast == 3 ||
-                  (p.epi_fast == 1 && !g_no_tr && tr_kind && (((uintptr_t)p.epi.bias) & 15) == 0 &&
+                  ((p.epi_fast == 1 || p.epi_fast == 4) && !g_no_tr && tr_kind && (((uintptr_t)p.epi.bias) & 15) == 0 &&
                    (!p.epi.rowvec || ((((uintptr_t)p.epi.rowvec) & 15) == 0 && (p.epi.rowvec_ld & 3) == 0)));
   // the LayerNorm fold exists in the register-direct epilogue only (callers ask ea_gemm_ln_fold_ok first)
   if (p.epi.ln_stats && (!tr || t.splits > 1)) return EA_ERR_UNSUPPORTED;
@@ -577,7 +620,12 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
       }
     } else
 #endif
-    if (t.kind == 1) {
+    if (t.kind == 30) {
+      if (s.lnx || q) return EA_ERR_UNSUPPORTED;
+      auto kfn = ea_gemm8_kernel<1>;
+      ea_allow_big_lds(kfn, EA_G8_LDS_BYTES);
+      EA_LAUNCH(kfn, grid, dim3(512, 1, 1), EA_G8_LDS_BYTES, stream, p);
+    } else if (t.kind == 1) {
       if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
       else { if (s.lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }
     } else {

@@ -17,6 +17,8 @@ UniPCMultistepScheduler.from_config(pipe.scheduler)` as in sam2image.py:42.
 Text encoding is outside the hot path: pass `prompt_embeds` / `negative_prompt_embeds`, or give
 the pipeline a `text_encoder` callable (list[str] -> [B, 77, ctx_dim]).
 """
+import copy
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -400,7 +402,9 @@ class StableDiffusionControlNetInpaintPipeline:
             # generation pipeline, utils/stable_diffusion_controlnet.py:579-600: the ControlNet sees the conditional half
             # only and ZEROS are added to the unconditional half -> per-row scale 0 for the first n_img samples
             per_net = [self._zero_uncond_rows(base, height, width, n_img) for base in per_net]
-        sch = self.scheduler
+        # a per-call copy: `loop` of the previous request may still be reading the scheduler's tables on another thread
+        # (serving.PipelinedRunner); set_timesteps only REBINDS attributes, so a shallow copy isolates the call
+        sch = copy.copy(self.scheduler)
         timesteps = sch.set_timesteps(num_inference_steps, eta=eta)
         lat = self.prepare_latents(n_img, 4, height, width, generator, latents)
         noise0 = lat.clone()

@@ -169,7 +169,9 @@ class ImageEncoderViT:
                 self.forward(xs)                      # warm-up outside capture (lazy allocations, workspace)
             cur.wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: this may run on the serving runner's worker thread while the main thread replays
+            # the denoising graph (a global-mode capture would be invalidated by the other thread's launches)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self.forward(xs)
             ent = self._graphs[key] = (g, xs, out, ops.workspace_refs())
         g, xs, out = ent[:3]

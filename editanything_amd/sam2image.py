@@ -56,6 +56,7 @@ class Demo:
         self.device = torch.device(device)
         self.last_embedding = None
         self._runners = {}
+        self.overlap = True           # process_many: two-stream software pipeline over consecutive requests (serving.py)
 
     def _pipe(self, path):
         if path not in self.pipes:
@@ -128,8 +129,9 @@ class Demo:
         """A queue of `process` requests (each a tuple / dict of its arguments) through the staged runner
         (serving.PipelinedRunner): every request is front (SAM encode + mask generation + control + VAE encode) -> loop -> back
         (VAE decode).  Returns `process`' return value per request, in order -- the same values `process` gives one request at
-        a time.  (The runner's two-stream form -- the next request's front and the previous one's back underneath the current
-        loop -- is an opt-in experiment, `PipelinedRunner(pipe, overlap=True)`: see serving.py for why it is off.)"""
+        a time, bit for bit.  The runner overlaps the next request's front and the previous one's back with the current loop
+        on a second stream (serving.PipelinedRunner, overlap=True: its default since round 5; `Demo.overlap = False` keeps the
+        stages of a request in order on one stream)."""
         from .serving import PipelinedRunner
         reqs = [r if isinstance(r, dict) else dict(zip(self.process.__code__.co_varnames[1:], r)) for r in requests]
         paths = {config_dict.get(r["condition_model"], r["condition_model"]) for r in reqs}
@@ -138,7 +140,7 @@ class Demo:
         pipe = self._pipe(paths.pop())
         runner = self._runners.get(id(pipe))
         if runner is None:
-            runner = self._runners[id(pipe)] = PipelinedRunner(pipe)
+            runner = self._runners[id(pipe)] = PipelinedRunner(pipe, overlap=self.overlap)
         meta = [None] * len(reqs)
 
         def front(i, r):

@@ -21,14 +21,20 @@ stage ever reads a buffer another in-flight request writes.  The side stream has
 Latency: a request leaves the runner one denoising loop after the sequential path would have finished it at the
 latest (its decode waits for nothing but its own loop); throughput is what moves -- bench.py reports both.
 
-**STATUS (end of round 4): `overlap` is OFF by default -- the runner then runs the three stages of every request in order on
-the caller's stream (same results as `pipe(**kw)`, no second stream, no thread).**  With `overlap=True` the throughput gain was
-measured (+1.7 ... +2.8 % at the benchmark's shape), and then a stress test found the captured loop's RESULT changing when work runs
-beside it on a second HIP stream (up to 0.1 on O(1) latents in 60-75 % of runs; plain calls are bit-deterministic).  The hunt
-(tools/diag_kernel_race.py, profiles/r04_pipelined_race.jsonl) found two kernel bugs that only a busy neighbour
-exposes -- a missing barrier in the d = 64 LDS-DMA attention kernel, and sum-of-squares updates lost behind a per-lane EXEC update
-in the GroupNorm statistics loop -- and fixed both: 0 of 30 stress runs differ now.  The default stays off until that has soaked
-longer (the fixes landed with the round's GPU budget spent).
+**STATUS (round 5): `overlap` is ON by default.**  Round 4 measured the gain (+1.7 ... +2.8 % at the benchmark's shape) and then
+found the captured loop's RESULT changing when work runs beside it on a second HIP stream.  Both causes were bugs of shipped
+kernels that only a busy neighbour exposes and both are fixed: a missing barrier in the d = 64 LDS-DMA attention kernel, and --
+root-caused in round 5 to the instruction level -- a packed-fp32 instruction with a cross-half source selection (v_pk_fma_f32 ...
+op_sel:[0,0,1]) that returns wrong lanes 48..63 while ANOTHER wave of the SIMD has MFMAs in flight (tools/probe_pk_swap.hip;
+the library is built without packed fp32 ops, csrc/build.py, tests/test_isa_hazards.py).  Soak after the fixes: 500 stress runs
+x 3 full-size requests, 0 differ from the plain call bit for bit (profiles/r05_pipeline_stress500.jsonl); every kernel family
+is tested bit-stable beside busy neighbour streams (tests/test_zz_neighbour_stream.py).  `overlap=False` runs the three stages
+of every request in order on the caller's stream (no second stream, no thread).
+
+Host-side rules of the overlapped form: `front` works on a per-call copy of the scheduler (pipeline.front), graphs captured on
+the worker thread use thread-local capture mode (sam.forward_graph), a first-of-its-shape denoising step is captured with the
+device idle (below), and a request that passes `generator=None` draws from torch's global generator in ISSUE order, which
+differs from the sequential order -- pass generators (the reference's `seed` argument does) for reproducible requests.
 """
 import concurrent.futures
 import time
@@ -67,7 +73,7 @@ def make_stream(device, priority, cu_count=0):
 
 
 class PipelinedRunner:
-    def __init__(self, pipe, overlap=False, side_stream=None, threaded=True, side_priority=1, side_cus=0):
+    def __init__(self, pipe, overlap=True, side_stream=None, threaded=True, side_priority=1, side_cus=0):
         """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
         the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
         packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:

@@ -1138,6 +1138,153 @@ def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# ea_gemm8.h: the 256 x 256 staggered 8-phase kernel (tuning variant 30; automatic for the large launches: SAM's Linears, the
+# fp32-accurate encoder's split-operand launches, the VAE's 512-channel convolutions -- ea_gemm.hip gemm8_shape_ok).
+@pytest.mark.parametrize("M,N,K,act,res,rowvec,splits", [
+    (512, 512, 256, 0, True, False, 0),      # 2 x 2 tiles, 4 K tiles (steady-state staging across tile boundaries), residual
+    (300, 320, 64, 1, False, False, 0),      # ONE K tile (prologue only), ragged M and N, SiLU
+    (256, 256, 128, 2, True, False, 0),      # one tile, two K tiles, GELU + residual (SAM's MLP epilogue)
+    (700, 520, 192, 0, False, False, 0),     # 3 x 3 tiles, odd K-tile count, ragged both ways
+    (512, 256, 192, 1, False, True, 0),      # per-sample row vector, 2 samples of 256 rows
+    (256, 320, 768, 0, True, False, 3),      # split-K: 3 slices, raw fp32 dump from the registers + reduce kernel
+])
+def test_large_tile_kernel_gemm(kb, M, N, K, act, res, rowvec, splits):
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    rv = f32(M // 256, N) if rowvec else None
+    got = _gemm_run(kb, A, W, bias, act, R, rv, 256 if rowvec else 1, 30, splits)
+    base = _gemm_run(kb, A, W, bias, act, R, rv, 256 if rowvec else 1, 1, splits)
+    ref = t(A) @ t(W).T + t(bias)
+    if rowvec:
+        ref = ref + t(rv).repeat_interleave(256, 0)
+    ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(got, ref.numpy()) < 2e-3
+    # same products, same K order and fp32 summation order as ea_gemm2's register-direct tiles: bit for bit
+    assert np.array_equal(got, base)
+
+
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,ksize,stride,ups,emb,res", [
+    (2, 16, 16, 64, 0, 256, 3, 1, 0, True, False),    # 3x3 + embedding row vector; taps change every K tile
+    (2, 16, 16, 64, 64, 320, 3, 1, 0, False, True),   # virtual concat (two sources) + skip residual, ragged N
+    (3, 16, 16, 128, 0, 256, 3, 2, 0, False, False),  # stride 2; M = 192 (one ragged tile)
+    (2, 8, 8, 64, 0, 256, 3, 1, 1, False, False),     # nearest 2x upsample inside the im2col
+    (2, 16, 16, 64, 64, 256, 1, 1, 0, False, False),  # 1x1 over a concat
+])
+def test_large_tile_kernel_conv(kb, B, H, W, c1, c2, cout, ksize, stride, ups, emb, res):
+    x1 = f16(B, H, W, c1)
+    x2 = f16(B, H, W, c2) if c2 else None
+    Ho = 2 * H if ups else (H // 2 if stride == 2 else H)
+    Wo = 2 * W if ups else (W // 2 if stride == 2 else W)
+    w, bias = f16(cout, c1 + c2, ksize, ksize, scale=0.1), f32(cout)
+    M = B * Ho * Wo
+    rv = f32(B, cout) if emb else None
+    R = f16(M, cout) if res else None
+    pad = 1 if ksize == 3 else 0
+    outs = []
+    for v in (30, 1):
+        tune(kb, variant=int(v), splits=1)
+        src = conv_src(x1, x2, None, ksize, stride, pad, ups, Ho, Wo)
+        out = kb.zeros((M, cout), np.float16)
+        e = epilogue(out, bias=bias, act=1, residual=R, rowvec=rv, rows_per_group=Ho * Wo)
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(pack_conv_w(w)), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, t(w), t(bias), stride=stride, padding=pad)
+    if emb:
+        ref = ref + t(rv)[:, :, None, None]
+    ref = F.silu(ref).permute(0, 2, 3, 1).reshape(M, cout)
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 3e-3
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K,res,act,exact", [
+    (300, 320, 128, True, 0, False),     # fp32 out + fp32 residual (SAM mlp.lin2 / proj on the fp32 residual stream), ragged
+    (256, 256, 192, False, 2, False),    # fp32 out, GELU, no residual
+    (512, 512, 384, True, 0, True),      # the fp32-accurate Linear: [hi | lo | hi] x [lo | hi | hi], accumulators x 2^-11 after 2K
+])
+def test_large_tile_kernel_fp32_output(kb, M, N, K, res, act, exact):
+    """ea_epi_tr.h F32OUT (ea_gemm8.h): fp32 output (+ fp32 residual) straight from the accumulator quads == the LDS-slab
+    epilogue of ea_gemm2's tiles bit for bit; with the K-position accumulator rescale of the split-operand launches."""
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f32(M, N) if res else None
+    outs = []
+    for v in (30, 1):
+        tune(kb, variant=v, splits=1)
+        out = kb.zeros((M, N), np.float32)
+        e = epilogue(out, bias=bias, act=act, scale=0.75, residual32=R)
+        if exact:
+            e.acc_scale_k, e.acc_scale = 2 * (K // 3), 1.0 / 2048.0
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    if exact:
+        k2 = 2 * (K // 3)
+        ref = (t(A[:, :k2]) @ t(W[:, :k2]).T) / 2048.0 + t(A[:, k2:]) @ t(W[:, k2:]).T + t(bias)
+    else:
+        ref = t(A) @ t(W).T + t(bias)
+    ref = (F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+
+
+def test_large_tile_kernel_refuses_what_it_cannot_run(kb):
+    """The planner sends a launch to ea_gemm8.h by shape (whole rounds of 256 x 256 tiles, K >= 1024) and only with the
+    plain register-direct epilogue; forcing variant 30 on a launch it cannot run reports EA_ERR_UNSUPPORTED."""
+    M, N, K = 64, 256, 128
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    out = kb.zeros((M, N), np.float32)
+    tune(kb, variant=30)
+    e = epilogue(out, bias=None, residual=f16(M, N))   # fp32 output with an fp16 residual: the slab epilogue's job
+    ws = workspace(kb, 0)
+    assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == -3
+
+
+@pytest.mark.parametrize("M,N,K,act,f32out", [
+    (16384, 5120, 1280, 2, False),   # SAM ViT-H mlp.lin1 + GELU, 4 images: 1280 tiles = 5 whole rounds -> ea_gemm8 by the plan
+    (19600, 3840, 1280, 0, False),   # windowed qkv (25 windows of 196 tokens per image): ragged last row tile
+    (16384, 5120, 3840, 0, True),    # the fp32-accurate lin1: split operands, fp32 out, accumulator rescale after 2K
+])
+def test_large_tile_kernel_full_size_sam_shapes(kb, M, N, K, act, f32out):
+    """At SAM's full-size shapes the AUTOMATIC plan (ea_gemm8.h) == forced 128-row ea_gemm2 tiles bit for bit, and both ==
+    torch on sampled rows."""
+    if kb.name != "gpu":
+        pytest.skip("full-size shapes run on the MI355X only")
+    A, W = f16(M, K), f16(N, K, scale=0.03)
+    bias = f32(N)
+    R = f32(M, N) if f32out else None
+    outs = []
+    for v in (0, 1):
+        tune(kb, variant=v)
+        out = kb.zeros((M, N), np.float32 if f32out else np.float16)
+        e = epilogue(out, bias=bias, act=act, residual32=R)
+        if f32out:
+            e.acc_scale_k, e.acc_scale = 2 * (K // 3), 1.0 / 2048.0
+        ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1))
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    rows = np.concatenate([np.arange(0, M, 997), np.arange(M - 40, M)])
+    if f32out:
+        k2 = 2 * (K // 3)
+        ref = (t(A[rows][:, :k2]) @ t(W[:, :k2]).T) / 2048.0 + t(A[rows][:, k2:]) @ t(W[:, k2:]).T + t(bias) + t(R[rows])
+    else:
+        ref = t(A[rows]) @ t(W).T + t(bias)
+        ref = F.gelu(ref) if act == 2 else ref
+    assert relerr(outs[0][rows], ref.numpy()) < 2e-3
+
+
 # ea_gemm3.h: the persistent 8-wave kernel (tuning variant 21 = m-split wave roles, 22 = k-split groups + accumulator
 # exchange, 23 = four multiplying + eight loader waves, 20 = the plan's own choice).  The emulated "device" has 4 CUs, so these shapes walk several rounds of the
 # persistent tile loop, with the DMA stream running across tile boundaries.

@@ -113,6 +113,8 @@ static std::vector<Case> all_cases() {
   // SAM ViT-H linears (4 images: 16384 tokens / 19600 window tokens) and VAE decoder convs (batch 4)
   g(16384, 3840, 1280, 0, 0); g(16384, 1280, 1280, 0, 1); g(16384, 5120, 1280, 2, 0); g(16384, 1280, 5120, 0, 1);
   cv(4, 256, 256, 0, 256, 3, 1, 0);   cv(4, 512, 128, 0, 128, 3, 1, 0);
+  g(19600, 3840, 1280, 0, 0); g(19600, 1280, 1280, 0, 0);   // windowed blocks: 25 windows of 196 tokens per image
+  cv(4, 128, 512, 0, 512, 3, 1, 0);   cv(4, 64, 512, 0, 512, 3, 1, 0);   // VAE decoder, 512-channel levels
   // calibration cubes (the guide's ladder is quoted at 4096^3 / 8192^3): compare with tools/gemm8_probe in the same call
   g(4096, 4096, 4096, 0, 0);  g(8192, 8192, 8192, 0, 0);
   // row-stride probes (round 3): the same launches with K moved off the power-of-two row strides (2560 / 10240 bytes), to see
