@@ -130,7 +130,7 @@ static int row_stat_parts(int N) { return (N % 160 == 0) ? N / 80 : (N + 63) / 6
 // K loop is long enough to amortise a 64-KiB-per-tile prologue and a 128-KiB epilogue (K >= 1024) AND the tile count
 // fills whole rounds of the 256 CUs (a 320-tile launch runs two rounds for 1.25 rounds of work and loses).
 static bool gemm8_shape_ok(const EaGemmParams& p) {
-  if (p.K < 1024 || p.M < 2048 || p.N < 512) return false;
+  if (p.K < 1024 || p.M < 2048 || p.N < 256) return false;
   const long long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
   const double tiles = (double)tm * tn * p.batch;
   const double rounds = tiles / 256.0;

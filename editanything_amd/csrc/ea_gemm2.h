@@ -105,6 +105,18 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
   const int wave = is_loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
   const int wm = wave / WN, wn = wave % WN;
 
+#if !(EA_EXP & 64) && !defined(EA_EMU)
+  // touch every 64-byte line of the kernel-argument block with ONE batch of scalar loads at entry, so that the compiler's five
+  // dependent batches of argument loads further down hit the scalar cache: -0.2 ... -0.4 us per launch on the K <= 1280 Linears
+  // (profiles/r05_kernarg_warm_ab.jsonl; EA_EXP & 64 switches it off for A/B builds)
+  {
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned w0, w1, w2, w3, w4;
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
+                 "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3), "=s"(w4) : "s"(ka) : "memory");
+  }
+#endif
   EA_STAMP(0);
   const int tiles_n = (p.N + BN - 1) / BN;
   const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
@@ -134,6 +146,9 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
 
   // ---- per-lane DMA coordinates: instruction j of this wave covers LDS rows (j*NW + wave)*8 .. +7
   const int lrow = lane >> 3, slot = lane & 7;
+  // conv set-up: pixel -> (sample, row, column) by float-reciprocal division where the row count allows (ea_prims.h ea_div_small)
+  const bool div_small = p.conv && p.M < EA_DIV_SMALL_MAX;
+  const float rcp_hw = 1.0f / (float)(p.conv ? p.Hout * p.Wout : 1), rcp_w = 1.0f / (float)(p.conv ? p.Wout : 1);
   int a_y[A_PW], a_x[A_PW];   // conv: input-space origin of the row's pixel
   int a_base[A_PW];           // conv: b*Hin*Win (pixel index of the sample), -1 = row out of range
   unsigned a_chunk[A_PW];     // element offset of the (swizzled) 16-B chunk this lane fetches
@@ -150,9 +165,9 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     if (ok) {
       if (p.conv) {
         const int hw = p.Hout * p.Wout;
-        const int b = m / hw;
+        const int b = div_small ? ea_div_small(m, hw, rcp_hw) : m / hw;
         const int rem = m - b * hw;
-        const int oy = rem / p.Wout;
+        const int oy = div_small ? ea_div_small(rem, p.Wout, rcp_w) : rem / p.Wout;
         a_base[j] = b * p.Hin * p.Win;
         a_y[j] = oy * p.stride - p.pad;
         a_x[j] = (rem - oy * p.Wout) * p.stride - p.pad;
@@ -651,6 +666,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     //  * ROW STATISTICS out (e.row_stats_out): per output row the (sum, sum of squares) over this wave's WTN columns,
     //    part = (column of the wave tile) / WTN -- what the next launch's LayerNorm fold consumes.
     if constexpr (TR != 0) {
+      EA_STAMP(2);
       ea_tr_epilogue<MI, NI, TR, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem, wave);
       EA_STAMP(4);
     }

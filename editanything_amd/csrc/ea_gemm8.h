@@ -74,6 +74,15 @@ __device__ __forceinline__ void ea_gemm8_tile(const EaGemmParams& p, const int w
   const int wave = ea_uniform(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
 
+#ifndef EA_EMU
+  {   // one batch of scalar loads over the kernel-argument block's cache lines (see ea_gemm2.h)
+    const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned w0, w1, w2, w3, w4;
+    asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
+                 "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3), "=s"(w4) : "s"(ka) : "memory");
+  }
+#endif
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tile = ea_xcd_remap(wg_x, tiles_m * tiles_n);
@@ -100,6 +109,9 @@ __device__ __forceinline__ void ea_gemm8_tile(const EaGemmParams& p, const int w
   // ---- per-lane DMA coordinates.  Piece (h, i) of this wave = 8-row group g = 2 * wave + i of half h; lane l fetches row
   // (l >> 3), 16-byte slot (l & 7) of the group (source chunk XOR-swizzled, the same involution as the fragment reads)
   const int lrow = lane >> 3, slot = lane & 7;
+  // conv set-up: pixel -> (sample, row, column) by float-reciprocal division where the row count allows (ea_prims.h ea_div_small)
+  const bool div_small = p.conv && p.M < EA_DIV_SMALL_MAX;
+  const float rcp_hw = 1.0f / (float)(p.conv ? p.Hout * p.Wout : 1), rcp_w = 1.0f / (float)(p.conv ? p.Wout : 1);
   int a_y[2][2], a_x[2][2], a_base[2][2], a_lds[2][2], b_lds[2][2];
   unsigned a_chunk[2][2], a_voff[2][2], b_voff[2][2];
 #pragma unroll
@@ -119,9 +131,9 @@ __device__ __forceinline__ void ea_gemm8_tile(const EaGemmParams& p, const int w
       if (m < p.M) {
         if (p.conv) {
           const int hw = p.Hout * p.Wout;
-          const int b = m / hw;
+          const int b = div_small ? ea_div_small(m, hw, rcp_hw) : m / hw;
           const int rem = m - b * hw;
-          const int oy = rem / p.Wout;
+          const int oy = div_small ? ea_div_small(rem, p.Wout, rcp_w) : rem / p.Wout;
           a_base[h][i] = b * p.Hin * p.Win;
           a_y[h][i] = oy * p.stride - p.pad;
           a_x[h][i] = (rem - oy * p.Wout) * p.stride - p.pad;

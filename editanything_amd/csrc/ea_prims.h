@@ -104,6 +104,19 @@ __device__ __forceinline__ void ea_swap16(float& a, float& b) {
 }
 #endif
 
+// n / d for 0 <= n < 2^22 and d >= 1 without the ~30-instruction integer division sequence: float estimate (v_rcp_f32 is within
+// 1 ulp, the product rounds once: |error| < 1 for n < 2^22) + two correction steps each way.  The im2col set-up of a
+// convolution launch does 2 such divisions per A piece and lane (pixel -> sample, row, column): 1.4-1.9 us of set-up per workgroup
+// against 0.8 us for a dense launch (profiles/r05_launch_phase_stamps.jsonl).  Exactness: tests/test_abi.py brute-forces the
+// same expression in float32 over every n < 2^22 for the workload's divisors.
+__device__ __forceinline__ int ea_div_small(int n, int d, float rcp) {
+  int q = (int)((float)n * rcp);
+  const int r = n - q * d;
+  q += (int)(r >= d) + (int)(r >= 2 * d) - (int)(r < 0) - (int)(r < -d);
+  return q;
+}
+#define EA_DIV_SMALL_MAX (1 << 22)
+
 // 16-B chunk swizzle of a 128-B LDS row (8 chunks): conflict-free ds_read_b128 for 16 consecutive rows.
 __device__ __forceinline__ int ea_swz(int row) { return (row >> 1) & 7; }
 

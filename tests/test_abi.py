@@ -47,3 +47,21 @@ def test_product_package_does_not_import_the_oracle():
                 if f == "smoke.py":           # __graft_entry__.smoke(): the one allowed checker inside the package
                     continue
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_float_reciprocal_division_of_the_conv_setup_is_exact():
+    """ea_prims.h ea_div_small (the im2col set-up's pixel -> (sample, row, column) divisions): float estimate + two correction steps
+    each way == integer division for every n < 2^22 and the divisors this workload has (H*W and W of every level, SAM's windows,
+    a few awkward ones) -- evaluated in float32 exactly as the kernel does; also with the reciprocal one ulp off either way (the
+    GPU's v_rcp_f32 is accurate to 1 ulp)."""
+    import numpy as np
+    n = np.arange(1 << 22, dtype=np.int32)
+    nf = n.astype(np.float32)
+    for d in (1, 2, 3, 5, 7, 8, 12, 14, 16, 24, 25, 32, 48, 64, 96, 100, 128, 196, 256, 512, 576, 1024, 2304, 4096, 9216, 16384, 65536,
+              262144, 1048576, 1000003):
+        r0 = np.float32(1.0) / np.float32(d)
+        for rcp in (r0, np.nextafter(r0, np.float32(0)), np.nextafter(r0, np.float32(2))):
+            q = (nf * rcp).astype(np.int32)
+            r = n - q * d
+            q = q + (r >= d).astype(np.int32) + (r >= 2 * d).astype(np.int32) - (r < 0).astype(np.int32) - (r < -d).astype(np.int32)
+            assert np.array_equal(q, n // d), d

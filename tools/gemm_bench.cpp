@@ -304,6 +304,47 @@ int main(int argc, char** argv) {
         }
       }
     }
+    // --debug 3 (tools builds): the kernel's phase timestamps (ea_gemm2.h EA_STAMP: 100 MHz wall clock per workgroup at
+    // 0 entry, 1 setup done, 2 K loop done, 3 past the pre-epilogue barrier, 4 end) from ONE launch, after the timed rounds
+    for (auto& cf : cfgs) {
+      if (!cf.exec || cf.debug != "3") continue;
+      apply_tuning(libs, cf.variant, cf.debug, cf.splits);
+      HIP_CHECK(hipMemsetAsync(ws, 0, 8 << 20, stream));
+      launch(libs[cf.lib], o_test);
+      HIP_CHECK(hipStreamSynchronize(stream));
+      std::vector<unsigned long long> st((8 << 20) / 8);
+      HIP_CHECK(hipMemcpy(st.data(), ws, 8 << 20, hipMemcpyDeviceToHost));
+      apply_tuning(libs, "auto", "0", "0");
+      unsigned long long t0 = ~0ull, t_end = 0;
+      int nb = 0;
+      double d[4] = {0, 0, 0, 0}, dmax[4] = {0, 0, 0, 0};
+      for (size_t b = 0; b + 8 <= st.size(); b += 8) {
+        if (!st[b] || !st[b + 4]) continue;
+        ++nb;
+        if (st[b] < t0) t0 = st[b];
+        if (st[b + 4] > t_end) t_end = st[b + 4];
+      }
+      double spread = 0;
+      for (size_t b = 0; b + 8 <= st.size(); b += 8) {
+        if (!st[b] || !st[b + 4]) continue;
+        if ((st[b] - t0) / 100.0 > spread) spread = (st[b] - t0) / 100.0;
+        const unsigned long long t[5] = {st[b], st[b + 1], st[b + 2], st[b + 3] ? st[b + 3] : st[b + 2], st[b + 4]};
+        for (int i = 0; i < 4; ++i) {
+          const double x = (double)(t[i + 1] - t[i]) / 100.0;
+          d[i] += x;
+          if (x > dmax[i]) dmax[i] = x;
+        }
+      }
+      char line[768];
+      snprintf(line, sizeof line,
+               "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"stamps\": 1, \"workgroups\": %d, \"start_spread_us\": %.2f, \"kernel_span_us\": %.2f, "
+               "\"mean_us\": {\"setup\": %.2f, \"k_loop\": %.2f, \"barrier\": %.2f, \"epilogue\": %.2f}, \"max_us\": {\"setup\": %.2f, \"k_loop\": %.2f, \"barrier\": %.2f, \"epilogue\": %.2f}}",
+               c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), nb, spread, nb ? (double)(t_end - t0) / 100.0 : 0.0,
+               nb ? d[0] / nb : 0, nb ? d[1] / nb : 0, nb ? d[2] / nb : 0, nb ? d[3] / nb : 0, dmax[0], dmax[1], dmax[2], dmax[3]);
+      puts(line);
+      fflush(stdout);
+      if (out) { fputs(line, out); fputc('\n', out); fflush(out); }
+    }
     for (auto& cf : cfgs) {
       char line[768];
       if (!cf.exec) {
