@@ -704,7 +704,7 @@ def roofline_leg(one_step, pipe, args):
             "classes": table}
 
 
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json")
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json")
 
 
 def pmc_cases():
