@@ -147,22 +147,32 @@ __device__ __forceinline__ float ea_expf(float x) {
 #endif
 }
 __device__ __forceinline__ float ea_silu(float x) { return x / (1.0f + ea_expf(-x)); }
-// Exact (erf) GELU of the reference (F.gelu, ldm/modules/attention.py:54-56).  erf by Abramowitz-Stegun 7.1.26
-// (|abs error| <= 1.5e-7, i.e. fp32 round-off class): 1 rcp + 1 exp + 8 FMA-class ops instead of libm erff's ~35
-// instructions -- the GEGLU epilogue evaluates 10^7-10^8 of these per launch and was VALU-bound on erff.
-__device__ __forceinline__ float ea_erf(float x) {
-  const float ax = fabsf(x);
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
-  float poly = 1.061405429f;
-  poly = poly * t - 1.453152027f;
-  poly = poly * t + 1.421413741f;
-  poly = poly * t - 0.284496736f;
-  poly = poly * t + 0.254829592f;
-  const float r = 1.0f - poly * t * ea_expf(-ax * ax);
-  return copysignf(r, x);
+// Exact (erf) GELU of the reference (F.gelu, ldm/modules/attention.py:54-56; SAM's MLPBlock):
+//   gelu(x) = x Phi(x) = max(x, 0) - |x| * (1 - Phi(|x|)),   1 - Phi(a) = erfc(a / sqrt 2) / 2 = 2^-(1 + a Q(a)),
+// Q a degree-6 polynomial fitted on a in [0, 4 sqrt 2] (beyond it 1 - Phi < 8e-9: the argument is clamped).  ONE transcendental
+// (v_exp_f32) + 11 full-rate VALU ops, no reciprocal, no sign handling: |abs error| <= 5.1e-7 over [-12, 12], i.e. the fp32
+// round-off class of the values themselves (the Abramowitz-Stegun 7.1.26 form used until round 4 -- 1 rcp + 1 exp + 13 ops --
+// measured 6.8e-7 on the same grid; libm erff costs ~35 instructions).  The GEGLU epilogues evaluate 10^7-10^8 of these per
+// launch and are VALU-bound on them: 21 us of an 89-us [32768 x 2560 x 320] launch, 8.7 us per tile round of SAM's mlp.lin1
+// on the 256 x 256 kernel (profiles/r05_launch_phase_stamps.jsonl).  Fit + error check: tests/test_abi.py.
+__device__ __forceinline__ float ea_exp2_raw(float x) {
+#ifdef EA_EMU
+  return exp2f(x);
+#else
+  return __builtin_amdgcn_exp2f(x);   // bare v_exp_f32: the argument here is <= -1, never a denormal input
+#endif
 }
 __device__ __forceinline__ float ea_gelu_erf(float x) {
-  return 0.5f * x * (1.0f + ea_erf(x * 0.70710678118654752440f));
+  const float a = fminf(fabsf(x), 5.65685424949238f);
+  float q = -4.276626896171365e-06f;
+  q = q * a + 1.2775987670465838e-05f;
+  q = q * a + 0.0005758762708865106f;
+  q = q * a - 0.007670961786061525f;
+  q = q * a + 0.05294874310493469f;
+  q = q * a + 0.45904383063316345f;
+  q = q * a + 1.1511269807815552f;
+  const float e = ea_exp2_raw(-a * q - 1.0f);       // 1 - Phi(a)
+  return fmaxf(x, 0.0f) - a * e;                     // (a, not |x|: +inf stays +inf; beyond the clamp the term is < 5e-8)
 }
 __device__ __forceinline__ f16x8 ea_ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void ea_st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }

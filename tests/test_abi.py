@@ -65,3 +65,29 @@ def test_float_reciprocal_division_of_the_conv_setup_is_exact():
             r = n - q * d
             q = q + (r >= d).astype(np.int32) + (r >= 2 * d).astype(np.int32) - (r < 0).astype(np.int32) - (r < -d).astype(np.int32)
             assert np.array_equal(q, n // d), d
+
+
+def test_one_exponential_gelu_matches_the_erf_gelu_to_fp32_roundoff():
+    """ea_platform.h ea_gelu_erf: max(x, 0) - a 2^-(1 + a Q(a)), a = min(|x|, 4 sqrt 2) -- the same float32 operation sequence,
+    against the reference's exact GELU in float64 over [-12, 12] (2e6 points) and at the extremes."""
+    import numpy as np
+    from scipy.special import erf
+    coef = [np.float32(c) for c in (1.1511269807815552, 0.45904383063316345, 0.05294874310493469, -0.007670961786061525,
+                                    0.0005758762708865106, 1.2775987670465838e-05, -4.276626896171365e-06)]
+
+    def gelu(x):
+        x = x.astype(np.float32)
+        a = np.minimum(np.abs(x), np.float32(5.65685424949238))
+        q = np.full_like(a, coef[-1])
+        for c in coef[-2::-1]:
+            q = q * a + c
+        e = np.exp2(-a * q - np.float32(1.0)).astype(np.float32)
+        return np.maximum(x, np.float32(0)) - a * e
+    xs = np.linspace(-12.0, 12.0, 2000001)
+    ref = 0.5 * xs * (1.0 + erf(xs / np.sqrt(2.0)))
+    got = gelu(xs).astype(np.float64)
+    assert np.abs(got - ref).max() < 6e-7
+    big = np.abs(ref) > 1e-3
+    assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() < 2e-4
+    ext = gelu(np.array([np.inf, -np.inf, 1e30, -1e30, 0.0, -0.0]))
+    assert ext[0] == np.inf and ext[2] == np.float32(1e30) and abs(ext[1]) < 1e-7 and abs(ext[3]) < 1e-7 and ext[4] == 0 and ext[5] == 0
