@@ -402,6 +402,36 @@ def attn_ref(q, k, v, scale, bias=None):
     return torch.einsum("bhij,bjhd->bihd", p, t(v))
 
 
+@pytest.mark.parametrize("hw,lres,S", [((64, 64), 32, 128), ((50, 72), 32, 128)])
+def test_sam_mask_postprocess_on_blob_masks(kb, hw, lres, S):
+    """Smooth blob-like logits (what a real mask looks like; one mask entirely on): masks, stability counts and boxes equal the
+    torch evaluation exactly away from threshold round-off.  (Round 5 tried deciding whole 8-pixel runs from the range of the
+    low-resolution logits under them: 3.3x slower on the benchmark's noise-like masks -- DESIGN 8g-5 -- reverted; the test stays.)"""
+    H, W = hw
+    n = 4
+    scale = S / max(H, W)
+    in_h, in_w = int(H * scale + 0.5), int(W * scale + 0.5)
+    yy, xx = np.meshgrid(np.arange(lres), np.arange(lres), indexing="ij")
+    low = np.stack([8.0 - 0.08 * ((yy - cy) ** 2 + (xx - cx) ** 2) for cy, cx in ((10, 12), (20, 8), (16, 16), (5, 28))]).astype(np.float32)
+    low[3] = 6.0                                               # everything on: every run is skipped
+    thr, off = 0.0, 1.0
+    mask = kb.zeros((n, H, W), np.uint8)
+    stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (n, 1)))
+    assert kb.lib.ea_sam_mask_postprocess(ptr(low), n, lres, lres, S, in_h, in_w, H, W, thr, off, ptr(mask), ptr(stats), kb.stream) == 0
+    up = F.interpolate(t(low)[None], (S, S), mode="bilinear", align_corners=False)[0][..., :in_h, :in_w]
+    ref = F.interpolate(up[None], (H, W), mode="bilinear", align_corners=False)[0]
+    got_m, got_s = kb.down(mask), kb.down(stats)
+    assert set(np.unique(got_m).tolist()) <= {0, 1}
+    margin = ((ref - thr).abs() > 1e-4).numpy()
+    assert (got_m.astype(bool) == (ref > thr).numpy())[margin].all()
+    inter, union = (ref > thr + off).sum((1, 2)).numpy(), (ref > thr - off).sum((1, 2)).numpy()
+    assert np.abs(got_s[:, 0] - inter).max() <= 2 and np.abs(got_s[:, 1] - union).max() <= 2
+    for i in range(n):
+        ys, xs = np.nonzero(got_m[i])
+        assert got_s[i, 2:].tolist() == [xs.min(), ys.min(), xs.max(), ys.max()]
+    assert got_m[3].all() and got_s[3, 0] == H * W and got_s[3, 1] == H * W
+
+
 @pytest.mark.parametrize("hw,lres,S", [((48, 64), 16, 64), ((37, 29), 16, 64), ((64, 64), 8, 32)])
 def test_sam_mask_postprocess(kb, hw, lres, S):
     """One-pass mask post-processing == F.interpolate(F.interpolate(low, S)[:in_h,:in_w], (H,W)) > thr, stability counts,
