@@ -726,6 +726,10 @@ def pmc_lookup(cases, label):
     if cases is None:
         return None
     c = cases[0].get(label)
+    if c is None and label.endswith(" x2"):      # twin launch (two problems of one shape in one grid): twice the single launch's bytes
+        one = pmc_lookup(cases, label[:-3])
+        if one is not None:
+            c = {k: 2 * v for k, v in one.items() if k in ("hbm_bytes", "hbm_bytes_with_reduce")}
     if c is None:      # ResBlock forms ("... emb" / "... res") of the same convolution: the plain launch's record
         c = next((v for k, v in cases[0].items() if k.startswith(label + " ")), None)
     return c

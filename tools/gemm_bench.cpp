@@ -120,6 +120,7 @@ static std::vector<Case> all_cases() {
   cv(8, 32, 640, 0, 640, 3, 2, 0);    cv(8, 16, 1280, 0, 1280, 3, 2, 0);  cv(8, 16, 1280, 1280, 1280, 1, 1, 0);
   cv(8, 8, 1280, 0, 1280, 3, 1, 1);   cv(8, 8, 1280, 1280, 1280, 1, 1, 0);
   cv(4, 256, 256, 0, 256, 3, 1, 1);   cv(4, 128, 512, 0, 512, 3, 1, 1);
+  cv(8, 32, 640, 0, 640, 1, 1, 0);    cv(8, 16, 1280, 0, 1280, 1, 1, 0);   // zero-convs of the 32 x 32 / 16 x 16 levels
   // calibration cubes (the guide's ladder is quoted at 4096^3 / 8192^3): compare with tools/gemm8_probe in the same call
   g(4096, 4096, 4096, 0, 0);  g(8192, 8192, 8192, 0, 0);
   // row-stride probes (round 3): the same launches with K moved off the power-of-two row strides (2560 / 10240 bytes), to see

@@ -5,7 +5,7 @@ import csv, glob, json, os, sys
 
 D, out_path = sys.argv[1], sys.argv[2]
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes, tools/gemm_bench 3 launches "
-               "per case; per-dispatch mean over the ea_gemm2_kernel / ea_gemm3_kernel dispatches of the case (split-K reduce "
+               "per case; per-dispatch mean over the ea_gemm2_kernel / ea_gemm8_kernel / ea_gemm_kernel dispatches of the case (split-K reduce "
                "launches listed apart). hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.", "cases": {}}
 for line in open(os.path.join(D, "cases.txt")):
     i, var, name = line.strip().split("|", 2)
@@ -15,7 +15,7 @@ for line in open(os.path.join(D, "cases.txt")):
         for f in glob.glob(os.path.join(D, f"c{i}_{p}", "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "ea_gemm2_kernel" in k or "ea_gemm3_kernel" in k:
+                if "ea_gemm2_kernel" in k or "ea_gemm3_kernel" in k or "ea_gemm8_kernel" in k or "ea_gemm_kernel" in k:
                     acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                 elif "splitk_reduce" in k:
                     red.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
