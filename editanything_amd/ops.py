@@ -6,6 +6,7 @@ libeditanything_hip.so on `torch.cuda.current_stream()`.  Activations are NHWC f
 There is no eager/CPU fallback: tensors must live on the MI355X.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -264,10 +265,13 @@ class _Config:
     gn_next = True
 
 
-CONFIG = _Config()
+CONFIG = _Config()          # the process default: what `current()` returns outside every `using(...)` block
+_ACTIVE = threading.local()
 
 
 def configure(**kw):
+    """Set switches of the PROCESS DEFAULT (tools / tests).  An object that wants its own -- two pipelines in one process with
+    different fusion settings -- passes `fusion=dict(...)` to `unet.ControlledDenoiser`, whose calls run under `using(...)`."""
     for k, v in kw.items():
         if not hasattr(_Config, k):
             raise TypeError(f"unknown ops option {k!r}")
@@ -275,9 +279,42 @@ def configure(**kw):
     return CONFIG
 
 
+def make_config(**kw):
+    """A private copy of the process default with `kw` applied (unknown keys raise)."""
+    c = _Config()
+    for k in ("ln_fold", "gn_epilogue", "gn_next"):
+        setattr(c, k, getattr(CONFIG, k))
+    for k, v in kw.items():
+        if not hasattr(_Config, k):
+            raise TypeError(f"unknown ops option {k!r}")
+        setattr(c, k, bool(v))
+    return c
+
+
+def current():
+    """The fusion switches in force for the calling thread: the innermost `using(cfg)` block's, else the process default."""
+    return getattr(_ACTIVE, "cfg", None) or CONFIG
+
+
+class using:
+    """with ops.using(cfg): ... -- `cfg`'s switches for every ops call of this thread inside the block (None: no change)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def __enter__(self):
+        self.prev = getattr(_ACTIVE, "cfg", None)
+        if self.cfg is not None:
+            _ACTIVE.cfg = self.cfg
+        return self.cfg
+
+    def __exit__(self, *exc):
+        _ACTIVE.cfg = self.prev
+
+
 def ln_fold_ok(M, N, K):
     """Can a LayerNorm-folded GEMM of this shape run (register-direct epilogue, no split-K)?"""
-    return CONFIG.ln_fold and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
+    return current().ln_fold and bool(_lib().ea_gemm_ln_fold_ok(int(M), int(N), int(K)))
 
 
 def row_stats_buffer(M, N, like):
@@ -400,7 +437,7 @@ class Normed:
 def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
     """True when a contraction of this shape is split along K and its reduction can apply the GroupNorm that consumes the
     output (`ea_epilogue.gn_next_out`)."""
-    if not CONFIG.gn_epilogue or not CONFIG.gn_next or PROFILE is not None or N % groups:
+    if not current().gn_epilogue or not current().gn_next or PROFILE is not None or N % groups:
         return False
     return bool(_lib().ea_gemm_gn_next_ok(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 
@@ -408,7 +445,7 @@ def gn_next_plan(M, N, K, conv, rows_per_sample, groups):
 def gn_stats_plan(M, N, K, conv, rows_per_sample, groups):
     """Rows per GroupNorm-statistics chunk when a contraction of this shape can leave the partials of its OUTPUT behind
     for the GroupNorm that reads it (`ea_epilogue.gn_stats_out`), else 0."""
-    if not CONFIG.gn_epilogue or PROFILE is not None or N % groups:
+    if not current().gn_epilogue or PROFILE is not None or N % groups:
         return 0
     return int(_lib().ea_gemm_gn_stats_chunk_rows(int(M), int(N), int(K), int(conv), int(rows_per_sample), N // groups))
 

@@ -489,13 +489,16 @@ class ControlledDenoiser:
     (text K/V of every attention layer, ControlNet hint features) are prepared once, then `eps(x, t)` is the
     per-step hot function: UNet encoder -> ControlNet (accumulating into the skips) -> UNet decoder."""
 
-    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True, twin=False, pair_zero_convs=True):
+    def __init__(self, unet, controlnets=(), overlap=True, share_cfg_prefix=True, twin=False, pair_zero_convs=True, fusion=None):
         """overlap: the ControlNet trunk runs beside the UNet encoder on a second stream (False: one stream, in order).
         share_cfg_prefix: `eps(cfg_halves=True)` computes the part the two CFG halves share once.
         twin: the (first) ControlNet's trunk and the UNet encoder run in LOCK STEP on one stream, every contraction of the
         pair as one twin launch (ops.Pair / ea_*_pair: one grid, two problems) -- the deterministic form of what `overlap`
         gets from two streams packing into each other.  Needs a ControlNet whose trunk is layer for layer the UNet's
-        encoder (every SD ControlNet; not the 9-channel inpainting UNet), else the pair falls back to `overlap`."""
+        encoder (every SD ControlNet; not the 9-channel inpainting UNet), else the pair falls back to `overlap`.
+        fusion: this denoiser's OWN fusion switches (`dict(ln_fold=..., gn_epilogue=..., gn_next=...)`, ops._Config) -- its
+        evaluations run under `ops.using(...)`, so two pipelines of one process can differ; None = the process default."""
+        self.fusion = None if fusion is None else ops.make_config(**fusion)
         self.unet = unet
         self.controlnets = list(controlnets) if isinstance(controlnets, (list, tuple)) else [controlnets]
         self.control_scales = None
@@ -570,6 +573,10 @@ class ControlledDenoiser:
             and u.ref is None and u.shares_cfg_prefix() and all(cn.shares_cfg_prefix() for cn in self.controlnets)
 
     def eps(self, x, timesteps, embs=None, cfg_halves=False, cfg_single=False):
+        with ops.using(self.fusion):
+            return self._eps(x, timesteps, embs, cfg_halves, cfg_single)
+
+    def _eps(self, x, timesteps, embs=None, cfg_halves=False, cfg_single=False):
         """x NCHW fp32 [B,C,h,w], timesteps int64 [B] -> eps NCHW fp32.  `embs`: optional precomputed
         `time_embeddings` rows, each [B, sum(Cout)] or [1, sum(Cout)] (one timestep shared by the whole batch).
 

@@ -145,6 +145,36 @@ def test_twin_trunk_equals_the_two_network_evaluation(tiny, gn_next):
         ops.configure(gn_next=True)
 
 
+def test_two_denoisers_in_one_process_keep_their_own_fusion_switches(tiny):
+    """ControlledDenoiser(fusion=...): one denoiser with the consuming GroupNorm inside the split-K reduction switched off, one with
+    the process default, evaluated alternately -- each reproduces its own configuration's result bit for bit (ops.using is per
+    object, not process-global state), and both meet the golden."""
+    from editanything_amd import ops
+    from editanything_amd.unet import ControlledDenoiser
+    cn, un, _ = tiny
+    d = g("ldm_tiny_eval.npz")
+    args = (t(d["ctx"]).to(DEV), [t(d["hint"]).to(DEV)], [float(s) for s in d["scales"]])
+    x, ts = t(d["x"]).to(DEV), t(d["t"]).to(DEV)
+    ref = {}
+    for gn_next in (False, True):
+        ops.configure(gn_next=gn_next)
+        try:
+            den = ControlledDenoiser(un, [cn], overlap=False)
+            with torch.no_grad():
+                den.prepare(*args)
+                ref[gn_next] = den.eps(x, ts).clone()
+        finally:
+            ops.configure(gn_next=True)
+    a, b = ControlledDenoiser(un, [cn], overlap=False, fusion=dict(gn_next=False)), ControlledDenoiser(un, [cn], overlap=False)
+    with torch.no_grad():
+        for den in (a, b):
+            den.prepare(*args)
+        for _ in range(2):
+            assert torch.equal(a.eps(x, ts), ref[False]) and torch.equal(b.eps(x, ts), ref[True])
+    assert ops.current() is ops.CONFIG and ops.CONFIG.gn_next is True
+    check(ref[True], d["eps_ctrl"])
+
+
 def test_vae_vs_reference_golden(tiny):
     _, _, vae = tiny
     d = g("ldm_tiny_vae.npz")

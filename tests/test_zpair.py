@@ -67,3 +67,28 @@ def test_twin_module_proxy_pairs_tensors_and_passes_equal_scalars():
     assert isinstance(t.emb_off, ops.Pair) and (t.emb_off.a, t.emb_off.b) == (0, 640)
     assert isinstance(t.ln, list) and isinstance(t.ln[0], tuple) and isinstance(t.ln[0][0], ops.Pair) and t.ln[0][1].b is mb.ln[0][1]
     assert _twin_value(3, 3) == 3
+
+
+def test_fusion_switches_are_per_thread_and_per_object():
+    """ops.current(): the process default outside every block, an object's own copy inside `ops.using(cfg)` (what
+    ControlledDenoiser(fusion=...) wraps its evaluations in), nested blocks restore, other threads are unaffected, unknown
+    switches raise."""
+    import threading
+    import pytest
+    assert ops.current() is ops.CONFIG and ops.CONFIG.gn_next is True
+    mine = ops.make_config(gn_next=False)
+    assert mine.gn_next is False and mine.ln_fold == ops.CONFIG.ln_fold and ops.CONFIG.gn_next is True
+    seen = {}
+    with ops.using(mine):
+        assert ops.current() is mine
+        with ops.using(None):                       # an object without its own switches: whatever is in force stays
+            assert ops.current() is mine
+        with ops.using(ops.make_config(ln_fold=False)) as inner:
+            assert ops.current() is inner and inner.ln_fold is False
+        assert ops.current() is mine
+        th = threading.Thread(target=lambda: seen.setdefault("other", ops.current()))
+        th.start()
+        th.join()
+    assert seen["other"] is ops.CONFIG and ops.current() is ops.CONFIG
+    with pytest.raises(TypeError):
+        ops.make_config(no_such_switch=True)
