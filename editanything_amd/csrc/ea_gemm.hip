@@ -279,8 +279,7 @@ static int launch_row_stats(EaGemmParams& p, void* stream) {
   return ea_launch_status();
 }
 
-#if EA_TOOLS
-// ---- ea_gemm3.h: the persistent 8-wave kernel.  Number of workgroups = CUs of the device (one resident per CU).
+// Number of CUs of the device (persistent launches: one resident workgroup per CU).
 static int cu_count() {
 #ifdef EA_EMU
   return 4;   // host emulation: a tiny "device", so the tests walk several rounds of the persistent tile loop
@@ -295,6 +294,8 @@ static int cu_count() {
 #endif
 }
 
+#if EA_TOOLS
+// ---- ea_gemm3.h: the persistent 8-wave kernel of round 3 (tools builds only).
 struct Plan3 {
   int use;        // 0: stay on ea_gemm2
   int bn, splits, ktiles_per_split, ks, gm, trx, gn_rows;
@@ -443,7 +444,7 @@ static int fast_select(EaGemmParams& p, void* workspace, size_t ws_bytes, size_t
   // only (plain / raw split-K forms, no fold, no statistics), so a launch that needs anything else keeps the plan above
   const EaEpilogue& e0 = p.epi;
   if ((g_variant == 30 || (g_variant == 0 && g_force_splits == 0 && !g_no_tr && gemm8_shape_ok(p))) && e0.act != EA_ACT_GEGLU &&
-      !e0.ln_stats && !e0.row_stats_out && !e0.gn_stats_out && !e0.gn_next_out && !(EA_TOOLS && g_tune.debug)) {
+      !e0.ln_stats && !e0.row_stats_out && !e0.gn_stats_out && !e0.gn_next_out && !(EA_TOOLS && g_tune.debug && g_tune.debug != 21 && g_tune.debug != 22)) {
     Plan2 t8 = t;
     t8.kind = 30; t8.bm = 256; t8.bn = 256;
     t8.tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -624,7 +625,15 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
       if (s.lnx || q) return EA_ERR_UNSUPPORTED;
       auto kfn = ea_gemm8_kernel<1>;
       ea_allow_big_lds(kfn, EA_G8_LDS_BYTES);
-      EA_LAUNCH(kfn, grid, dim3(512, 1, 1), EA_G8_LDS_BYTES, stream, p);
+      // persistent over the tiles (ea_gemm8.h: one workgroup per CU and K slice walks its tiles) from 8 rounds of tiles up.
+      // Measured against one workgroup per tile (profiles/r05_gemm8_persistent_ab.jsonl): -12 ... -13 % at 8 / 16 rounds (the VAE's
+      // up-sampling convolutions), -8 % at 8192^3, but +-0 ... +4 % WORSE at 2 - 5 rounds (SAM's Linears, the other VAE
+      // convolutions): the static walk gives up the dispatcher's load balancing, which matters while a round is a large
+      // share of the launch.  debug 21 / 22 (tools): never / always persistent (A/B)
+      const bool persist = (EA_TOOLS && g_tune.debug == 21) ? false : (EA_TOOLS && g_tune.debug == 22) ? true : t.tiles >= 8 * cu_count();
+      const int width = persist ? cu_count() : t.tiles;
+      dim3 grid8(t.tiles < width ? t.tiles : width, 1, p.batch * t.splits);
+      EA_LAUNCH(kfn, grid8, dim3(512, 1, 1), EA_G8_LDS_BYTES, stream, p);
     } else if (t.kind == 1) {
       if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR(128, 160, 2); else EA_LAUNCH_TR(128, 160, 1); }
       else { if (s.lnx) EA_LAUNCH_TR(128, 128, 2); else EA_LAUNCH_TR(128, 128, 1); }

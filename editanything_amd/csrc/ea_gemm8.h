@@ -300,7 +300,15 @@ __device__ __forceinline__ void ea_gemm8_tile(const EaGemmParams& p, const int w
   ea_tr_epilogue<8, 4, TRX, true, true>(p, acc, m0 + wm * 128, n0 + wn * 64, m0, batch, bz, ln_mu, ln_rs, smem, wave);
 }
 
+// The grid may be NARROWER than the tile count: workgroup w then walks tiles w, w + gridDim.x, ... (a persistent launch; the host
+// picks it from 8 rounds of tiles up, ea_gemm.hip).  A 256 x 256 workgroup owns a whole CU (128 KiB of LDS, 2 x 250 registers per
+// SIMD lane), so with one workgroup per tile the next one is dispatched only after the slowest wave of the previous has retired;
+// walking the tiles inside the launch removes that at the price of the dispatcher's load balancing.  tile -> (row, column) uses
+// the same XCD-aware map either way (workgroup w and tile w + k * 256 sit on the same XCD).  Between two tiles nothing needs a
+// barrier of its own: both wave rows leave a tile through the same final barrier (after which no wave reads the stage ring again)
+// and the register-direct epilogue does not touch LDS.
 template <int TRX>
 __global__ __launch_bounds__(512, 2) void ea_gemm8_kernel(EaGemmParams p) {
-  ea_gemm8_tile<TRX>(p, blockIdx.x, blockIdx.z);
+  const int ntile = ((p.M + EA_G8_BM - 1) / EA_G8_BM) * ((p.N + EA_G8_BN - 1) / EA_G8_BN);
+  for (int t = blockIdx.x; t < ntile; t += gridDim.x) ea_gemm8_tile<TRX>(p, t, blockIdx.z);
 }

@@ -1236,6 +1236,26 @@ def test_large_tile_kernel_conv(kb, B, H, W, c1, c2, cout, ksize, stride, ups, e
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_large_tile_kernel_persistent_walk_equals_one_workgroup_per_tile(kb):
+    """ea_gemm8_kernel with a grid narrower than the tile count (the host's choice from 8 rounds of tiles up; forced here through
+    the tools selector 22, 21 = never): every workgroup walks several tiles -- stage ring reused across tiles, the staggered wave
+    rows re-aligned at every tile start -- and the result is the per-tile launch's bit for bit."""
+    M, N, K = 1500, 776, 192         # 6 x 4 = 24 tiles on the emulated 4-CU device: six tiles per workgroup, ragged edges
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias, R = f32(N), f16(M, N)
+    outs = []
+    for dbg in (22, 21):
+        tune(kb, variant=30, splits=1, debug=dbg)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias, act=2, scale=0.75, residual=R)
+        ws = workspace(kb, 0)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    ref = F.gelu(t(A) @ t(W).T + t(bias)) * 0.75 + t(R)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+
+
 @pytest.mark.parametrize("M,N,K,res,act,exact", [
     (300, 320, 128, True, 0, False),     # fp32 out + fp32 residual (SAM mlp.lin2 / proj on the fp32 residual stream), ragged
     (256, 256, 192, False, 2, False),    # fp32 out, GELU, no residual
