@@ -208,9 +208,13 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
     for (int s = 1; s <= smax; ++s) {
       if (g_force_splits > 0 && s != g_force_splits && allow_split) continue;
       if (s > 1 && nk / s < 4 && g_force_splits == 0) break;
-      // 64-row tiles re-read every weight tile twice as often: with deep split-K (few M tiles, weight-streaming
-      // bound) they lose to 128-row tiles in every measured case
-      if (bm == 64 && s > 2 && g_force_splits == 0) break;
+      // 64-row tiles re-read every weight tile twice as often: no deep split-K on them.  (Round 5 re-measured this cut-off:
+      // ALONE, 64-row x 8 slices = 512 workgroups is ahead on the M = 512 convolutions since the XCD-partitioned tile order --
+      // conv3x3 8x8 1280->1280 38.3 -> 32.8 us, the stride-2 convolutions 39 -> 33 us, profiles/r05_split_sweep.jsonl,
+      // r05_plan_rule_ab.jsonl -- but in the STEP, where the ControlNet branch runs beside the UNet encoder, the launches that
+      // take every CU slot give the neighbour stream nothing: same box A/B/A/B 11.99 / 12.02 / 11.93 / 12.06 images/s (new / old),
+      // profiles/r05_plan_rule_bench_aba.jsonl.  The rule stays; EA_EXP & 128 builds the relaxed one (>= 10 K tiles per slice).)
+      if (bm == 64 && s > 2 && (!(EA_EXP & 128) || nk / s < 10) && g_force_splits == 0) break;
       // ... and they only pay while every workgroup is resident at once (<= 2 per CU): with a second round the
       // 128-row tiles' better weight reuse wins again (M32768 x K1280: 44 us vs 38 us)
       if (bm == 64 && g_force_splits == 0 && !forced_bm &&
