@@ -491,8 +491,8 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
         !e.residual32 && !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 &&
         (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 7) == 0 && p.debug != 9)
       p.epi_fast = 2;
-    // register-direct fp32 output (ea_epi_tr.h F32OUT; ea_gemm8 and the TR = 3 instantiations of ea_gemm2): fp32 out, optional fp32 residual
-    if ((t.kind == 30 || t.kind == 1 || t.kind == 9) && !g_no_tr && t.splits == 1 && e.out_f32 && !e.residual && !e.row_scale && !e.bias_per_row && e.act != EA_ACT_GEGLU &&
+    // register-direct fp32 output (ea_gemm8.h only: ea_epi_tr.h F32OUT): fp32 out, optional fp32 residual
+    if (t.kind == 30 && t.splits == 1 && e.out_f32 && !e.residual && !e.row_scale && !e.bias_per_row && e.act != EA_ACT_GEGLU &&
         (e.N & 3) == 0 && (e.ldc & 3) == 0 && (((uintptr_t)e.out) & 15) == 0 && (p.strideC & 3) == 0 && span < 0x7fffffffLL &&
         (!e.residual32 || ((e.ldr & 3) == 0 && (((uintptr_t)e.residual32) & 15) == 0 && (p.strideR & 3) == 0 && (long long)p.M * e.ldr < 0x7fffffffLL)) &&
         (!e.rowvec || (p.batch == 1 && e.rows_per_group > 0 && (e.rows_per_group % t.bm) == 0)) && p.debug != 9)
@@ -551,12 +551,6 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
   s.tr = tr ? 1 : 0;
   s.tr_raw = tr_raw ? 1 : 0;
   s.lnx = (tr && (p.epi.ln_stats || ((p.epi.row_stats_out || p.epi.gn_stats_out) && t.splits == 1))) ? 1 : 0;   // fold / statistics compiled in
-  if (p.epi_fast == 4 && s.lnx) {       // the fp32-output form carries neither fold nor statistics: the slab epilogue's job
-    p.epi_fast = 0;
-    s.tr = 0;
-    if (p.epi.ln_stats || p.epi.gn_stats_out) return EA_ERR_UNSUPPORTED;
-    s.lnx = 0;
-  }
   s.reduce_gn = p.epi.gn_next_out ? 1 : 0;
   return EA_OK;
 }
@@ -631,11 +625,7 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
       }
     } else
 #endif
-    if (p.epi_fast == 4 && t.kind != 30) {
-      if (q) return EA_ERR_UNSUPPORTED;
-      if (t.kind == 1) { if (t.bn == 160) EA_LAUNCH_TR(128, 160, 3); else EA_LAUNCH_TR(128, 128, 3); }
-      else { if (t.bn == 160) EA_LAUNCH_TR(64, 160, 3); else EA_LAUNCH_TR(64, 128, 3); }
-    } else if (t.kind == 30) {
+    if (t.kind == 30) {
       if (s.lnx || q) return EA_ERR_UNSUPPORTED;
       auto kfn = ea_gemm8_kernel<1>;
       ea_allow_big_lds(kfn, EA_G8_LDS_BYTES);
@@ -757,7 +747,7 @@ static int launch_pair(EaGemmParams& p, EaGemmParams& q, void* workspace, size_t
     const size_t half = (ws_bytes / 2) & ~(size_t)255;
     int st = fast_select(p, workspace, half, 0, sp);
     if (st == EA_OK) st = fast_select(q, workspace, 2 * half, half, sq);
-    if (st == EA_OK && same_launch(sp, sq) && sp.tr && (sp.t.kind == 1 || sp.t.kind == 9) && p.debug == 0 && q.debug == 0 && p.epi_fast != 4 && q.epi_fast != 4)
+    if (st == EA_OK && same_launch(sp, sq) && sp.tr && (sp.t.kind == 1 || sp.t.kind == 9) && p.debug == 0 && q.debug == 0)
       return fast_issue(sp, p, &q, stream);
     if (st != EA_OK && st != EA_ERR_WORKSPACE) return st;
   }

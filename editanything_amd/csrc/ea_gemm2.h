@@ -72,7 +72,7 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // max(issue, compute).  One barrier per K tile, 3-deep ring: at barrier kt the loaders have waited for tile kt
 // (counted vmcnt, tile kt + 1 still in flight), the compute waves have retired their reads of tile kt - 1, whose buffer
 // the loaders refill with tile kt + 2 right after.
-// TR = 1 / 2 / 3: TRANSPOSED accumulators + register-direct epilogue (3 = the fp32-output form; 2 = with the LayerNorm fold and the row-statistics
+// TR = 1 / 2: TRANSPOSED accumulators + register-direct epilogue (2 = with the LayerNorm fold and the row-statistics
 // output compiled in; the plain launches run the instantiation without them).  The MFMA operands are swapped (D^T = W A^T), so a lane
 // holds 4 CONSECUTIVE output columns of one output row per 16x16 tile (row = lane % 16, columns 4 * (lane / 16) ..+3)
 // instead of 4 consecutive rows of one column: after one v_permlane16_swap per register two tiles give every lane 8
@@ -667,9 +667,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     //    part = (column of the wave tile) / WTN -- what the next launch's LayerNorm fold consumes.
     if constexpr (TR != 0) {
       EA_STAMP(2);
-      // TR = 3: the plain form with the fp32-output branch compiled in (p.epi_fast == 4: SAM's fp32 residual stream) -- its own
-      // instantiation, so the instantiations every fp16 launch runs carry nothing for it
-      ea_tr_epilogue<MI, NI, TR == 3 ? 1 : TR, true, TR == 3>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem, wave);
+      ea_tr_epilogue<MI, NI, TR, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem, wave);
       EA_STAMP(4);
     }
     return;
