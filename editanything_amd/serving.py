@@ -31,7 +31,9 @@ x 3 full-size requests, 0 differ from the plain call bit for bit (profiles/r05_p
 is tested bit-stable beside busy neighbour streams (tests/test_zz_neighbour_stream.py).  `overlap=False` runs the three stages
 of every request in order on the caller's stream (no second stream, no thread).
 
-Host-side rules of the overlapped form: `front` works on a per-call copy of the scheduler (pipeline.front), graphs captured on
+Host-side rules of the overlapped form: the FIRST request of a runner's life runs its three stages with nothing beside them (every
+kernel's first launch -- code-object load, scratch / LDS attributes -- on an idle device; overlap starts with the second request),
+`front` works on a per-call copy of the scheduler (pipeline.front), graphs captured on
 the worker thread use thread-local capture mode (sam.forward_graph), a first-of-its-shape denoising step is captured with the
 device idle (below), and a request that passes `generator=None` draws from torch's global generator in ISSUE order, which
 differs from the sequential order -- pass generators (the reference's `seed` argument does) for reproducible requests.
@@ -82,6 +84,7 @@ class PipelinedRunner:
         thread) and lives as long as the runner, so graphs captured on it stay valid."""
         self.pipe = pipe
         self.device = pipe.device
+        self._cold = True          # no request has gone through yet: see `run`
         self.overlap = bool(overlap)
         self.threaded = threaded and self.overlap
         self._pool = None
@@ -228,9 +231,18 @@ class PipelinedRunner:
             ev_loop = torch.cuda.Event()
             ev_loop.record(main)
             prev = (call, ev_loop)
+            if self._cold:
+                # the FIRST request of this runner's life goes through its three stages with nothing beside them: every kernel
+                # of `front` / `loop` / `back` has its first launch (code object load, scratch / LDS attributes, allocator growth)
+                # on an otherwise idle device; overlap starts with the second request
+                outs[i] = self._back(*prev, main).result()
+                torch.cuda.synchronize(self.device)
+                prev = None
+                self._cold = False
             if capture and i + 1 < n:
                 nxt = self._front(requests[i + 1])
-        outs[n - 1] = self._back(*prev, main)
+        if prev is not None:
+            outs[n - 1] = self._back(*prev, main)
         outs = [o.result() if isinstance(o, concurrent.futures.Future) else o for o in outs]
         done = torch.cuda.Event()
         self._on_side(lambda: done.record()).result()
