@@ -476,6 +476,21 @@ class StableDiffusionControlNetInpaintPipeline:
         c.per_net, c.unipc, c.step_noise, c.mixing, c.in_loop_blend, c.gkey = per_net, unipc, step_noise, mixing, in_loop_blend, gkey
         c.do_cfg, c.n_img, c.generator, c.alignment_ratio, c.alpha_weight = do_cfg, n_img, generator, alignment_ratio, alpha_weight
         c.callback, c.callback_steps, c.output_type, c.return_dict = callback, callback_steps, output_type, return_dict
+        # Every random draw of the LOOP is made here, in the order `loop` consumes it (one re-noise draw in front of the steps when
+        # mixing; per step the eta > 0 variance noise, then the mixing re-noise): `loop` never touches the generator.  A call
+        # draws front-then-loop from its generator whichever way it is run, so when serving.PipelinedRunner issues front(i + 1)
+        # beside loop(i) -- possibly on the SAME generator object (torch.manual_seed returns the global one) -- request i + 1
+        # still starts from the state request i's loop would have left: overlapped == sequential, bit for bit (round-5 advisor).
+        g0 = generator if not isinstance(generator, list) else generator[0]
+        nsteps = len(timesteps)
+        c.loop_noise = []
+        if mixing:
+            c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
+        for i in range(nsteps):
+            if step_noise:
+                c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
+            if mixing and i < nsteps - 1:
+                c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
         c.final = None
         return c
 
@@ -487,8 +502,9 @@ class StableDiffusionControlNetInpaintPipeline:
     def loop(self, c):
         """Stage 2: hand the call's tensors to the (static) buffers of the captured step, run the denoising steps, leave
         the final latents in `c.final` (a tensor the call owns)."""
-        sch, timesteps, generator = c.sch, c.timesteps, c.generator
+        sch, timesteps = c.sch, c.timesteps
         nsteps = len(timesteps)
+        draws = iter(c.loop_noise)          # pre-drawn by `front`, in this order
         lat, x_orig, extra, blend_mask = c.lat, c.x_orig, c.extra, c.blend_mask
         unipc, step_noise, mixing, in_loop_blend, gkey = c.unipc, c.step_noise, c.mixing, c.in_loop_blend, c.gkey
         ref_state, ref_ctx = c.ref_state, c.ref_ctx
@@ -537,9 +553,8 @@ class StableDiffusionControlNetInpaintPipeline:
                     for dst, src in zip(st["tab"][k] if isinstance(v, list) else [st["tab"][k]], v if isinstance(v, list) else [v]):
                         dst.copy_(src)
             st["step"].zero_()
-        mix_gen = generator if not isinstance(generator, list) else generator[0]
         if mixing:   # …inpaint.py:1968-1975: the kept region starts from the re-noised original, the rest from pure noise
-            self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[0])]), 0.0, True, mix_gen)
+            self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[0])]), 0.0, True, next(draws))
         for i in range(nsteps):
             if not self_advance:
                 st["t"].fill_(int(timesteps[i]))
@@ -549,8 +564,7 @@ class StableDiffusionControlNetInpaintPipeline:
                     st["unipc"]["coefP"].copy_(c.coef_p_table[i])
                 for dst, tb in zip(st["embs"], emb_tables):
                     dst.copy_(tb[i:i + 1])
-            st["noise"] = randn_tensor(lat.shape, generator if not isinstance(generator, list) else generator[0], self.device) \
-                if step_noise else None
+            st["noise"] = next(draws) if step_noise else None
             blend_now = in_loop_blend and i < nsteps * c.alignment_ratio and i + 1 < nsteps
             st["blend_mask"] = blend_mask if blend_now else None
             if ref_state is not None:
@@ -581,7 +595,7 @@ class StableDiffusionControlNetInpaintPipeline:
                 c.callback(i, int(timesteps[i]), st["lat"])
             if mixing and i < nsteps - 1:     # …inpaint.py:2039-2051
                 self._mix_blend(st["lat"], x_orig, blend_mask, float(sch.alphas_cumprod[int(timesteps[i + 1])]),
-                                float(c.alpha_weight), i < nsteps * c.alignment_ratio, mix_gen)
+                                float(c.alpha_weight), i < nsteps * c.alignment_ratio, next(draws))
         c.final = st["lat"].clone()           # never hand out (or decode from) the captured step's static buffer
         self._mark("denoise loop")
 
@@ -670,13 +684,13 @@ class StableDiffusionControlNetInpaintPipeline:
         state = ReferenceOnly(self.unet, self.controlnets[-1], n_img, do_cfg, rmask, imask, **opts)
         return state, den, ref_lat.contiguous(), ref_noise
 
-    def _mix_blend(self, lat, x_orig, gen_mask, a_next, alpha, renoise_kept, generator):
+    def _mix_blend(self, lat, x_orig, gen_mask, a_next, alpha, renoise_kept, noise):
         """In place, with proper = sqrt(a) * x_orig + sqrt(1 - a) * fresh noise (scheduler.add_noise at the next timestep):
             generated region (gen_mask = 1):  (1 - alpha) * lat + alpha * proper
             kept region      (gen_mask = 0):  proper if `renoise_kept` else lat
         One `ea_lincomb_f32` launch.  The reference draws the fresh noise with torch.randn_like on the device's global
-        RNG (…inpaint.py:1975, 2041); here it comes from the call's generator, so a seeded call is reproducible."""
-        noise = randn_tensor(lat.shape, generator, self.device)
+        RNG (…inpaint.py:1975, 2041); here `noise` comes from the call's generator (drawn by `front`, in the loop's order), so a
+        seeded call is reproducible."""
         c1, c2 = a_next ** 0.5, (1.0 - a_next) ** 0.5
         if renoise_kept:
             coef, alt = [1.0 - alpha, alpha * c1, alpha * c2, 0.0, 0.0, c1, c2], (x_orig, noise)

@@ -35,8 +35,11 @@ Host-side rules of the overlapped form: the FIRST request of a runner's life run
 kernel's first launch -- code-object load, scratch / LDS attributes -- on an idle device; overlap starts with the second request),
 `front` works on a per-call copy of the scheduler (pipeline.front), graphs captured on
 the worker thread use thread-local capture mode (sam.forward_graph), a first-of-its-shape denoising step is captured with the
-device idle (below), and a request that passes `generator=None` draws from torch's global generator in ISSUE order, which
-differs from the sequential order -- pass generators (the reference's `seed` argument does) for reproducible requests.
+device idle (below).  Random draws: `front` makes EVERY draw of its request, the loop's included (pipeline.front: eta > 0 step
+noise, the mixing pipeline's re-noise), and the fronts are issued in request order by one thread -- so requests that share a
+generator object (`torch.manual_seed(s)` returns the GLOBAL one, `generator=None` uses it too) consume it exactly as the
+one-call-at-a-time path does and the overlapped results equal the sequential ones bit for bit
+(tests/test_pipeline_parity.py::test_software_pipelined_requests_sharing_one_generator).
 """
 import concurrent.futures
 import time
@@ -211,8 +214,11 @@ class PipelinedRunner:
             if self.keep_calls is not None:
                 self.keep_calls.append(call)
             capture = not self.pipe.has_graph(call)
-            if capture:
-                # first call of a shape: the step is captured inside `loop` -- nothing else may run on the device then
+            # first call of a shape (the step is captured inside `loop`) or first request of this runner's life (below): nothing
+            # else may run on the device -- also when the pipe already holds the graph (a call made before the runner existed, a
+            # second runner on the same pipe: round-5 advisor)
+            idle = capture or self._cold
+            if idle:
                 if prev is not None:
                     outs[i - 1] = self._back(*prev, main).result()
                 torch.cuda.synchronize(self.device)
@@ -239,7 +245,7 @@ class PipelinedRunner:
                 torch.cuda.synchronize(self.device)
                 prev = None
                 self._cold = False
-            if capture and i + 1 < n:
+            if idle and i + 1 < n:
                 nxt = self._front(requests[i + 1])
         if prev is not None:
             outs[n - 1] = self._back(*prev, main)

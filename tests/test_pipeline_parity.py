@@ -153,6 +153,38 @@ def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny, over
     assert all(np.array_equal(a, o.images) for o in b)
 
 
+@pytest.mark.parametrize("kind", ["mixing", "eta"])
+def test_software_pipelined_requests_sharing_one_generator(mg, tiny, kind):
+    """Round-5 advisor (serving.py): requests that share ONE generator object -- `torch.manual_seed(s)` hands out the GLOBAL
+    generator, which is what the reference's `seed` argument does (sam2image.py:163-167) -- and whose LOOP draws from it (the
+    mixing pipeline's per-step re-noise; eta > 0 DDIM variance noise).  Overlapped, front(i + 1) runs on the worker thread beside
+    loop(i): every draw of a request is therefore made by its `front` (pipeline.front), in the order the loop consumes them, and
+    four such requests through the two-stream runner must equal the four plain calls made one after the other on the same
+    generator, bit for bit."""
+    from editanything_amd import serving
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintMixingPipeline, StableDiffusionControlNetInpaintPipeline
+    if kind == "mixing":
+        cns, kw = mg.mix_case_kwargs("mix_a05", mg.pipe_inputs())
+        cls, ukey = StableDiffusionControlNetInpaintMixingPipeline, "unet"
+    else:
+        ukey, cns, kw = mg.pipe_case_kwargs("a_050_eta", mg.pipe_inputs())
+        cls = StableDiffusionControlNetInpaintPipeline
+    n = 4
+    seq_pipe = _pipe(cls, tiny, ukey, cns, True)
+    g = torch.manual_seed(29)                      # the global generator
+    want = [seq_pipe(generator=g, **kw).images.clone() for _ in range(n)]
+    assert not torch.equal(want[0], want[1]), "consecutive calls on one generator must see different noise"
+    for overlap in (True, False):
+        pipe = _pipe(cls, tiny, ukey, cns, True)
+        runner = serving.PipelinedRunner(pipe, overlap=overlap)
+        g = torch.manual_seed(29)
+        got = runner.run([dict(kw, generator=g) for _ in range(n)])
+        torch.cuda.synchronize()
+        runner.close()
+        for r in range(n):
+            assert torch.equal(got[r].images, want[r]), f"overlap={overlap} request {r}: rel-L2 {rel_l2(got[r].images, want[r]):.3e}"
+
+
 def test_batched_tile_refinement_vs_the_reference_one_call_per_sample(mg, tiny):
     """editany_lora.py:885-936 refines the samples one pipeline call at a time, every call drawing from the same generator
     (initial latents, then the VAE posterior noise).  tests/golden/pipe_tile.npz holds what the reference's OWN `__call__`
@@ -420,9 +452,10 @@ def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
     then the VAE posterior noise, whose first row is the batch-1 draw) -- and must reach the SAME bar against the fp32
     oracle's batch-1 result (samples are independent: cldm/cldm.py has no cross-sample operation).  Images 1..3 carry other
     images / controls / prompts / seeds: they exercise the batched launch set and must not leak into image 0.
-    Then the same call as the MIDDLE request of three through the staged runner (serving.PipelinedRunner in its shipped, in-order
-    form: front -> loop -> back per request): bit-identical latents, whatever ran before.  (The two-stream form, overlap=True, is
-    an experiment whose results are NOT reproducible at this size: profiles/r04_pipelined_race.jsonl.)"""
+    Then the same call as the MIDDLE request of three through serving.PipelinedRunner in BOTH forms -- in order on one stream
+    (overlap=False) and software-pipelined over two streams (overlap=True: front(i + 1) / back(i - 1) beside loop(i)): bit-identical
+    latents, whatever ran before or beside.  (Round 4 found the two-stream form irreproducible at this size; both causes were
+    kernel bugs, fixed and root-caused in round 5 -- DESIGN.md 8g-1, profiles/r05_pipeline_stress500.jsonl.)"""
     from editanything_amd import serving
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
     from editanything_amd.scheduler import DDIMScheduler
@@ -442,14 +475,15 @@ def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
     assert psnr >= 35.0, psnr
     for b in range(1, B):
         assert float(torch.nn.functional.cosine_similarity(lat[b].flatten(), ref.flatten(), dim=0)) < 0.9      # other samples really differ
-    runner = serving.PipelinedRunner(pipe)
-    outs = runner.run([_batch4_call(e2e, (5, 6, 7, 8)), _batch4_call(e2e), _batch4_call(e2e, (9, 10, 11, 12))])
-    torch.cuda.synchronize()
     again = pipe(**_batch4_call(e2e)).images.float().cpu()
     assert torch.equal(again, lat), "the plain call is run-to-run deterministic"
-    assert torch.equal(outs[1].images.float().cpu(), lat), "the staged runner must not change a request's result"
-    assert not torch.equal(outs[0].images.float().cpu(), lat)
-    runner.close()
+    for overlap in (False, True):
+        runner = serving.PipelinedRunner(pipe, overlap=overlap)
+        outs = runner.run([_batch4_call(e2e, (5, 6, 7, 8)), _batch4_call(e2e), _batch4_call(e2e, (9, 10, 11, 12))])
+        torch.cuda.synchronize()
+        assert torch.equal(outs[1].images.float().cpu(), lat), f"overlap={overlap}: the runner must not change a request's result"
+        assert not torch.equal(outs[0].images.float().cpu(), lat)
+        runner.close()
 
 
 def test_sd21_eval_network_batch_8_vs_frozen_oracle(sd21):
