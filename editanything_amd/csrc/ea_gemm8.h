@@ -76,11 +76,12 @@ __device__ __forceinline__ void ea_gemm8_tile(const EaGemmParams& p, const int w
 
 #ifndef EA_EMU
   {   // one batch of scalar loads over the kernel-argument block's cache lines (see ea_gemm2.h)
+    static_assert(sizeof(EaGemmParams) > 0x100, "the five 64-byte lines touched below must lie inside the kernel-argument block");
     const unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned w0, w1, w2, w3, w4;
     asm volatile("s_load_dword %0, %5, 0x0\n\ts_load_dword %1, %5, 0x40\n\ts_load_dword %2, %5, 0x80\n\t"
                  "s_load_dword %3, %5, 0xc0\n\ts_load_dword %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
-                 : "=s"(w0), "=s"(w1), "=s"(w2), "=s"(w3), "=s"(w4) : "s"(ka) : "memory");
+                 : "=&s"(w0), "=&s"(w1), "=&s"(w2), "=&s"(w3), "=&s"(w4) : "s"(ka) : "memory");   // early-clobber: no output may land on the ka pair (SMEM returns are asynchronous)
   }
 #endif
   const int tiles_n = (p.N + BN - 1) / BN;

@@ -172,7 +172,12 @@ __device__ __forceinline__ float ea_gelu_erf(float x) {
   q = q * a + 0.45904383063316345f;
   q = q * a + 1.1511269807815552f;
   const float e = ea_exp2_raw(-a * q - 1.0f);       // 1 - Phi(a)
-  return fmaxf(x, 0.0f) - a * e;                     // (a, not |x|: +inf stays +inf; beyond the clamp the term is < 5e-8)
+  // (a, not |x|: +inf stays +inf; beyond the clamp the term is < 5e-8.)  NaN: fminf / fmaxf return their non-NaN operand, so the
+  // clamped form alone turns a NaN into -2e-8 and hides an upstream overflow; it is re-attached explicitly (round-5 advisor;
+  // the build keeps NaN semantics: -fno-finite-math-only.  tests/test_abi.py pins NaN in -> NaN out through the C ABI's SiLU /
+  // GELU entry on the emulator and the GPU)
+  const float r = fmaxf(x, 0.0f) - a * e;
+  return (x != x) ? x : r;
 }
 __device__ __forceinline__ f16x8 ea_ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
 __device__ __forceinline__ void ea_st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }

@@ -56,7 +56,10 @@ class Demo:
         self.device = torch.device(device)
         self.last_embedding = None
         self._runners = {}
-        self.overlap = True           # process_many: two-stream software pipeline over consecutive requests (serving.py)
+        # process_many: True = the two-stream software pipeline over consecutive requests (serving.py).  OFF by default since round 6:
+        # measured +2 % throughput for 2 x the latency of a request (bench.py `sequential` / `latency_p50_ms`) -- the reference is an
+        # interactive app, so the default serves one request at a time and a throughput deployment opts in
+        self.overlap = False
 
     def _pipe(self, path):
         if path not in self.pipes:
@@ -129,18 +132,18 @@ class Demo:
         """A queue of `process` requests (each a tuple / dict of its arguments) through the staged runner
         (serving.PipelinedRunner): every request is front (SAM encode + mask generation + control + VAE encode) -> loop -> back
         (VAE decode).  Returns `process`' return value per request, in order -- the same values `process` gives one request at
-        a time, bit for bit.  The runner overlaps the next request's front and the previous one's back with the current loop
-        on a second stream (serving.PipelinedRunner, overlap=True: its default since round 5; `Demo.overlap = False` keeps the
-        stages of a request in order on one stream)."""
+        a time, bit for bit.  `Demo.overlap = True` (opt-in, throughput mode) lets the runner overlap the next request's front and
+        the previous one's back with the current loop on a second stream; the default keeps the stages of a request in order on
+        one stream (latency mode: a request is finished before the next one starts)."""
         from .serving import PipelinedRunner
         reqs = [r if isinstance(r, dict) else dict(zip(self.process.__code__.co_varnames[1:], r)) for r in requests]
         paths = {config_dict.get(r["condition_model"], r["condition_model"]) for r in reqs}
         if len(paths) != 1:           # the pipeline overlaps calls of ONE pipeline object
             return [self.process(**r) for r in reqs]
         pipe = self._pipe(paths.pop())
-        runner = self._runners.get(id(pipe))
+        runner = self._runners.get((id(pipe), bool(self.overlap)))
         if runner is None:
-            runner = self._runners[id(pipe)] = PipelinedRunner(pipe, overlap=self.overlap)
+            runner = self._runners[(id(pipe), bool(self.overlap))] = PipelinedRunner(pipe, overlap=self.overlap)
         meta = [None] * len(reqs)
 
         def front(i, r):

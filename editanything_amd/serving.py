@@ -21,7 +21,9 @@ stage ever reads a buffer another in-flight request writes.  The side stream has
 Latency: a request leaves the runner one denoising loop after the sequential path would have finished it at the
 latest (its decode waits for nothing but its own loop); throughput is what moves -- bench.py reports both.
 
-**STATUS (round 5): `overlap` is ON by default.**  Round 4 measured the gain (+1.7 ... +2.8 % at the benchmark's shape) and then
+**STATUS (round 6): `overlap` is OPT-IN** (`PipelinedRunner(pipe, overlap=True)`, `Demo.overlap = True`, bench.py's throughput
+mode): it is correct -- see below -- but buys +2 % throughput for twice the latency of a request (bench.py `sequential`,
+`latency_p50_ms`), and the reference is an interactive app.  History: round 4 measured the gain (+1.7 ... +2.8 % at the benchmark's shape) and then
 found the captured loop's RESULT changing when work runs beside it on a second HIP stream.  Both causes were bugs of shipped
 kernels that only a busy neighbour exposes and both are fixed: a missing barrier in the d = 64 LDS-DMA attention kernel, and --
 root-caused in round 5 to the instruction level -- a packed-fp32 instruction with a cross-half source selection (v_pk_fma_f32 ...
@@ -77,8 +79,108 @@ def make_stream(device, priority, cu_count=0):
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
+# ---------------------------------------------------------------------------------------------------- request merging
+# Consecutive requests of one shape can be evaluated as ONE call with the batches concatenated: samples are independent in
+# every network of the path (cldm/cldm.py, ldm/modules: no cross-sample operation; GroupNorm / LayerNorm statistics are per
+# sample), so a request's images are the ones it gets alone up to fp16 summation order (the contraction planner picks other
+# split-K factors at other M).  Why: at the benchmark's network batch of 8 the 16 x 16 / 8 x 8 levels have M = 2048 / 512 rows --
+# launches of 15 - 40 us whose fixed part (set-up, epilogue, split-K round trip, partial rounds of the 256 CUs) weighs as much as
+# their K loop; at twice the rows the same fixed part is paid once for two requests (bench.py `batch_sweep`).
+_MERGE_SAME = ("height", "width", "num_inference_steps", "guidance_scale", "num_images_per_prompt", "eta", "output_type",
+               "return_dict", "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs")
+_MERGE_NONE = ("prompt", "negative_prompt", "callback", "controlnet_conditioning_scale_map", "alpha_weight", "ref_image",
+               "ref_mask", "ref_prompt", "ref_prompt_embeds", "control_image")
+
+
+def merge_kwargs(pipe, kws):
+    """ONE kwargs dict that evaluates the pipeline calls `kws` (a list of kwargs dicts) as a single batched call, or None when
+    they cannot be merged (different sizes / step counts / scales, string prompts, reference-only control, mixing, eta > 0,
+    callbacks, a 9-channel inpainting UNet: anything whose per-call state is not a row of a batch).  Every request keeps ITS
+    random draws: the initial latents and the VAE posterior noise are drawn here from the request's own generator, in the
+    order its own call would draw them (…inpaint.py:1005-1007 then :1079-1081), and handed over as `latents=` / `vae_noise=`.
+    -> (merged kwargs, [images per request])."""
+    from . import host
+    from .pipeline import randn_tensor
+    if len(kws) < 2:
+        return None
+    k0 = kws[0]
+    for kw in kws:
+        if any(kw.get(k) is not None for k in _MERGE_NONE) or kw.get("eta", 0.0) != 0.0 or kw.get("vae_noise") is not None:
+            return None
+        if any(kw.get(k) != k0.get(k) for k in _MERGE_SAME):
+            return None
+        if not torch.is_tensor(kw.get("prompt_embeds")) or (kw.get("negative_prompt_embeds") is None) != (k0.get("negative_prompt_embeds") is None):
+            return None
+        if (kw.get("image") is None) != (k0.get("image") is None):
+            return None
+    if pipe.unet.cfg["in_channels"] != 4 and k0.get("image") is not None:
+        return None
+    height, width = k0.get("height"), k0.get("width")
+    if height is None or width is None:
+        return None
+    nipp = int(k0.get("num_images_per_prompt", 1) or 1)
+    if nipp != 1:
+        return None                                       # (rows of one prompt are tiled per call: keep the merge to plain batches)
+    dev = pipe.device
+
+    def control(kw):
+        c = kw.get("controlnet_conditioning_image")
+        return list(c) if isinstance(c, (list, tuple)) else [c]
+    ctl = [control(kw) for kw in kws]
+    if any(len(c) != len(ctl[0]) or not all(torch.is_tensor(t) and t.dim() == 4 for t in c) for c in ctl):
+        return None
+    lats, vns, imgs, msks, sizes = [], [], [], [], []
+    for kw, c in zip(kws, ctl):
+        b = kw["prompt_embeds"].shape[0]
+        n_img = b * nipp
+        if any(t.shape[0] not in (b, n_img) for t in c):
+            return None
+        sizes.append(n_img)
+        g = kw.get("generator")
+        shape = (n_img, 4, height // 8, width // 8)
+        if isinstance(g, (list, tuple)):                  # one generator per image (pipeline.prepare_latents / _vae_noise rules)
+            if len(g) != n_img:
+                return None
+            draw, g = (lambda: torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g])), g[0]
+        else:
+            draw = lambda: randn_tensor(shape, g, dev)
+        lats.append(kw["latents"].to(dev) if kw.get("latents") is not None else draw())
+        if kw.get("image") is not None:
+            img = host.prepare_image(kw["image"])
+            msk = host.prepare_mask_image(kw["mask_image"])
+            if img.shape[0] != msk.shape[0] or img.shape[0] not in (b, n_img) or img.shape[-2:] != (height, width) or msk.shape[-2:] != (height, width):
+                return None
+            vns.append(randn_tensor((img.shape[0], 4, height // 8, width // 8), g, dev))
+            imgs.append(img)
+            msks.append(msk)
+    if imgs and len({(i.shape[0] == n) for i, n in zip(imgs, sizes)}) != 1:
+        return None                                       # rows must repeat the same way in every request
+    cat = lambda ts: torch.cat([t.to(dev) for t in ts])
+    out = {k: v for k, v in k0.items() if k in _MERGE_SAME}
+    out.update(prompt_embeds=cat([kw["prompt_embeds"] for kw in kws]), latents=cat(lats), generator=None)
+    if k0.get("negative_prompt_embeds") is not None:
+        out["negative_prompt_embeds"] = cat([kw["negative_prompt_embeds"] for kw in kws])
+    merged_ctl = [cat([c[j] for c in ctl]) for j in range(len(ctl[0]))]
+    out["controlnet_conditioning_image"] = merged_ctl if isinstance(k0.get("controlnet_conditioning_image"), (list, tuple)) else merged_ctl[0]
+    if imgs:
+        out.update(image=cat(imgs), mask_image=cat(msks), vae_noise=cat(vns))
+    return out, sizes
+
+
+def split_output(out, sizes):
+    """The per-request outputs of a merged call (rows in request order)."""
+    from .pipeline import StableDiffusionPipelineOutput
+    images = out.images if hasattr(out, "images") else out[0]
+    res, lo = [], 0
+    for n in sizes:
+        part = images[lo:lo + n]
+        res.append(StableDiffusionPipelineOutput(part, None) if hasattr(out, "images") else (part, None))
+        lo += n
+    return res
+
+
 class PipelinedRunner:
-    def __init__(self, pipe, overlap=True, side_stream=None, threaded=True, side_priority=1, side_cus=0):
+    def __init__(self, pipe, overlap=False, side_stream=None, threaded=True, side_priority=1, side_cus=0, merge=1):
         """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
         the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
         packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:
@@ -87,6 +189,7 @@ class PipelinedRunner:
         thread) and lives as long as the runner, so graphs captured on it stay valid."""
         self.pipe = pipe
         self.device = pipe.device
+        self.merge = int(merge)    # consecutive requests evaluated as one batched call where they can be (merge_kwargs)
         self._cold = True          # no request has gone through yet: see `run`
         self.overlap = bool(overlap)
         self.threaded = threaded and self.overlap
@@ -144,10 +247,12 @@ class PipelinedRunner:
             self._pool.shutdown(wait=True)
             self._pool = None
 
-    def _front(self, req, after=None):
-        """On the side stream: `req` is the pipeline's kwargs, or a callable producing them (the SAM encode + mask
-        generation + control-image part of a request belongs here: it is issued on the side stream too).
-        after: an event of the caller's stream the inputs depend on."""
+    def _front(self, group, after=None):
+        """On the side stream: the front stage of one UNIT = `merge` consecutive requests.  A request is the pipeline's kwargs,
+        or a callable producing them (the SAM encode + mask generation + control-image part of a request belongs here: it is
+        issued on the side stream too).  Requests that `merge_kwargs` accepts become ONE call (their batches concatenated), the
+        others one call each.  after: an event of the caller's stream the inputs depend on.
+        -> (calls, sizes per call or None, event)."""
         def fn():
             if after is not None:
                 self.side.wait_event(after)
@@ -155,66 +260,88 @@ class PipelinedRunner:
             if self.latency_events is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            with self._span(("front", id(req))):
-                kw = req() if callable(req) else req
-                call = self.pipe.front(**kw)
-            call._t0, call._req = e0, id(req)
+            with self._span(("front", id(group[0]))):
+                calls, sizes = self._front_calls(group)
+            for c in calls:
+                c._t0, c._req = e0, id(group[0])
             ev = torch.cuda.Event()
             ev.record()
-            return call, ev
+            return calls, sizes, ev
         return self._on_side(fn)
 
-    def _back(self, call, ev_loop, consumer):
+    def _front_calls(self, group):
+        kws = [r() if callable(r) else r for r in group]
+        merged = merge_kwargs(self.pipe, kws) if len(kws) > 1 else None
+        if merged is not None:
+            return [self.pipe.front(**merged[0])], [merged[1]]
+        return [self.pipe.front(**kw) for kw in kws], [None] * len(kws)
+
+    def _finish(self, calls, sizes):
+        """back() of a unit's calls -> the per-REQUEST outputs, in order."""
+        outs = []
+        for c, sz in zip(calls, sizes):
+            o = self.pipe.back(c)
+            outs.extend(split_output(o, sz) if sz is not None else [o])
+        return outs
+
+    def _back(self, calls, sizes, ev_loop, consumer):
         def fn():
             self.side.wait_event(ev_loop)
-            call.final.record_stream(self.side)   # allocated on the caller's stream, read here
-            with self._span(("back", call._req)):
-                out = self.pipe.back(call)
-            img = getattr(out, "images", None)
-            if torch.is_tensor(img):
-                img.record_stream(consumer)       # allocated here, read by the caller on its stream
-            if call._t0 is not None:
+            for c in calls:
+                c.final.record_stream(self.side)  # allocated on the caller's stream, read here
+            with self._span(("back", calls[0]._req)):
+                outs = self._finish(calls, sizes)
+            for out in outs:
+                img = getattr(out, "images", None)
+                if torch.is_tensor(img):
+                    img.record_stream(consumer)   # allocated here, read by the caller on its stream
+            if calls[0]._t0 is not None:
                 e1 = torch.cuda.Event(enable_timing=True)
                 e1.record()
-                self.latency_events.append((call._t0, e1))
-            return out
+                self.latency_events.append((calls[0]._t0, e1))
+            return outs
         return self._on_side(fn)
 
     @torch.no_grad()
-    def run(self, requests):
+    def run(self, requests, merge=None):
         """requests: a sequence of kwargs dicts (or callables returning one) for `pipe(...)`.  Returns the list of
         pipeline outputs, in order.  Device work is enqueued asynchronously; the caller's stream is made to wait for the
-        side stream before returning, so the outputs are ordinary tensors of the caller's stream."""
+        side stream before returning, so the outputs are ordinary tensors of the caller's stream.
+        merge (default: the runner's): that many consecutive requests form one unit and, where `merge_kwargs` accepts them, ONE
+        batched call."""
         requests = list(requests)
-        n = len(requests)
-        outs = [None] * n
+        merge = max(1, int(self.merge if merge is None else merge))
+        units = [requests[i:i + merge] for i in range(0, len(requests), merge)]
+        n = len(units)
         if n == 0:
-            return outs
-        if not self.overlap:              # in order, on the caller's stream: front -> loop -> back per request
-            for i, req in enumerate(requests):
+            return []
+        outs = [None] * n                 # per unit: list of per-request outputs (or a Future of one)
+        if not self.overlap:              # in order, on the caller's stream: front -> loop -> back per unit
+            for i, group in enumerate(units):
                 e0 = None
                 if self.latency_events is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                call = self.pipe.front(**(req() if callable(req) else req))
-                self.pipe.loop(call)
-                outs[i] = self.pipe.back(call)
+                calls, sizes = self._front_calls(group)
+                for c in calls:
+                    self.pipe.loop(c)
+                outs[i] = self._finish(calls, sizes)
                 if e0 is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()
                     self.latency_events.append((e0, e1))
-            return outs
+            return [o for u in outs for o in u]
         main = torch.cuda.current_stream(self.device)
         start = torch.cuda.Event()
         start.record(main)                        # inputs the caller produced on its stream
-        nxt = self._front(requests[0], after=start)
-        prev = None                               # (call, loop-done event) of the request whose decode is still owed
+        nxt = self._front(units[0], after=start)
+        prev = None                               # (calls, sizes, loop-done event) of the unit whose decode is still owed
         for i in range(n):
-            call, ev_front = nxt.result()
+            calls, sizes, ev_front = nxt.result()
             if self.keep_calls is not None:
-                self.keep_calls.append(call)
-            capture = not self.pipe.has_graph(call)
-            # first call of a shape (the step is captured inside `loop`) or first request of this runner's life (below): nothing
+                self.keep_calls.extend(calls)
+            capture = any(not self.pipe.has_graph(c) for c in calls)
+            # first call of a shape (the step is captured inside `loop`) or first unit of this runner's life (below): nothing
             # else may run on the device -- also when the pipe already holds the graph (a call made before the runner existed, a
             # second runner on the same pipe: round-5 advisor)
             idle = capture or self._cold
@@ -227,30 +354,31 @@ class PipelinedRunner:
                 if prev is not None:
                     outs[i - 1] = self._back(*prev, main)
                 if i + 1 < n:
-                    nxt = self._front(requests[i + 1])
+                    nxt = self._front(units[i + 1])
             main.wait_event(ev_front)
             t0 = time.perf_counter()
-            with self._span(("loop", call._req)):
-                self.pipe.loop(call)
+            with self._span(("loop", calls[0]._req)):
+                for c in calls:
+                    self.pipe.loop(c)
             if self.host_trace is not None:
                 self.host_trace.append((i, time.perf_counter() - t0))
             ev_loop = torch.cuda.Event()
             ev_loop.record(main)
-            prev = (call, ev_loop)
+            prev = (calls, sizes, ev_loop)
             if self._cold:
-                # the FIRST request of this runner's life goes through its three stages with nothing beside them: every kernel
+                # the FIRST unit of this runner's life goes through its three stages with nothing beside them: every kernel
                 # of `front` / `loop` / `back` has its first launch (code object load, scratch / LDS attributes, allocator growth)
-                # on an otherwise idle device; overlap starts with the second request
+                # on an otherwise idle device; overlap starts with the second unit
                 outs[i] = self._back(*prev, main).result()
                 torch.cuda.synchronize(self.device)
                 prev = None
                 self._cold = False
             if idle and i + 1 < n:
-                nxt = self._front(requests[i + 1])
+                nxt = self._front(units[i + 1])
         if prev is not None:
             outs[n - 1] = self._back(*prev, main)
         outs = [o.result() if isinstance(o, concurrent.futures.Future) else o for o in outs]
         done = torch.cuda.Event()
         self._on_side(lambda: done.record()).result()
         main.wait_event(done)
-        return outs
+        return [o for u in outs for o in u]

@@ -77,12 +77,13 @@ def test_one_exponential_gelu_matches_the_erf_gelu_to_fp32_roundoff():
 
     def gelu(x):
         x = x.astype(np.float32)
-        a = np.minimum(np.abs(x), np.float32(5.65685424949238))
+        a = np.fmin(np.abs(x), np.float32(5.65685424949238))
         q = np.full_like(a, coef[-1])
         for c in coef[-2::-1]:
             q = q * a + c
         e = np.exp2(-a * q - np.float32(1.0)).astype(np.float32)
-        return np.maximum(x, np.float32(0)) - a * e
+        r = np.fmax(x, np.float32(0)) - a * e          # (np.fmin / np.fmax: the device's fminf / fmaxf drop a NaN operand)
+        return np.where(x != x, x, r)                   # ... so the NaN is re-attached explicitly
     xs = np.linspace(-12.0, 12.0, 2000001)
     ref = 0.5 * xs * (1.0 + erf(xs / np.sqrt(2.0)))
     got = gelu(xs).astype(np.float64)
@@ -91,3 +92,4 @@ def test_one_exponential_gelu_matches_the_erf_gelu_to_fp32_roundoff():
     assert (np.abs(got - ref)[big] / np.abs(ref)[big]).max() < 2e-4
     ext = gelu(np.array([np.inf, -np.inf, 1e30, -1e30, 0.0, -0.0]))
     assert ext[0] == np.inf and ext[2] == np.float32(1e30) and abs(ext[1]) < 1e-7 and abs(ext[3]) < 1e-7 and ext[4] == 0 and ext[5] == 0
+    assert np.isnan(gelu(np.array([np.nan]))[0]), "an upstream overflow must stay visible (round-5 advisor)"

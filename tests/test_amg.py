@@ -298,7 +298,9 @@ def test_process_many_equals_process_one_at_a_time():
         ne = torch.randn(1, 77, arch.TINY_UNET["context_dim"], generator=g)
         reqs.append(("x", img, False, "a photo", "best quality", "blurry", 2, 128, 128, 4, False, 1.0, 9.0, 3 + r, 0.0, pe, ne))
     want = [demo.process(*r) for r in reqs]
-    for _ in range(2):
+    assert demo.overlap is False, "latency mode is the default (round 6); the two-stream throughput mode is opt-in"
+    for overlap in (True, True, False):
+        demo.overlap = overlap
         got = demo.process_many(reqs)
         assert len(got) == len(want)
         for (go, gp), (wo, wp) in zip(got, want):

@@ -185,6 +185,50 @@ def test_software_pipelined_requests_sharing_one_generator(mg, tiny, kind):
             assert torch.equal(got[r].images, want[r]), f"overlap={overlap} request {r}: rel-L2 {rel_l2(got[r].images, want[r]):.3e}"
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_merged_requests_equal_their_own_calls(mg, tiny, overlap):
+    """serving.PipelinedRunner(merge=2): two consecutive requests evaluated as ONE batched call (batches concatenated; every request
+    keeps its own draws: x_T and the VAE posterior noise come from ITS generator in ITS order, serving.merge_kwargs).  Samples are
+    independent in every network of the path, so each request gets the images its own call gives -- up to fp16 summation order
+    (other M, other split-K plan): rel-L2 <= 2e-3 here, and the 20-step full-size form is held to the oracle in
+    test_pipeline_e2e_batch4_image0_vs_fp32_oracle.  Five requests: two merged pairs + one left over; then a group that cannot be
+    merged (eta > 0 draws noise inside the loop) falls back to one call per request, bit-identical to the plain calls."""
+    from editanything_amd import serving
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
+    ukey, cns, kw0 = mg.pipe_case_kwargs("a_none", mg.pipe_inputs())
+    rng = np.random.default_rng(8)
+    reqs = []
+    for r in range(5):
+        kw = dict(kw0)
+        for k, v in kw0.items():
+            if r and torch.is_tensor(v) and v.is_floating_point() and k not in ("mask_image",):
+                kw[k] = v + 0.05 * r * torch.from_numpy(rng.standard_normal(tuple(v.shape)).astype(np.float32)).to(v.device)
+        if torch.is_tensor(kw.get("image")):
+            kw["image"] = kw["image"].clamp(-1, 1)
+        reqs.append(kw)
+    seq_pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
+    want = [seq_pipe(generator=torch.Generator("cpu").manual_seed(40 + r), **kw).images.clone() for r, kw in enumerate(reqs)]
+    pipe = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
+    runner = serving.PipelinedRunner(pipe, overlap=overlap, merge=2)
+    for rounds in range(2):
+        got = runner.run([dict(kw, generator=torch.Generator("cpu").manual_seed(40 + r)) for r, kw in enumerate(reqs)])
+        torch.cuda.synchronize()
+        assert len(got) == 5
+        for r in range(5):
+            assert got[r].images.shape == want[r].shape
+            e = rel_l2(got[r].images, want[r])
+            assert e <= 2e-3, (rounds, r, e)
+        assert torch.equal(got[4].images, want[4]), "the left-over request runs as its own call"
+    assert len(pipe._graphs) == 2, "one captured step per batch size (merged pair, single request)"
+    ukey2, cns2, kwe = mg.pipe_case_kwargs("a_050_eta", mg.pipe_inputs())
+    pipe_e, seq_e = (_pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey2, cns2, True) for _ in range(2))
+    want_e = [seq_e(generator=torch.Generator("cpu").manual_seed(50 + r), **kwe).images.clone() for r in range(2)]
+    got_e = serving.PipelinedRunner(pipe_e, overlap=overlap, merge=2).run([dict(kwe, generator=torch.Generator("cpu").manual_seed(50 + r)) for r in range(2)])
+    torch.cuda.synchronize()
+    assert all(torch.equal(g.images, w) for g, w in zip(got_e, want_e))
+    runner.close()
+
+
 def test_batched_tile_refinement_vs_the_reference_one_call_per_sample(mg, tiny):
     """editany_lora.py:885-936 refines the samples one pipeline call at a time, every call drawing from the same generator
     (initial latents, then the VAE posterior noise).  tests/golden/pipe_tile.npz holds what the reference's OWN `__call__`
@@ -484,6 +528,17 @@ def test_pipeline_e2e_batch4_image0_vs_fp32_oracle(sd21):
         assert torch.equal(outs[1].images.float().cpu(), lat), f"overlap={overlap}: the runner must not change a request's result"
         assert not torch.equal(outs[0].images.float().cpu(), lat)
         runner.close()
+    # two bs-4 requests merged into ONE network-batch-16 evaluation (serving.PipelinedRunner(merge=2), bench.py `merged`): the
+    # golden's request is the SECOND of the pair (rows 4..7 of the merged batch) and is held to the same bar against the oracle
+    runner = serving.PipelinedRunner(pipe, merge=2)
+    outs = runner.run([_batch4_call(e2e, (5, 6, 7, 8)), _batch4_call(e2e)])
+    torch.cuda.synchronize()
+    mlat = outs[1].images.float().cpu()
+    cos_m = float(torch.nn.functional.cosine_similarity(mlat[0].flatten(), ref.flatten(), dim=0))
+    print(f"e2e C2, two requests merged (network batch 16): image 0 of request 2 latents cosine {cos_m:.6f} vs the oracle, rel-L2 vs its own call {rel_l2(mlat, lat):.3e}")
+    assert mlat.shape == lat.shape and cos_m >= 0.999
+    assert rel_l2(mlat, lat) <= 2e-2, "20 steps of fp16 summation-order differences stay inside the oracle tolerance class"
+    runner.close()
 
 
 def test_sd21_eval_network_batch_8_vs_frozen_oracle(sd21):
