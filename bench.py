@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--loop-priority", choices=["default", "high"], default="default",
                     help="experiment switch: issue the denoising loops on a high-priority stream (the side stream of the "
                          "software pipeline keeps the default priority)")
+    ap.add_argument("--no-merged", action="store_true", help="skip the request-merging measurement (network batch 16)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra single-GPU measurements (process() end-to-end WITH automatic mask generation; "
                          "the fp32-accurate SAM encoder) that are reported beside the headline")
@@ -280,6 +281,29 @@ def main():
                "host_ms_issuing_one_loop": host_ms, "pipelined_timeline_ms": timeline,
                "note": "sequential = SAM -> prepare -> loop -> decode of one batch after the other on one stream; latency = first "
                        "launch of a batch's SAM encode to the end of its VAE decode (device events; steady-state requests)"}
+    # request merging (serving.PipelinedRunner(merge=2)): consecutive bs-4 requests evaluated pairwise as ONE network-batch-16 call --
+    # the same `steps` batches of 4 images, every request with its own draws; reported BESIDE the headline (which stays one bs-4
+    # request per evaluation, BASELINE config 2), one stream and two streams
+    merged = None
+    if runner is not None and not args.quick and not args.no_merged:
+        merged = {"what": "the same bs-4 requests, evaluated two at a time as one batched call (network batch %d); a request's images equal "
+                          "its own call's up to fp16 summation order (tests/test_pipeline_parity.py::test_merged_requests_equal_their_own_calls, "
+                          "::test_pipeline_e2e_batch4_image0_vs_fp32_oracle)" % (4 * args.batch)}
+        k = max(4, args.steps - args.steps % 2)
+        for name, ov in (("one_stream", False), ("two_streams", True)):
+            mr = serving.PipelinedRunner(pipe, overlap=ov, merge=2, threaded=args.pipeline_thread == "on",
+                                         side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority])
+            mr.run([request(args.seed + 4000 + i) for i in range(4)])
+            torch.cuda.synchronize()
+            mr.latency_events = []
+            t1 = time.perf_counter()
+            mr.run([request(args.seed + 4100 + i) for i in range(k)])
+            torch.cuda.synchronize()
+            t_m = (time.perf_counter() - t1) / k
+            lat = [a.elapsed_time(b) for a, b in mr.latency_events]
+            merged[name] = {"value": round(args.batch / t_m, 4), "unit": "images/s", "ms_per_step": round(t_m * 1e3, 2), "steps": k,
+                            "latency_p50_ms": round(float(np.median(lat[1:-1] if len(lat) > 2 else lat)), 2)}
+            mr.close()
     # untimed diagnostic pass: GPU time per phase of one step (events on the launch stream; not part of `value`).
     # pipeline marks: start | inputs+vae_encode | prepare(hint,text kv) | denoise loop | vae_decode
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -329,6 +353,8 @@ def main():
     if seq is not None:
         result["sequential"] = seq
         result["pipelining_gain"] = round(value / world / seq["value"], 4)
+    if merged is not None:
+        result["merged"] = merged
     if rank == 0 and not args.quick:
         result["config"]["calibration"] = calibration(dev)
         result["config"]["value_x_mix_probe_ms"] = round(value / world * result["config"]["calibration"]["mix_probe_ms"], 2)

@@ -129,32 +129,44 @@ def merge_kwargs(pipe, kws):
     ctl = [control(kw) for kw in kws]
     if any(len(c) != len(ctl[0]) or not all(torch.is_tensor(t) and t.dim() == 4 for t in c) for c in ctl):
         return None
-    lats, vns, imgs, msks, sizes = [], [], [], [], []
+    # 1. validate everything; 2. only then draw -- a group that turns out unmergeable must leave every generator untouched (its
+    # requests then run as their own calls and draw for themselves)
+    prepared, sizes = [], []
     for kw, c in zip(kws, ctl):
         b = kw["prompt_embeds"].shape[0]
         n_img = b * nipp
-        if any(t.shape[0] not in (b, n_img) for t in c):
+        if any(t.shape[0] not in (1, n_img) for t in c):
             return None
-        sizes.append(n_img)
         g = kw.get("generator")
-        shape = (n_img, 4, height // 8, width // 8)
-        if isinstance(g, (list, tuple)):                  # one generator per image (pipeline.prepare_latents / _vae_noise rules)
-            if len(g) != n_img:
-                return None
-            draw, g = (lambda: torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g])), g[0]
-        else:
-            draw = lambda: randn_tensor(shape, g, dev)
-        lats.append(kw["latents"].to(dev) if kw.get("latents") is not None else draw())
+        if isinstance(g, (list, tuple)) and len(g) != n_img:
+            return None
+        if kw.get("latents") is not None and tuple(kw["latents"].shape) != (n_img, 4, height // 8, width // 8):
+            return None
+        img = msk = None
         if kw.get("image") is not None:
             img = host.prepare_image(kw["image"])
             msk = host.prepare_mask_image(kw["mask_image"])
-            if img.shape[0] != msk.shape[0] or img.shape[0] not in (b, n_img) or img.shape[-2:] != (height, width) or msk.shape[-2:] != (height, width):
+            if img.shape[0] != msk.shape[0] or img.shape[0] not in (1, n_img) or img.shape[-2:] != (height, width) or msk.shape[-2:] != (height, width):
                 return None
-            vns.append(randn_tensor((img.shape[0], 4, height // 8, width // 8), g, dev))
-            imgs.append(img)
-            msks.append(msk)
-    if imgs and len({(i.shape[0] == n) for i, n in zip(imgs, sizes)}) != 1:
-        return None                                       # rows must repeat the same way in every request
+        prepared.append((img, msk))
+        sizes.append(n_img)
+    rows = lambda t, n: t if t.shape[0] == n else t.expand(n, *t.shape[1:])      # one row for the whole request -> its n rows
+    lats, vns, imgs, msks = [], [], [], []
+    for kw, (img, msk), n_img in zip(kws, prepared, sizes):
+        g = kw.get("generator")
+        shape = (n_img, 4, height // 8, width // 8)
+        if kw.get("latents") is not None:
+            lats.append(kw["latents"].to(dev))
+        elif isinstance(g, (list, tuple)):                # one generator per image (pipeline.prepare_latents / _vae_noise rules)
+            lats.append(torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g]))
+        else:
+            lats.append(randn_tensor(shape, g, dev))
+        if img is not None:
+            g0 = g[0] if isinstance(g, (list, tuple)) else g
+            vns.append(rows(randn_tensor((img.shape[0], 4, height // 8, width // 8), g0, dev), n_img))
+            imgs.append(rows(img, n_img))
+            msks.append(rows(msk, n_img))
+    ctl = [[rows(t, n) for t in c] for c, n in zip(ctl, sizes)]
     cat = lambda ts: torch.cat([t.to(dev) for t in ts])
     out = {k: v for k, v in k0.items() if k in _MERGE_SAME}
     out.update(prompt_embeds=cat([kw["prompt_embeds"] for kw in kws]), latents=cat(lats), generator=None)

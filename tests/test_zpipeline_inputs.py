@@ -191,3 +191,54 @@ def test_load_textual_inversion_adds_tokens_and_rows(tmp_path):
     pipe.tokenizer = None
     with pytest.raises(ValueError):
         pipe.load_textual_inversion(str(tmp_path / "plain.bin"))
+
+
+# ---------------------------------------------------------------------------- serving.merge_kwargs (host-only part)
+def _merge_req(seed, b=2, eta=0.0, img_rows=None, gen_list=False):
+    g = torch.Generator("cpu").manual_seed(1000 + seed)
+    rows = b if img_rows is None else img_rows
+    gens = [torch.Generator("cpu").manual_seed(10 * seed + i) for i in range(b)] if gen_list else torch.Generator("cpu").manual_seed(seed)
+    return dict(prompt_embeds=torch.randn(b, 77, 8, generator=g), negative_prompt_embeds=torch.randn(b, 77, 8, generator=g),
+                image=torch.rand(rows, 3, 64, 64, generator=g) * 2 - 1, mask_image=(torch.rand(rows, 1, 64, 64, generator=g) > 0.5).float(),
+                controlnet_conditioning_image=torch.rand(b, 3, 64, 64, generator=g), height=64, width=64, num_inference_steps=4,
+                guidance_scale=7.5, eta=eta, output_type="latent", generator=gens)
+
+
+def test_merge_kwargs_concatenates_requests_and_keeps_each_request_its_own_draws():
+    """serving.merge_kwargs: N requests -> one batched call whose rows are the requests' rows in order, whose `latents` / `vae_noise`
+    are exactly what each request's own call would draw from ITS generator (x_T first, then the VAE posterior noise:
+    …inpaint.py:1005-1007, 1079-1081; a list of generators = one per image for x_T, the first for the VAE noise); a group that
+    cannot be merged returns None and leaves every generator untouched (its requests then draw for themselves)."""
+    from editanything_amd import serving
+    from editanything_amd.pipeline import randn_tensor
+    pipe = types.SimpleNamespace(unet=types.SimpleNamespace(cfg={"in_channels": 4}), device=torch.device("cpu"))
+    reqs = [_merge_req(1), _merge_req(2, img_rows=1), _merge_req(3, gen_list=True)]
+    merged, sizes = serving.merge_kwargs(pipe, reqs)
+    assert sizes == [2, 2, 2] and merged["generator"] is None and merged["latents"].shape == (6, 4, 8, 8)
+    fresh = [_merge_req(1), _merge_req(2, img_rows=1), _merge_req(3, gen_list=True)]
+    lo = 0
+    for r, kw in enumerate(fresh):
+        g = kw["generator"]
+        if isinstance(g, list):
+            lat = torch.cat([randn_tensor((1, 4, 8, 8), gi, "cpu") for gi in g])
+            vn = randn_tensor((kw["image"].shape[0], 4, 8, 8), g[0], "cpu")
+        else:
+            lat = randn_tensor((2, 4, 8, 8), g, "cpu")
+            vn = randn_tensor((kw["image"].shape[0], 4, 8, 8), g, "cpu")
+        assert torch.equal(merged["latents"][lo:lo + 2], lat), r
+        assert torch.equal(merged["vae_noise"][lo:lo + 2], vn.expand(2, -1, -1, -1)), r
+        assert torch.equal(merged["prompt_embeds"][lo:lo + 2], kw["prompt_embeds"])
+        assert torch.equal(merged["image"][lo:lo + 2], kw["image"].expand(2, -1, -1, -1))
+        assert torch.equal(merged["controlnet_conditioning_image"][lo:lo + 2], kw["controlnet_conditioning_image"])
+        lo += 2
+    # unmergeable groups: None, and no generator has moved
+    for bad in ([_merge_req(1), _merge_req(2, eta=0.3)], [_merge_req(1), dict(_merge_req(2), height=128)],
+                [_merge_req(1), dict(_merge_req(2), prompt="a photo")], [_merge_req(1), _merge_req(2, b=3, img_rows=2)],
+                [_merge_req(1), dict(_merge_req(2), alpha_weight=0.5)], [_merge_req(1)]):
+        before = [kw["generator"].get_state().clone() for kw in bad]
+        assert serving.merge_kwargs(pipe, bad) is None
+        assert all(torch.equal(kw["generator"].get_state(), st) for kw, st in zip(bad, before))
+    assert serving.merge_kwargs(types.SimpleNamespace(unet=types.SimpleNamespace(cfg={"in_channels": 9}), device=torch.device("cpu")),
+                                [_merge_req(1), _merge_req(2)]) is None
+    out = serving.split_output(types.SimpleNamespace(images=torch.arange(6)), [2, 1, 3])
+    assert [o.images.tolist() for o in out] == [[0, 1], [2], [3, 4, 5]]

@@ -4,8 +4,8 @@ configurations in ONE process (same box, same weights, A/B/A by listing a config
 
     python tools/eval_time.py base twin:twin=1 twin+gn:twin=1,gn_next=1 base
 
-A configuration is `name[:key=value,...]`; keys: overlap, share_cfg_prefix, twin (ControlledDenoiser options) and ln_fold,
-gn_epilogue, gn_next (ops.configure).  Prints one JSON line per configuration: ms per evaluation (best and every round of
+A configuration is `name[:key=value,...]`; keys: overlap, share_cfg_prefix, twin (ControlledDenoiser options), ln_fold,
+gn_epilogue, gn_next (ops.configure) and batch (images per evaluation, default 4 -> network batch 8; round 6: the batch sweep).  Prints one JSON line per configuration: ms per evaluation (best and every round of
 10 replays, so a bimodal replay time shows), launches per evaluation are not counted here (rocprofv3 does that).
 """
 import json
@@ -25,24 +25,25 @@ OPS_KEYS = ("ln_fold", "gn_epilogue", "gn_next")
 t0 = time.time()
 un = ControlledUnetModel(arch.SD21_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_UNET), 12), dev)
 cn = ControlNet(arch.SD21_CONTROLNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD21_CONTROLNET, True), 11), dev)
-g = torch.Generator("cpu").manual_seed(0)
-lat = torch.randn(4, 4, 64, 64, generator=g).to(dev)
-hint = (torch.rand(4, 3, 512, 512, generator=g) * 255).to(dev)
-hint = torch.cat([hint, hint])
-ctx = (torch.randn(8, 77, 1024, generator=g) * 0.5).to(dev)
-ts = torch.full((8,), 501, dtype=torch.long, device=dev)
 setup = round(time.time() - t0, 1)
 ref = None
 for spec in (sys.argv[1:] or ["base"]):
     name, _, kv = spec.partition(":")
     opts = {k: v for k, v in (p.split("=") for p in kv.replace("+", ",").split(",") if p)}
+    nimg = int(opts.pop("batch", 4))
+    g = torch.Generator("cpu").manual_seed(0)
+    lat = torch.randn(nimg, 4, 64, 64, generator=g).to(dev)
+    hint = (torch.rand(nimg, 3, 512, 512, generator=g) * 255).to(dev)
+    hint = torch.cat([hint, hint])
+    ctx = (torch.randn(2 * nimg, 77, 1024, generator=g) * 0.5).to(dev)
+    ts = torch.full((2 * nimg,), 501, dtype=torch.long, device=dev)
     ops.CONFIG.ln_fold, ops.CONFIG.gn_epilogue, ops.CONFIG.gn_next = True, True, True
     ops.configure(**{k: int(v) for k, v in opts.items() if k in OPS_KEYS})
     den = ControlledDenoiser(un, [cn], **{k: bool(int(v)) for k, v in opts.items() if k not in OPS_KEYS})
     with torch.no_grad():
         den.prepare(ctx, [hint])
         embs = [e[:1].clone() for e in den.time_embeddings(ts[:1])]
-        assert den.will_share_prefix(8, embs)
+        assert den.will_share_prefix(2 * nimg, embs)
         run = lambda: den.eps(lat, ts, embs=embs, cfg_halves=True, cfg_single=True)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -65,9 +66,9 @@ for spec in (sys.argv[1:] or ["base"]):
             torch.cuda.synchronize()
             rounds.append(round(e0.elapsed_time(e1) / 10, 3))
         o = out.float().clone()
-    if ref is None:
+    if ref is None or ref.shape != o.shape:
         ref = o
-    print(json.dumps({"config": name, "options": opts, "ms_per_eval": min(rounds), "rounds_ms": rounds, "setup_s": setup,
+    print(json.dumps({"config": name, "options": opts, "images": nimg, "ms_per_eval": min(rounds), "ms_per_eval_per_image": round(min(rounds) / nimg, 3), "rounds_ms": rounds, "setup_s": setup,
                       "rel_l2_vs_first_config": round(float((o - ref).norm() / ref.norm()), 6), "finite": bool(torch.isfinite(o).all())}),
           flush=True)
     del graph, den
