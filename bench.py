@@ -382,7 +382,7 @@ MIX_PROBE = [("conv", (8, 8, 1280, 1280), 380), ("conv", (8, 32, 640, 640), 180)
 
 def calibration(dev):
     """What lets a reader normalise `value` for the box it was measured on (boxes of this pool differ by up to 12 % on one
-    build): `mix_probe_ms` = the ten heaviest contraction classes of THIS workload (MIX_PROBE), 20 launches
+    build, profiles/HISTORY.md 8e-2): `mix_probe_ms` = the ten heaviest contraction classes of THIS workload (MIX_PROBE), 20 launches
     each on one stream, summed with their launches-per-step weights -- a step-shaped load, unlike the 4096^3 cube of round 4
     whose ratio to `value` moved by 4-10 % between boxes -- plus a device-to-device copy rate and the clocks /
     power the box reports.  Untimed region; ~0.3 s.  Goes INSIDE `config` (the driver keeps `config`)."""

@@ -7,7 +7,7 @@
 // (ldm/modules/diffusionmodules/model.py:619-652).  Everything else stays on ea_gemm2.h (the planner: ea_gemm.hip
 // gemm8_shape_ok -- measured per class on the MI355X, profiles/r05_gemm8_*).
 //
-// Why another main loop: ea_gemm2's wave tile is 64 x 80 -- 9 fragment reads (ds_read_b128) per 20
+// Why another main loop (profiles/HISTORY.md 8e-1, 10-1): ea_gemm2's wave tile is 64 x 80 -- 9 fragment reads (ds_read_b128) per 20
 // MFMAs, and its compute side tops out at ~1.29 PF/s on LDS read issue alone.  Here a wave owns 128 x 64 outputs (8 x 4
 // MFMA tiles, 128 accumulator registers) and a K tile is cut into FOUR phases, one 64 x 32 accumulator quadrant each:
 // 16 MFMAs (v_mfma_f32_16x16x32_f16) fed by 8 (A) or 4 (B) fragment reads; the B fragments of a quadrant column stay in

@@ -4,7 +4,7 @@ The reference serves one request at a time, strictly in order: SAM image encodin
 (sam2image.py:117-120) -> prompt / control / VAE-encode preparation -> the denoising loop -> VAE decode
 (sam2image.py:154-177; …inpaint.py:1131-1703).  Inside ONE request those stages depend on each other; across requests
 they do not, and on the MI355X the denoising loop leaves the chip under-filled for about half of every ControlNet +
-UNet evaluation (the UNet decoder runs alone: DESIGN.md 8e-2) while SAM / VAE launches are large and chip-filling.
+UNet evaluation (the UNet decoder runs alone: profiles/HISTORY.md 8e-2) while SAM / VAE launches are large and chip-filling.
 `PipelinedRunner` therefore keeps three requests in flight:
 
     caller's stream :  ... | hand-over(i) -> 20 x captured step (i) -> final latents(i) | hand-over(i+1) -> ...

@@ -644,7 +644,7 @@ class ControlledDenoiser:
         # ---- phase 0, on the caller's stream, BEFORE the fork: every network's first convolution (conv_in, 4 input channels: the
         # one layer of an evaluation that the LDS-DMA contraction kernel does not take -- K is not a multiple of 64 -- and that runs
         # on the register-staged generic kernel, whose epilogue is a long VALU burst).  Round 4 found launches of that kernel on one
-        # stream exposing a lost-update bug in the GroupNorm statistics loop of ANOTHER stream sharing the SIMDs (DESIGN.md 8f-1;
+        # stream exposing a lost-update bug in the GroupNorm statistics loop of ANOTHER stream sharing the SIMDs (profiles/HISTORY.md 8f-1;
         # fixed in ea_norm.hip).  Nothing of it was ever seen inside an evaluation, and the loop is fixed; issuing the two launches
         # here simply keeps the one VALU-heavy contraction of an evaluation from ever having a concurrent neighbour (cost: ~10 us).
         for c in ctx:

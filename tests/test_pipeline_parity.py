@@ -108,7 +108,7 @@ def test_software_pipelined_requests_equal_sequential_calls(mg, gold, tiny, over
     (front as a plain kwargs dict and as a callable that runs a SAM encode first), and request 0 still meets the reference
     golden.  overlap=False is the shipped form (the stages of a request in order on the caller's stream); overlap=True runs
     front(i+1) / back(i-1) on a second stream, from a worker thread, underneath loop(i) (serving.py; the full-size stress of that
-    form is tools/diag_pipeline_det.py)."""
+    form is tools/diag_pipeline_det.py, profiles/HISTORY.md 8f-1)."""
     from editanything_amd import serving
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
     from editanything_amd.sam import ImageEncoderViT

@@ -1,6 +1,6 @@
 """`-m gpu` regression tests: every shipped kernel path is BIT-STABLE beside a busy second stream.
 
-History (profiles/r04_pipelined_race.jsonl, profiles/r05_gn_exec_repro.*): a gradio worker pool
+History (profiles/HISTORY.md 8f-1 and 8g-1, profiles/r04_pipelined_race.jsonl, profiles/r05_gn_exec_repro.*): a gradio worker pool
 (sam2image.py:267) puts two streams on one GPU as a matter of course, and round 4 found two kernel bugs that only a busy
 neighbour exposes -- a missing barrier in the d = 64 LDS-DMA attention kernel, and GroupNorm sum-of-squares updates that
 came out wrong in lanes 48..63.  Round 5 traced the second one to the instruction level: on gfx950 a PACKED fp32 VALU

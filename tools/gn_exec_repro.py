@@ -1,4 +1,4 @@
-"""In-chain half of the round-5 reproducer for the GroupNorm statistics loss (the stand-alone half is
+"""In-chain half of the round-5 reproducer for the GroupNorm statistics loss (profiles/HISTORY.md 8f-1; the stand-alone half is
 tools/gn_exec_repro.cpp): ONE ControlNet + UNet evaluation (SD2.1, network batch 8, single-stream form) run N times eagerly and
 N times as a HIP-graph replay beside a thread that streams M = 20 GEMMs (the generic register-staged kernel) on a second
 stream -- once per LIBRARY BUILD: the shipped one and the side builds of tools/build_gn_repro.sh, which differ ONLY in the

@@ -2,7 +2,7 @@
 // (tools/build_gn_repro.sh: -DEA_GN_STATS_LOOP=n; the product is built without the macro and never sees this file).
 // The round-3 form of the statistics loop (per-THREAD bound `px < p_end`): every trip ends with the sum-of-squares updates
 // (v_pk_fma_f32 x3, v_pk_add_f32) directly followed by `s_andn2_b64 exec` -- the form whose lanes 48..63 occasionally lost
-// those last updates beside another stream's generic-kernel launches (profiles/r04_pipelined_race.jsonl).
+// those last updates beside another stream's generic-kernel launches (profiles/HISTORY.md 8f-1, profiles/r04_pipelined_race.jsonl).
 //   EA_GN_STATS_LOOP == 1   the round-3 loop as it shipped
 //   EA_GN_STATS_LOOP == 2   the same with wait states pinned between the last updates and the EXEC update
 //   EA_GN_STATS_LOOP == 3   the same source as 1; the build adds -fno-slp-vectorize (no packed fp32 instructions)
