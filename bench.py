@@ -290,18 +290,22 @@ def main():
                           "its own call's up to fp16 summation order (tests/test_pipeline_parity.py::test_merged_requests_equal_their_own_calls, "
                           "::test_pipeline_e2e_batch4_image0_vs_fp32_oracle)" % (4 * args.batch)}
         k = max(4, args.steps - args.steps % 2)
-        for name, ov in (("one_stream", False), ("two_streams", True)):
-            mr = serving.PipelinedRunner(pipe, overlap=ov, merge=2, threaded=args.pipeline_thread == "on",
+        for name, ov, mg in (("one_stream", False, 2), ("two_streams", True, 2), ("merge4_one_stream", False, 4)):
+            if mg > 2 and args.steps < 8:
+                continue
+            mr = serving.PipelinedRunner(pipe, overlap=ov, merge=mg, threaded=args.pipeline_thread == "on",
                                          side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority])
-            mr.run([request(args.seed + 4000 + i) for i in range(4)])
+            kk = k - k % mg
+            mr.run([request(args.seed + 4000 + i) for i in range(2 * mg)])
             torch.cuda.synchronize()
             mr.latency_events = []
             t1 = time.perf_counter()
-            mr.run([request(args.seed + 4100 + i) for i in range(k)])
+            mr.run([request(args.seed + 4100 + i) for i in range(kk)])
             torch.cuda.synchronize()
-            t_m = (time.perf_counter() - t1) / k
+            t_m = (time.perf_counter() - t1) / kk
             lat = [a.elapsed_time(b) for a, b in mr.latency_events]
-            merged[name] = {"value": round(args.batch / t_m, 4), "unit": "images/s", "ms_per_step": round(t_m * 1e3, 2), "steps": k,
+            merged[name] = {"value": round(args.batch / t_m, 4), "unit": "images/s", "ms_per_step": round(t_m * 1e3, 2), "steps": kk,
+                            "requests_per_call": mg, "network_batch": 2 * mg * args.batch,
                             "latency_p50_ms": round(float(np.median(lat[1:-1] if len(lat) > 2 else lat)), 2)}
             mr.close()
     # untimed diagnostic pass: GPU time per phase of one step (events on the launch stream; not part of `value`).

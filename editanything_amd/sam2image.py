@@ -60,6 +60,9 @@ class Demo:
         # measured +2 % throughput for 2 x the latency of a request (bench.py `sequential` / `latency_p50_ms`) -- the reference is an
         # interactive app, so the default serves one request at a time and a throughput deployment opts in
         self.overlap = False
+        # process_many: that many consecutive requests of one shape are evaluated as ONE batched pipeline call (serving.merge_kwargs;
+        # every request keeps its own seed's draws).  1 = off (default); 2 gives +15 % throughput at 4 images per request
+        self.merge = 1
 
     def _pipe(self, path):
         if path not in self.pipes:
@@ -134,7 +137,8 @@ class Demo:
         (VAE decode).  Returns `process`' return value per request, in order -- the same values `process` gives one request at
         a time, bit for bit.  `Demo.overlap = True` (opt-in, throughput mode) lets the runner overlap the next request's front and
         the previous one's back with the current loop on a second stream; the default keeps the stages of a request in order on
-        one stream (latency mode: a request is finished before the next one starts)."""
+        one stream (latency mode: a request is finished before the next one starts).  `Demo.merge = 2` (opt-in) evaluates two
+        consecutive requests as one batched call: same images up to fp16 summation order, +15 % throughput."""
         from .serving import PipelinedRunner
         reqs = [r if isinstance(r, dict) else dict(zip(self.process.__code__.co_varnames[1:], r)) for r in requests]
         paths = {config_dict.get(r["condition_model"], r["condition_model"]) for r in reqs}
@@ -144,6 +148,7 @@ class Demo:
         runner = self._runners.get((id(pipe), bool(self.overlap)))
         if runner is None:
             runner = self._runners[(id(pipe), bool(self.overlap))] = PipelinedRunner(pipe, overlap=self.overlap)
+        runner.merge = int(self.merge)
         meta = [None] * len(reqs)
 
         def front(i, r):

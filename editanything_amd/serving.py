@@ -86,41 +86,98 @@ def make_stream(device, priority, cu_count=0):
 # split-K factors at other M).  Why: at the benchmark's network batch of 8 the 16 x 16 / 8 x 8 levels have M = 2048 / 512 rows --
 # launches of 15 - 40 us whose fixed part (set-up, epilogue, split-K round trip, partial rounds of the 256 CUs) weighs as much as
 # their K loop; at twice the rows the same fixed part is paid once for two requests (bench.py `batch_sweep`).
-_MERGE_SAME = ("height", "width", "num_inference_steps", "guidance_scale", "num_images_per_prompt", "eta", "output_type",
-               "return_dict", "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs")
-_MERGE_NONE = ("prompt", "negative_prompt", "callback", "controlnet_conditioning_scale_map", "alpha_weight", "ref_image",
-               "ref_mask", "ref_prompt", "ref_prompt_embeds", "control_image")
+_MERGE_SAME = ("height", "width", "num_inference_steps", "guidance_scale", "eta", "output_type", "return_dict",
+               "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs")
+_MERGE_NONE = ("callback", "controlnet_conditioning_scale_map", "alpha_weight", "ref_image", "ref_mask", "ref_prompt",
+               "ref_prompt_embeds", "control_image", "vae_noise", "latents")
+
+
+def _request_geometry(kw):
+    """(prompt batch b, images per prompt, height, width) of a pipeline call, by `front`'s own rules; None when it cannot be told
+    without running the call."""
+    pe, pr = kw.get("prompt_embeds"), kw.get("prompt")
+    if torch.is_tensor(pe) and pe.dim() == 3:
+        b = pe.shape[0]
+    elif isinstance(pr, str):
+        b = 1
+    elif isinstance(pr, (list, tuple)) and all(isinstance(x, str) for x in pr):
+        b = len(pr)
+    else:
+        return None
+    h, w = kw.get("height"), kw.get("width")
+    if h is None or w is None:
+        c = kw.get("controlnet_conditioning_image", kw.get("control_image"))
+        c = c[0] if isinstance(c, (list, tuple)) else c
+        if not torch.is_tensor(c):
+            return None
+        h, w = h or c.shape[-2], w or c.shape[-1]
+    return b, int(kw.get("num_images_per_prompt", 1) or 1), int(h), int(w)
+
+
+def predraw(pipe, kw):
+    """The first two random draws of the call `pipe(**kw)`, made NOW from its generator in the call's own order: the initial
+    latents (`prepare_latents`, …inpaint.py:1005-1007; a list of generators draws one image each) and then, for an inpaint call,
+    the VAE posterior noise (`prepare_masked_image_latents`, :1079-1081; a list uses its first generator).  -> kwargs for the
+    same call with `latents=` / `vae_noise=` filled in -- bit-identical results (tests/test_pipeline_parity.py::
+    test_inpaint_pipeline_explicit_noise_equals_generator_draws), every later draw of the call still comes from its generator --
+    or None when the shapes cannot be told up front (the call then draws for itself).
+    Why: requests of a group may SHARE a generator object (`torch.manual_seed(s)` hands out the global one and the next request's
+    seed re-seeds it, sam2image.py:163-167), so each request's draws are taken the moment its kwargs exist."""
+    from . import host
+    from .pipeline import randn_tensor
+    if kw.get("latents") is not None or kw.get("vae_noise") is not None:
+        return None
+    geo = _request_geometry(kw)
+    if geo is None:
+        return None
+    b, nipp, h, w = geo
+    n_img, g, dev = b * nipp, kw.get("generator"), pipe.device
+    shape = (n_img, 4, h // 8, w // 8)
+    if isinstance(g, (list, tuple)):
+        if len(g) != n_img:
+            return None                                   # (the call itself raises: let it)
+        lat, g0 = torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g]), g[0]
+    else:
+        lat, g0 = randn_tensor(shape, g, dev), g
+    out = dict(kw, latents=lat)
+    if kw.get("image") is not None:
+        rows = host.prepare_image(kw["image"]).shape[0]
+        out["vae_noise"] = randn_tensor((rows, 4, h // 8, w // 8), g0, dev)
+    return out
+
+
+def mergeable_alone(kw):
+    """Could this call be a block of rows of a merged call?  (No per-call state, no random draw beyond x_T / VAE noise.)"""
+    return not any(kw.get(k) is not None for k in _MERGE_NONE) and kw.get("eta", 0.0) == 0.0 and _request_geometry(kw) is not None
 
 
 def merge_kwargs(pipe, kws):
-    """ONE kwargs dict that evaluates the pipeline calls `kws` (a list of kwargs dicts) as a single batched call, or None when
-    they cannot be merged (different sizes / step counts / scales, string prompts, reference-only control, mixing, eta > 0,
-    callbacks, a 9-channel inpainting UNet: anything whose per-call state is not a row of a batch).  Every request keeps ITS
-    random draws: the initial latents and the VAE posterior noise are drawn here from the request's own generator, in the
-    order its own call would draw them (…inpaint.py:1005-1007 then :1079-1081), and handed over as `latents=` / `vae_noise=`.
-    -> (merged kwargs, [images per request])."""
+    """ONE kwargs dict that evaluates the PRE-DRAWN pipeline calls `kws` (`predraw` outputs) as a single batched call, or None when
+    they cannot be merged (different sizes / step counts / scales, reference-only control, mixing, eta > 0, callbacks, a
+    9-channel inpainting UNet, string prompts without a text encoder: anything whose per-call state is not a row of a batch).
+    The merged call has one row per IMAGE (num_images_per_prompt = 1): a request of b prompts x n images contributes b * n rows in
+    the pipeline's own order (prompt-major, `_encode_prompt`'s repeat / `_prepare_cond_image`'s repeat_interleave), its latents
+    and VAE noise are its own draws.  -> (merged kwargs, [rows per request])."""
     from . import host
-    from .pipeline import randn_tensor
     if len(kws) < 2:
         return None
     k0 = kws[0]
     for kw in kws:
-        if any(kw.get(k) is not None for k in _MERGE_NONE) or kw.get("eta", 0.0) != 0.0 or kw.get("vae_noise") is not None:
+        if kw is None or kw.get("latents") is None:
+            return None
+        if any(kw.get(k) is not None for k in _MERGE_NONE if k not in ("latents", "vae_noise")) or kw.get("eta", 0.0) != 0.0:
             return None
         if any(kw.get(k) != k0.get(k) for k in _MERGE_SAME):
-            return None
-        if not torch.is_tensor(kw.get("prompt_embeds")) or (kw.get("negative_prompt_embeds") is None) != (k0.get("negative_prompt_embeds") is None):
             return None
         if (kw.get("image") is None) != (k0.get("image") is None):
             return None
     if pipe.unet.cfg["in_channels"] != 4 and k0.get("image") is not None:
         return None
-    height, width = k0.get("height"), k0.get("width")
-    if height is None or width is None:
+    geos = [_request_geometry(kw) for kw in kws]
+    if any(g is None or g[2:] != geos[0][2:] for g in geos):
         return None
-    nipp = int(k0.get("num_images_per_prompt", 1) or 1)
-    if nipp != 1:
-        return None                                       # (rows of one prompt are tiled per call: keep the merge to plain batches)
+    height, width = geos[0][2:]
+    do_cfg = float(k0.get("guidance_scale", 7.5)) > 1.0
     dev = pipe.device
 
     def control(kw):
@@ -129,53 +186,67 @@ def merge_kwargs(pipe, kws):
     ctl = [control(kw) for kw in kws]
     if any(len(c) != len(ctl[0]) or not all(torch.is_tensor(t) and t.dim() == 4 for t in c) for c in ctl):
         return None
-    # 1. validate everything; 2. only then draw -- a group that turns out unmergeable must leave every generator untouched (its
-    # requests then run as their own calls and draw for themselves)
-    prepared, sizes = [], []
-    for kw, c in zip(kws, ctl):
-        b = kw["prompt_embeds"].shape[0]
+
+    def rows(t, b, nipp):
+        """[1 | b | b * nipp rows] -> b * nipp rows in prompt-major order."""
+        n = b * nipp
+        if t.shape[0] == n:
+            return t
+        if t.shape[0] == 1:
+            return t.expand(n, *t.shape[1:])
+        return t.repeat_interleave(nipp, dim=0) if t.shape[0] == b else None
+
+    parts = dict(pe=[], ne=[], lat=[], img=[], msk=[], vn=[], ctl=[[] for _ in ctl[0]])
+    sizes = []
+    for kw, c, (b, nipp, _, _) in zip(kws, ctl, geos):
         n_img = b * nipp
-        if any(t.shape[0] not in (1, n_img) for t in c):
-            return None
-        g = kw.get("generator")
-        if isinstance(g, (list, tuple)) and len(g) != n_img:
-            return None
-        if kw.get("latents") is not None and tuple(kw["latents"].shape) != (n_img, 4, height // 8, width // 8):
-            return None
-        img = msk = None
-        if kw.get("image") is not None:
-            img = host.prepare_image(kw["image"])
-            msk = host.prepare_mask_image(kw["mask_image"])
-            if img.shape[0] != msk.shape[0] or img.shape[0] not in (1, n_img) or img.shape[-2:] != (height, width) or msk.shape[-2:] != (height, width):
+        pe, ne = kw.get("prompt_embeds"), kw.get("negative_prompt_embeds")
+        if pe is None:
+            if getattr(pipe, "text_encoder", None) is None:
                 return None
-        prepared.append((img, msk))
+            pr = kw["prompt"]
+            prompts = [pr] if isinstance(pr, str) else list(pr)
+            pe = pipe._encode_text(prompts)
+            if do_cfg and ne is None:                     # pipeline._encode_prompt's rule for the negative prompt
+                neg = kw.get("negative_prompt") if kw.get("negative_prompt") is not None else ""
+                negs = [neg] * len(prompts) if isinstance(neg, str) else list(neg)
+                if len(negs) != len(prompts):
+                    return None
+                ne = pipe._encode_text(negs)
+        elif kw.get("prompt") is not None:
+            return None                                   # (check_inputs refuses both: let the call raise)
+        if do_cfg and ne is None:
+            return None
+        if tuple(kw["latents"].shape) != (n_img, 4, height // 8, width // 8):
+            return None
+        parts["pe"].append(rows(pe, b, nipp))
+        if do_cfg:
+            parts["ne"].append(rows(ne, b, nipp))
+        parts["lat"].append(kw["latents"])
+        for j, t in enumerate(c):
+            r = rows(t, b, nipp)
+            if r is None:
+                return None
+            parts["ctl"][j].append(r)
+        if kw.get("image") is not None:
+            img, msk, vn = host.prepare_image(kw["image"]), host.prepare_mask_image(kw["mask_image"]), kw.get("vae_noise")
+            if vn is None or img.shape[0] != msk.shape[0] or vn.shape[0] != img.shape[0] or img.shape[-2:] != (height, width) \
+                    or msk.shape[-2:] != (height, width) or (img.shape[0] not in (1, n_img) and not (nipp == 1 and img.shape[0] == b)):
+                return None                               # (b images x n per prompt: `front` TILES the encoded batch; keep out)
+            parts["img"].append(rows(img, b, nipp))
+            parts["msk"].append(rows(msk, b, nipp))
+            parts["vn"].append(rows(vn, b, nipp))
         sizes.append(n_img)
-    rows = lambda t, n: t if t.shape[0] == n else t.expand(n, *t.shape[1:])      # one row for the whole request -> its n rows
-    lats, vns, imgs, msks = [], [], [], []
-    for kw, (img, msk), n_img in zip(kws, prepared, sizes):
-        g = kw.get("generator")
-        shape = (n_img, 4, height // 8, width // 8)
-        if kw.get("latents") is not None:
-            lats.append(kw["latents"].to(dev))
-        elif isinstance(g, (list, tuple)):                # one generator per image (pipeline.prepare_latents / _vae_noise rules)
-            lats.append(torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g]))
-        else:
-            lats.append(randn_tensor(shape, g, dev))
-        if img is not None:
-            g0 = g[0] if isinstance(g, (list, tuple)) else g
-            vns.append(rows(randn_tensor((img.shape[0], 4, height // 8, width // 8), g0, dev), n_img))
-            imgs.append(rows(img, n_img))
-            msks.append(rows(msk, n_img))
-    ctl = [[rows(t, n) for t in c] for c, n in zip(ctl, sizes)]
     cat = lambda ts: torch.cat([t.to(dev) for t in ts])
     out = {k: v for k, v in k0.items() if k in _MERGE_SAME}
-    out.update(prompt_embeds=cat([kw["prompt_embeds"] for kw in kws]), latents=cat(lats), generator=None)
-    if k0.get("negative_prompt_embeds") is not None:
-        out["negative_prompt_embeds"] = cat([kw["negative_prompt_embeds"] for kw in kws])
-    merged_ctl = [cat([c[j] for c in ctl]) for j in range(len(ctl[0]))]
+    out.update(height=height, width=width, num_images_per_prompt=1, prompt_embeds=cat(parts["pe"]), latents=cat(parts["lat"]),
+               generator=None)
+    if do_cfg:
+        out["negative_prompt_embeds"] = cat(parts["ne"])
+    merged_ctl = [cat(c) for c in parts["ctl"]]
     out["controlnet_conditioning_image"] = merged_ctl if isinstance(k0.get("controlnet_conditioning_image"), (list, tuple)) else merged_ctl[0]
-    if imgs:
-        out.update(image=cat(imgs), mask_image=cat(msks), vae_noise=cat(vns))
+    if parts["img"]:
+        out.update(image=cat(parts["img"]), mask_image=cat(parts["msk"]), vae_noise=cat(parts["vn"]))
     return out, sizes
 
 
@@ -282,11 +353,37 @@ class PipelinedRunner:
         return self._on_side(fn)
 
     def _front_calls(self, group):
-        kws = [r() if callable(r) else r for r in group]
-        merged = merge_kwargs(self.pipe, kws) if len(kws) > 1 else None
-        if merged is not None:
-            return [self.pipe.front(**merged[0])], [merged[1]]
-        return [self.pipe.front(**kw) for kw in kws], [None] * len(kws)
+        """front() of a unit -> (calls, rows-per-request list or None per call), request order kept.  A request that could be a
+        row block of a merged call (no draws beyond x_T / VAE noise, no per-call state: `mergeable_alone`) has those draws taken
+        the moment its kwargs exist (`predraw`) -- the next request's preparation may re-seed a generator object they share
+        (sam2image.py:163-167 seeds the GLOBAL one) -- and waits for its neighbours; any other request runs its own front() right
+        there, in order, exactly as the one-at-a-time path would."""
+        if len(group) == 1:
+            r = group[0]
+            return [self.pipe.front(**(r() if callable(r) else r))], [None]
+        calls, sizes, pending = [], [], []
+
+        def flush():
+            merged = merge_kwargs(self.pipe, pending) if len(pending) > 1 else None
+            if merged is not None:
+                calls.append(self.pipe.front(**merged[0]))
+                sizes.append(merged[1])
+            else:
+                for kw in pending:                        # own calls on their own (already drawn) noise: bit-identical to plain calls
+                    calls.append(self.pipe.front(**kw))
+                    sizes.append(None)
+            del pending[:]
+        for r in group:
+            kw = r() if callable(r) else r
+            pd = predraw(self.pipe, kw) if mergeable_alone(kw) else None
+            if pd is None:
+                flush()
+                calls.append(self.pipe.front(**kw))
+                sizes.append(None)
+            else:
+                pending.append(pd)
+        flush()
+        return calls, sizes
 
     def _finish(self, calls, sizes):
         """back() of a unit's calls -> the per-REQUEST outputs, in order."""

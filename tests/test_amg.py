@@ -307,6 +307,17 @@ def test_process_many_equals_process_one_at_a_time():
             assert gp == wp and len(go) == len(wo) == 3
             for a, b in zip(go[1:], wo[1:]):          # ([0] is show_anns' randomly coloured visualisation, sam2image.py:101-106)
                 assert np.array_equal(np.asarray(a), np.asarray(b))
+    # merged pairs (Demo.merge = 2): the reference's seeding re-seeds the GLOBAL generator per request (sam2image.py:163-167) and
+    # asks for num_samples images of ONE prompt -- each request must still get its own seed's images (fp16 summation-order tolerance)
+    demo.merge = 2
+    for overlap in (False, True):
+        demo.overlap = overlap
+        got = demo.process_many(reqs)
+        for r, ((go, gp), (wo, wp)) in enumerate(zip(got, want)):
+            assert gp == wp and len(go) == len(wo) == 3
+            for a, b in zip(go[1:], wo[1:]):
+                d = np.abs(np.asarray(a).astype(np.float32) - np.asarray(b).astype(np.float32))
+                assert d.mean() <= 1.0 and np.percentile(d, 99) <= 6, (overlap, r, float(d.mean()), float(d.max()))   # uint8 images
 
 
 @gpu

@@ -205,16 +205,18 @@ def _merge_req(seed, b=2, eta=0.0, img_rows=None, gen_list=False):
 
 
 def test_merge_kwargs_concatenates_requests_and_keeps_each_request_its_own_draws():
-    """serving.merge_kwargs: N requests -> one batched call whose rows are the requests' rows in order, whose `latents` / `vae_noise`
-    are exactly what each request's own call would draw from ITS generator (x_T first, then the VAE posterior noise:
-    …inpaint.py:1005-1007, 1079-1081; a list of generators = one per image for x_T, the first for the VAE noise); a group that
-    cannot be merged returns None and leaves every generator untouched (its requests then draw for themselves)."""
+    """serving.predraw + merge_kwargs: N requests -> one batched call whose rows are the requests' rows in order, whose `latents` /
+    `vae_noise` are exactly what each request's own call would draw from ITS generator (x_T first, then the VAE posterior noise:
+    …inpaint.py:1005-1007, 1079-1081; a list of generators = one per image for x_T, the first for the VAE noise) -- taken the
+    moment the request's kwargs exist, so a generator object the NEXT request re-seeds (torch.manual_seed: sam2image.py:163-167)
+    cannot disturb them; num_images_per_prompt > 1 expands prompt-major; a group that cannot be merged returns None."""
     from editanything_amd import serving
     from editanything_amd.pipeline import randn_tensor
-    pipe = types.SimpleNamespace(unet=types.SimpleNamespace(cfg={"in_channels": 4}), device=torch.device("cpu"))
+    pipe = types.SimpleNamespace(unet=types.SimpleNamespace(cfg={"in_channels": 4}), device=torch.device("cpu"), text_encoder=None)
     reqs = [_merge_req(1), _merge_req(2, img_rows=1), _merge_req(3, gen_list=True)]
-    merged, sizes = serving.merge_kwargs(pipe, reqs)
-    assert sizes == [2, 2, 2] and merged["generator"] is None and merged["latents"].shape == (6, 4, 8, 8)
+    drawn = [serving.predraw(pipe, kw) for kw in reqs]
+    merged, sizes = serving.merge_kwargs(pipe, drawn)
+    assert sizes == [2, 2, 2] and merged["generator"] is None and merged["latents"].shape == (6, 4, 8, 8) and merged["num_images_per_prompt"] == 1
     fresh = [_merge_req(1), _merge_req(2, img_rows=1), _merge_req(3, gen_list=True)]
     lo = 0
     for r, kw in enumerate(fresh):
@@ -225,20 +227,40 @@ def test_merge_kwargs_concatenates_requests_and_keeps_each_request_its_own_draws
         else:
             lat = randn_tensor((2, 4, 8, 8), g, "cpu")
             vn = randn_tensor((kw["image"].shape[0], 4, 8, 8), g, "cpu")
+        assert torch.equal(drawn[r]["latents"], lat) and torch.equal(drawn[r]["vae_noise"], vn), r     # own-call form: own shapes
         assert torch.equal(merged["latents"][lo:lo + 2], lat), r
         assert torch.equal(merged["vae_noise"][lo:lo + 2], vn.expand(2, -1, -1, -1)), r
         assert torch.equal(merged["prompt_embeds"][lo:lo + 2], kw["prompt_embeds"])
         assert torch.equal(merged["image"][lo:lo + 2], kw["image"].expand(2, -1, -1, -1))
         assert torch.equal(merged["controlnet_conditioning_image"][lo:lo + 2], kw["controlnet_conditioning_image"])
         lo += 2
-    # unmergeable groups: None, and no generator has moved
-    for bad in ([_merge_req(1), _merge_req(2, eta=0.3)], [_merge_req(1), dict(_merge_req(2), height=128)],
-                [_merge_req(1), dict(_merge_req(2), prompt="a photo")], [_merge_req(1), _merge_req(2, b=3, img_rows=2)],
-                [_merge_req(1), dict(_merge_req(2), alpha_weight=0.5)], [_merge_req(1)]):
-        before = [kw["generator"].get_state().clone() for kw in bad]
-        assert serving.merge_kwargs(pipe, bad) is None
-        assert all(torch.equal(kw["generator"].get_state(), st) for kw, st in zip(bad, before))
+    # the reference's seeding: every request re-seeds the GLOBAL generator; draws taken per request are the sequential ones
+    kws = []
+    for seed in (5, 6):
+        kw = dict(_merge_req(seed), generator=torch.manual_seed(seed))
+        kws.append(serving.predraw(pipe, kw))
+    for seed, d in zip((5, 6), kws):
+        assert torch.equal(d["latents"], randn_tensor((2, 4, 8, 8), torch.manual_seed(seed), "cpu"))
+    # num_images_per_prompt = 3, one prompt / one control / one image per request (sam2image.process's form): prompt-major rows
+    nip = [dict(_merge_req(s, b=1), num_images_per_prompt=3) for s in (7, 8)]
+    m2, sz2 = serving.merge_kwargs(pipe, [serving.predraw(pipe, kw) for kw in nip])
+    assert sz2 == [3, 3] and m2["prompt_embeds"].shape[0] == 6 and m2["image"].shape[0] == 6 and m2["latents"].shape[0] == 6
+    assert torch.equal(m2["prompt_embeds"][3:], nip[1]["prompt_embeds"].expand(3, -1, -1))
+    # string prompts need the pipeline's text encoder
+    txt = [dict(_merge_req(s), prompt=["a", "b"], prompt_embeds=None, negative_prompt_embeds=None) for s in (1, 2)]
+    assert serving.merge_kwargs(pipe, [serving.predraw(pipe, kw) for kw in txt]) is None
+    enc = types.SimpleNamespace(unet=pipe.unet, device=pipe.device, text_encoder=object(),
+                                _encode_text=lambda ps: torch.stack([torch.full((77, 8), float(len(p_))) for p_ in ps]))
+    m3, _ = serving.merge_kwargs(enc, [serving.predraw(enc, kw) for kw in txt])
+    assert m3["prompt_embeds"].shape == (4, 77, 8) and float(m3["negative_prompt_embeds"].abs().max()) == 0.0   # "" -> length 0
+    # unmergeable: alone (eta, mixing, reference-only ... : no predraw at all -> generator untouched) or as a group
+    for kw in (_merge_req(2, eta=0.3), dict(_merge_req(2), alpha_weight=0.5), dict(_merge_req(2), ref_image=object())):
+        assert not serving.mergeable_alone(kw)
+    assert serving.mergeable_alone(_merge_req(1))
+    for bad in ([_merge_req(1), dict(_merge_req(2), height=128, width=128)], [_merge_req(1), dict(_merge_req(2), num_inference_steps=5)],
+                [_merge_req(1), _merge_req(2, b=3, img_rows=2)], [_merge_req(1)]):
+        assert serving.merge_kwargs(pipe, [serving.predraw(pipe, kw) for kw in bad]) is None
     assert serving.merge_kwargs(types.SimpleNamespace(unet=types.SimpleNamespace(cfg={"in_channels": 9}), device=torch.device("cpu")),
-                                [_merge_req(1), _merge_req(2)]) is None
+                                [serving.predraw(pipe, kw) for kw in (_merge_req(1), _merge_req(2))]) is None
     out = serving.split_output(types.SimpleNamespace(images=torch.arange(6)), [2, 1, 3])
     assert [o.images.tolist() for o in out] == [[0, 1], [2], [3, 4, 5]]
