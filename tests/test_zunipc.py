@@ -186,3 +186,35 @@ def test_gpu_pipeline_with_unipc_graph_equals_eager_and_blends():
     out = pipes[False](image=img, mask_image=Image.fromarray(mask), alignment_ratio=0.9,
                        generator=torch.Generator().manual_seed(3), **kw).images
     assert not torch.isnan(out).any() and float(out.abs().max()) < 1e3
+
+
+@pytest.mark.parametrize("n", [10, 20, 50])
+def test_predictor_equals_the_reference_trees_dpm_solver_pp(n):
+    """The PREDICTOR half is pinned to the reference tree: UniP-1 / UniP-2 with B(h) = e^h - 1 are the multistep DPM-Solver++ updates
+    of the same order, and `ldm/models/diffusion/dpm_solver/dpm_solver.py` (the DPM-Solver authors' implementation, in the reference
+    tree) executed from source gives the coefficients frozen in tests/golden/unipc_predictor_dpmpp.npz (oracle/make_golden_unipc.py):
+    every step of the 10 / 20 / 50-step grids -- warm-up step and `lower_order_final` last step at order 1, order 2 in between --
+    agrees to 1e-6 (the reference keeps its time grid in float32).  The corrector has no counterpart there: property tests only."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unipc_predictor_dpmpp.npz"))
+    s = make(n)
+    assert np.array_equal(np.asarray(s.timesteps), g[f"timesteps_{n}"])
+    want = g[f"coef_{n}"]
+    got = np.asarray([s.step_coefficients(i)[1] for i in range(n)])
+    assert got.shape == want.shape == (n, 3)
+    assert np.abs(got - want).max() <= 1e-6 * np.abs(want).max()
+    assert want[0, 2] == 0 and want[-1, 2] == 0 and (want[1:-1, 2] != 0).all()
+    # ... and the tensor form takes the same step: one order-2 predictor step through `step()` with the corrector off
+    s2 = make(n, disable_corrector=tuple(range(n)))
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 8, 8, generator=gen, dtype=torch.float64)
+    for i in range(3):
+        eps = torch.randn(1, 4, 8, 8, generator=gen, dtype=torch.float64)
+        t = int(s2.timesteps[i])
+        m_t = s2.convert_model_output(eps, t, x)
+        if i == 2:
+            c_x, c_m0, c_m1 = want[2]
+            ref = c_x * x + c_m0 * m_t + c_m1 * m_prev
+            assert torch.allclose(s2.step(eps, t, x).prev_sample, ref, rtol=1e-5, atol=1e-5)      # (x0 predictions are ~50 at alpha_t = 0.07; the golden carries the reference's float32 time grid)
+            break
+        x, m_prev = s2.step(eps, t, x).prev_sample, m_t
