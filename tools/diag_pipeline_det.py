@@ -68,7 +68,7 @@ with torch.no_grad():
     out["plain_call2_vs_runner_first"] = d(q, b3[0].images)
     # stage by stage: what `front` prepares on the side stream (worker thread) against the same on the caller's stream
     r = serving.PipelinedRunner(pipe, overlap=True, threaded=True)
-    c_side, _ = r._front(call(1)).result()
+    (c_side,), _, _ = r._front([call(1)]).result()
     torch.cuda.synchronize()
     c_main = pipe.front(**call(1))
     torch.cuda.synchronize()
@@ -109,25 +109,47 @@ if opts.get("stress"):
             r = serving.PipelinedRunner(pipe, overlap=True, threaded="unthreaded" not in mode, side_priority=None if "torchstream" in mode else (0 if "prio0" in mode else (-1 if "priohigh" in mode else 1)))
             if "front_on_main" in mode:       # only the decode of the previous request overlaps the loop
                 orig_front = r._front
-                def front_main(req, after=None, _o=orig_front):
+                def front_main(group, after=None, _o=orig_front):
                     import concurrent.futures
                     f = concurrent.futures.Future()
-                    kw = req() if callable(req) else req
-                    c_ = pipe.front(**kw)
-                    c_._t0, c_._req = None, id(req)
+                    calls, sizes = r._front_calls(group)
+                    for c_ in calls:
+                        c_._t0, c_._req = None, id(group[0])
                     ev = torch.cuda.Event(); ev.record()
-                    f.set_result((c_, ev))
+                    f.set_result((calls, sizes, ev))
                     return f
                 r._front = front_main
             if "back_on_main" in mode:        # only the front of the next request overlaps the loop
-                def back_main(call_, ev_loop, consumer):
+                def back_main(calls, sizes, ev_loop, consumer):
                     import concurrent.futures
                     f = concurrent.futures.Future()
-                    f.set_result(pipe.back(call_))
+                    f.set_result(r._finish(calls, sizes))
                     return f
                 r._back = back_main
             ctx = torch.cuda.stream(torch.cuda.Stream()) if "nonnull" in mode else contextlib.nullcontext()
             bad = []
+            if "merge2" in mode:
+                # round 6: requests evaluated two at a time as one batched call (serving.merge_kwargs), overlapped or not -- the
+                # merged results must be run-to-run BIT-identical and within the fp16 summation-order tolerance of the plain calls
+                r.close()
+                r = serving.PipelinedRunner(pipe, overlap="nooverlap" not in mode, merge=2)
+                first, worst = None, 0.0
+                for it in range(int(opts["stress"])):
+                    o = r.run([call(2), call(1), call(3), call(1)])
+                    torch.cuda.synchronize()
+                    imgs = [x.images.clone() for x in o]
+                    if first is None:
+                        first = imgs
+                        rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+                        worst = max(rel(imgs[0], ref[2]), rel(imgs[1], ref[1]), rel(imgs[2], ref[3]), rel(imgs[3], ref[1]))
+                    ds = [d(a, b) for a, b in zip(imgs, first)]
+                    if max(ds) > 0:
+                        bad.append((it, [round(x, 4) for x in ds]))
+                print(json.dumps({"mode": mode, "stress_runs": int(opts["stress"]), "requests_per_run": 4, "runs_that_differ_from_the_first_run": len(bad),
+                                  "first": bad[:4], "max_rel_l2_vs_the_plain_calls": round(worst, 5), "sam_on_side_stream": bool(opts.get("sam")),
+                                  "sam_encodes": len(sam_flags), "sam_embeddings_that_differ": int(sum(int(f) for f in sam_flags))}), flush=True)
+                r.close()
+                continue
             with ctx:
                 for it in range(int(opts["stress"])):
                     o = r.run([call(2), call(1), call(3)])
