@@ -285,7 +285,7 @@ def main():
     # the same `steps` batches of 4 images, every request with its own draws; reported BESIDE the headline (which stays one bs-4
     # request per evaluation, BASELINE config 2), one stream and two streams
     merged = None
-    if runner is not None and not args.quick and not args.no_merged:
+    if runner is not None and not args.quick and not args.no_merged and world == 1:
         merged = {"what": "the same bs-4 requests, evaluated two at a time as one batched call (network batch %d); a request's images equal "
                           "its own call's up to fp16 summation order (tests/test_pipeline_parity.py::test_merged_requests_equal_their_own_calls, "
                           "::test_pipeline_e2e_batch4_image0_vs_fp32_oracle)" % (4 * args.batch)}
