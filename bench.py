@@ -59,6 +59,7 @@ def parse():
                     help="experiment switch: issue the denoising loops on a high-priority stream (the side stream of the "
                          "software pipeline keeps the default priority)")
     ap.add_argument("--no-merged", action="store_true", help="skip the request-merging measurement (network batch 16)")
+    ap.add_argument("--merged-modes", default="one_stream,two_streams", help="which merged modes to measure (diagnostics)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the two extra single-GPU measurements (process() end-to-end WITH automatic mask generation; "
                          "the fp32-accurate SAM encoder) that are reported beside the headline")
@@ -292,6 +293,8 @@ def main():
         k = max(4, args.steps - args.steps % 2)
         # (four requests per call -- network batch 32 -- measured no better than two: 12.71 vs 13.60 images/s, profiles/r06_bench_line_box3.json)
         for name, ov, mg in (("one_stream", False, 2), ("two_streams", True, 2)):
+            if name not in args.merged_modes.split(","):
+                continue
             mr = serving.PipelinedRunner(pipe, overlap=ov, merge=mg, threaded=args.pipeline_thread == "on",
                                          side_priority={"torch": None, "low": 1, "normal": 0, "high": -1}[args.side_priority])
             kk = k - k % mg
@@ -665,13 +668,17 @@ def other_configs(args, dev, sds, pipe, sam):
         c[0, 0], c[0, 1] = ids % 256, ids // 256
         return torch.from_numpy(c).to(dev)
 
+    rep_ms = []
+
     def timed(fn, reps=2):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
+            t1 = time.perf_counter()
             fn()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            rep_ms.append(round((time.perf_counter() - t1) * 1e3, 1))
         return (time.perf_counter() - t0) / reps
 
     def device_decode(p):
@@ -695,6 +702,42 @@ def other_configs(args, dev, sds, pipe, sam):
     out["c5"] = dict({"metric": "1024^2 images/s per GPU: SAM vit_h encode + SD2.1 ControlNet inpaint, 128 x 128 latents, 50 DDIM steps, CFG 7.5, bs 1",
                       "value": round(1.0 / t5, 4), "unit": "images/s", "ms_per_step": round(t5 * 1e3, 2)},
                      **contraction_summary(step5, [pipe]))
+    # where one such call's time goes: device time of the loop (pipeline marks) against the HOST time spent issuing it -- at network
+    # batch 2 a step's ~1000 graph nodes can take the host as long to submit as the device to run
+    pipe.trace = []
+    orig_loop, host = pipe.loop, []
+
+    def timed_loop(c_):
+        t1 = time.perf_counter()
+        orig_loop(c_)
+        host.append((time.perf_counter() - t1) * 1e3)
+    pipe.loop = timed_loop
+    try:
+        step5()
+        torch.cuda.synchronize()
+    finally:
+        pipe.loop = orig_loop
+    marks, pipe.trace = dict(pipe.trace), None
+    out["c5"]["loop_device_ms"] = round(marks["prepare(hint,text kv)"].elapsed_time(marks["denoise loop"]), 1)
+    out["c5"]["loop_host_issue_ms"] = round(host[0], 1)
+    if not args.no_merged:
+        # the same bs-1 requests, two per call (serving.PipelinedRunner(merge=2): network batch 4, every request its own seed's draws)
+        from editanything_amd import serving
+
+        def req5(seed):
+            def make():
+                sam_encode(img5)
+                return dict(prompt_embeds=e5, negative_prompt_embeds=n5, image=init5, mask_image=mask5, controlnet_conditioning_image=ctrl5,
+                            height=res, width=res, num_inference_steps=50, guidance_scale=7.5, num_images_per_prompt=1,
+                            generator=torch.Generator("cpu").manual_seed(seed), output_type="np_device")
+            return make
+        mr = serving.PipelinedRunner(pipe, merge=2)
+        t5m = timed(lambda: mr.run([req5(args.seed + 50), req5(args.seed + 51)]), reps=1) / 2
+        out["c5"]["merged2"] = {"value": round(1.0 / t5m, 4), "unit": "images/s", "ms_per_image": round(t5m * 1e3, 2), "network_batch": 4,
+                                "vs_one_request_per_call": round(t5 / t5m, 4)}
+        for k in [k for k in pipe._graphs if k[3] == res and k[2] == 2]:
+            del pipe._graphs[k]
+        torch.cuda.empty_cache()
     # ---- c4: SD1.5, two ControlNets + tile refinement, 768^2
     res = 768
     un = ControlledUnetModel(arch.SD15_UNET, synth.synth_state_dict_torch(arch.unet_param_shapes(arch.SD15_UNET), args.seed + 31), dev)
@@ -727,8 +770,32 @@ def other_configs(args, dev, sds, pipe, sam):
     out["c4"] = dict({"metric": "768^2 images/s per GPU: SAM vit_h encode + SD1.5 two-ControlNet mixing inpaint (20 steps) + tile-ControlNet refinement (20 steps), CFG 7.5, bs 1",
                       "value": round(1.0 / t4, 4), "unit": "images/s", "ms_per_step": round(t4 * 1e3, 2)},
                      **contraction_summary(step4, [pipe_a, pipe_t]))
+    if not args.no_merged:
+        # the same bs-1 requests, two per call in BOTH stages (network batch 4): the mixing stage's per-step re-noise is drawn per
+        # request and handed over (serving.predraw `loop_noise=`), the refinement stage of a request still starts from ITS stage-1 image
+        from editanything_amd import serving
+        ra, rt = serving.PipelinedRunner(pipe_a, merge=2), serving.PipelinedRunner(pipe_t, merge=2)
+
+        def step4m():
+            gens = [torch.Generator("cpu").manual_seed(args.seed + 40 + i) for i in range(2)]
+
+            def req_a(gen):
+                def make():
+                    sam_encode(img4)
+                    return dict(prompt_embeds=e4, negative_prompt_embeds=n4, image=init4, mask_image=mask4, controlnet_conditioning_image=[ctrl4, inp_cond],
+                                controlnet_conditioning_scale=[1.0, 1.0], height=res, width=res, num_inference_steps=20, guidance_scale=7.5,
+                                num_images_per_prompt=1, generator=gen, alpha_weight=0.5, alignment_ratio=0.95, output_type="np_device")
+                return make
+            tiles = [o.images.permute(0, 3, 1, 2).contiguous() for o in ra.run([req_a(gen) for gen in gens])]
+            return rt.run([dict(prompt_embeds=e4, negative_prompt_embeds=n4, image=t * 2 - 1, mask_image=mask4, controlnet_conditioning_image=t,
+                                controlnet_conditioning_scale=1.0, height=res, width=res, num_inference_steps=20, guidance_scale=7.5,
+                                num_images_per_prompt=1, generator=gen, output_type="np_device") for t, gen in zip(tiles, gens)])
+        t4m = timed(step4m, reps=1) / 2
+        out["c4"]["merged2"] = {"value": round(1.0 / t4m, 4), "unit": "images/s", "ms_per_image": round(t4m * 1e3, 2), "network_batch": 4,
+                                "vs_one_request_per_call": round(t4 / t4m, 4)}
     del pipe_a, pipe_t, un, cns
     torch.cuda.empty_cache()
+    out["c4"]["every_timed_call_ms"] = rep_ms      # c5 x 2 (+ merged pair), c4 x 2 (+ merged pair): a one-off stall shows here
     return out
 
 

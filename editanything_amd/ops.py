@@ -189,6 +189,18 @@ def lanewise(fn):
     return wrap
 
 
+_NONDEFAULT_PRIORITY_STREAMS = [0]
+
+
+def note_nondefault_priority_stream():
+    """serving.make_stream created a HIP stream whose priority is not 0 (pipeline._capture then validates its instantiations)."""
+    _NONDEFAULT_PRIORITY_STREAMS[0] += 1
+
+
+def nondefault_priority_streams():
+    return _NONDEFAULT_PRIORITY_STREAMS[0]
+
+
 def dup_rows(t, dim=0):
     """cat([t, t], dim): the two identical halves of a CFG batch materialised (unet.py shared prefix)."""
     if isinstance(t, Pair):

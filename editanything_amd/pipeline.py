@@ -37,6 +37,13 @@ class StableDiffusionPipelineOutput:
         return iter((self.images, self.nsfw_content_detected))
 
 
+def loop_draw_count(nsteps, step_noise, mixing):
+    """Random tensors (each of the latents' shape) the denoising loop consumes, in order: the mixing pipeline's re-noise in front
+    of the steps (…inpaint.py:1968-1975), then per step the eta > 0 variance noise and -- every step but the last -- the mixing
+    re-noise (:2039-2051)."""
+    return (1 if mixing else 0) + (nsteps if step_noise else 0) + (nsteps - 1 if mixing else 0)
+
+
 def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
     """diffusers.utils.randn_tensor semantics: a CPU generator draws on the CPU, then the sample moves."""
     gdev = generator.device.type if generator is not None else "cpu"
@@ -345,7 +352,7 @@ class StableDiffusionControlNetInpaintPipeline:
               num_images_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
               negative_prompt_embeds=None, output_type="pil", return_dict=True, callback=None, callback_steps=1,
               cross_attention_kwargs=None, controlnet_conditioning_scale=1.0, alignment_ratio=None,
-              guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None,
+              guess_mode=False, controlnet_conditioning_scale_map=None, vae_noise=None, alpha_weight=None, loop_noise=None,
               ref_image=None, ref_mask=None, ref_controlnet_conditioning_scale=1.0, ref_prompt=None,
               ref_prompt_embeds=None, attention_auto_machine_weight=1.0, gn_auto_machine_weight=1.0,
               style_fidelity=0.5, reference_attn=True, reference_adain=True, ref_scale=1.0, **unused):
@@ -481,18 +488,31 @@ class StableDiffusionControlNetInpaintPipeline:
         # draws front-then-loop from its generator whichever way it is run, so when serving.PipelinedRunner issues front(i + 1)
         # beside loop(i) -- possibly on the SAME generator object (torch.manual_seed returns the global one) -- request i + 1
         # still starts from the state request i's loop would have left: overlapped == sequential, bit for bit (round-5 advisor).
+        # `loop_noise=`: those draws handed in (a sequence of `loop_draw_count` tensors of the latents' shape) -- what a caller that
+        # batches several calls into one passes, like `latents=` / `vae_noise=` (serving.merge_kwargs).
         g0 = generator if not isinstance(generator, list) else generator[0]
-        nsteps = len(timesteps)
-        c.loop_noise = []
-        if mixing:
-            c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
-        for i in range(nsteps):
-            if step_noise:
-                c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
-            if mixing and i < nsteps - 1:
-                c.loop_noise.append(randn_tensor(lat.shape, g0, self.device))
+        n_draws = loop_draw_count(len(timesteps), step_noise, mixing)
+        if loop_noise is not None:
+            if len(loop_noise) != n_draws or any(tuple(t.shape) != tuple(lat.shape) for t in loop_noise):
+                raise ValueError(f"`loop_noise` must hold {n_draws} tensors of shape {tuple(lat.shape)}")
+            c.loop_noise = [t.to(self.device, torch.float32) for t in loop_noise]
+        else:
+            c.loop_noise = [randn_tensor(lat.shape, g0, self.device) for _ in range(n_draws)]
         c.final = None
         return c
+
+    def normalize_kwargs(self, kw):
+        """The keyword form of a call as the BASE `front` sees it (subclasses fold their argument conventions in): what
+        serving.predraw / merge_kwargs reason about."""
+        return dict(kw)
+
+    def loop_draws(self, num_inference_steps, eta, alpha_weight, has_image):
+        """How many latents-shaped random tensors the loop of such a call consumes (`loop_draw_count`), by `front`'s own rules."""
+        sch = copy.copy(self.scheduler)
+        nsteps = len(sch.set_timesteps(num_inference_steps, eta=eta))
+        step_noise = eta > 0 and not isinstance(sch, UniPCMultistepScheduler)
+        mixing = alpha_weight is not None and has_image and self.unet.cfg["in_channels"] == 4
+        return loop_draw_count(nsteps, step_noise, mixing)
 
     def has_graph(self, call):
         """True when `loop(call)` will replay an already captured step (nothing is captured, nothing allocated)."""
@@ -712,29 +732,57 @@ class StableDiffusionControlNetInpaintPipeline:
 
     def _capture(self, st, ref=None):
         """Warm up once on a side stream (restoring the latents), then capture ONE step into a HIP graph.  The warm-up
-        also fills the per-call caches a capture could not (mask index lists, FFT plans)."""
+        also fills the per-call caches a capture could not (mask index lists, FFT plans).
+
+        Round 6: while a HIP stream of NON-default priority exists in the process (serving.make_stream: the two-stream runner's
+        low-priority side stream) some instantiations of the very same capture replay 1.3 - 2.6 x slower -- deterministically by
+        instantiation count, eager launches unaffected (tools/probe_graph_lottery.py, profiles/r06_side_stream_priority.jsonl).  In
+        that situation the step is instantiated three to five times, each timed over two replays on restored inputs, and the fastest
+        kept (about one instantiation in three is slow, by 1.3 x and more; they can be consecutive)."""
         step = (lambda: self._ref_step(st, ref)) if ref is not None else (lambda: self._step(st))
         saved = st["lat"].clone()
         unipc_saved = {k: v.clone() for k, v in st["unipc"].items()} if st.get("unipc") is not None else None
+
+        def restore():
+            st["lat"].copy_(saved)
+            if unipc_saved is not None:             # the multistep history a step pushed
+                for k, v in unipc_saved.items():
+                    st["unipc"][k].copy_(v)
+            if st.get("tab") is not None:           # ... and the step index it advanced
+                st["step"].zero_()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             step()
         torch.cuda.current_stream().wait_stream(s)
-        st["lat"].copy_(saved)
-        if unipc_saved is not None:                 # the multistep history the warm-up pushed
-            for k, v in unipc_saved.items():
-                st["unipc"][k].copy_(v)
-        if st.get("tab") is not None:               # ... and the step index it advanced
-            st["step"].zero_()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            step()
-        st["lat"].copy_(saved)
-        if unipc_saved is not None:
-            for k, v in unipc_saved.items():
-                st["unipc"][k].copy_(v)
-        return g
+        restore()
+
+        def instantiate():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            restore()
+            return g
+        if not ops.nondefault_priority_streams():
+            return instantiate()
+        # at least three instantiations, at most five; done once two of them sit within 10 % of the fastest seen (slow ones are
+        # 1.3 x and more off, about one in three, and CAN be consecutive: two agreeing attempts alone prove nothing)
+        tried = []
+        for attempt in range(5):
+            g = instantiate()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g.replay()                               # (first replay of an instantiation: uploads)
+            e0.record()
+            g.replay()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            restore()
+            tried.append((e0.elapsed_time(e1), g))
+            fastest = min(t for t, _ in tried)
+            if attempt >= 2 and sum(1 for t, _ in tried if t <= 1.1 * fastest) >= 2:
+                break
+        return min(tried, key=lambda tg: tg[0])[1]
 
     def _level_sizes(self, height, width):
         """(h, w) of every ControlNet output: one per input block, plus the middle block."""
@@ -781,6 +829,9 @@ class StableDiffusionControlNetInpaintMixingPipeline(StableDiffusionControlNetIn
     def front(self, *args, alpha_weight=0.5, **kw):
         return super().front(*args, alpha_weight=alpha_weight, **kw)
 
+    def normalize_kwargs(self, kw):
+        return dict(kw, alpha_weight=kw.get("alpha_weight", 0.5))
+
 
 class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline):
     """Generation variant (sam2image.py:168-177 calls `pipe(prompt=..., image=control, ...)`): here `image` IS the
@@ -793,3 +844,11 @@ class StableDiffusionControlNetPipeline(StableDiffusionControlNetInpaintPipeline
             kw["controlnet_conditioning_image"] = image
             image = None
         return super().front(prompt=prompt, image=None, mask_image=None, **kw)
+
+    def normalize_kwargs(self, kw):
+        kw = dict(kw)
+        image = kw.pop("image", None)
+        kw.pop("mask_image", None)
+        if "controlnet_conditioning_image" not in kw:
+            kw["controlnet_conditioning_image"] = image
+        return kw

@@ -60,8 +60,18 @@ def make_stream(device, priority, cu_count=0):
     Why not torch.cuda.Stream(): HIP multiplexes its streams onto a few hardware queues PER PRIORITY LEVEL (4 by default),
     handing each new stream the least-used queue of its level.  A side stream of normal priority can therefore land on the
     hardware queue that also carries the ControlNet branch of the captured step -- the two then run strictly in order and
-    the side stream's work displaces exactly the overlap the step already had (measured: pipelining gain 1.00,
-    profiles/r04_pipelined_ab.jsonl).  A stream of another priority level draws from another set of queues."""
+    the side stream's work displaces exactly the overlap the step already had (measured in round 4 with a torch pool stream:
+    pipelining gain 1.00, profiles/r04_pipelined_ab.jsonl).  A stream of another priority level draws from another set of queues.
+
+    ROUND 6 -- the price of that: while a stream of a NON-DEFAULT priority exists (low or high alike), some of the HIP graphs
+    instantiated afterwards replay 1.3 - 2.6 x slower -- deterministically by instantiation count (the 1st, 4th, 6th, 10th after the
+    stream's creation in tools/probe_graph_lottery.py: bs 1 18.7 vs 7.2 ms per evaluation, bs 8 31.9 vs 24.3, 1024^2 27.7 vs 19.1),
+    eager launches unaffected, an explicitly created priority-0 stream harmless: a graph's internal branch streams evidently end up on
+    hardware queues of mixed priority levels.  It hit bench.py's later captures (c4 / c5 lines -30 %, the batch sweep's network batch
+    16) and would hit a server that meets a new request shape after its runner exists.  The low-priority stream stays the default
+    (same-box: with_amg through the runner 10.30 vs 9.87 images/s at priority 0; headline gain 1.016 - 1.02 vs 1.005 - 1.016), and the
+    cure sits where the damage is: `pipeline._capture` validates its instantiations whenever such a stream exists
+    (`ops.note_nondefault_priority_stream`): three to five instantiations, timed, the fastest kept (profiles/r06_side_stream_priority.jsonl)."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     h = ctypes.c_void_p()
@@ -76,6 +86,8 @@ def make_stream(device, priority, cu_count=0):
     if rc != 0:
         raise RuntimeError(f"HIP stream creation (priority={priority}, cu_count={cu_count}) failed: {rc}")
     _keep.append(h)
+    if priority != 0 and not cu_count:
+        ops.note_nondefault_priority_stream()      # graphs instantiated from now on are validated (pipeline._capture)
     return torch.cuda.ExternalStream(h.value, device=device)
 
 
@@ -87,9 +99,9 @@ def make_stream(device, priority, cu_count=0):
 # launches of 15 - 40 us whose fixed part (set-up, epilogue, split-K round trip, partial rounds of the 256 CUs) weighs as much as
 # their K loop; at twice the rows the same fixed part is paid once for two requests (bench.py `batch_sweep`).
 _MERGE_SAME = ("height", "width", "num_inference_steps", "guidance_scale", "eta", "output_type", "return_dict",
-               "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs")
-_MERGE_NONE = ("callback", "controlnet_conditioning_scale_map", "alpha_weight", "ref_image", "ref_mask", "ref_prompt",
-               "ref_prompt_embeds", "control_image", "vae_noise", "latents")
+               "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs", "alpha_weight")
+_MERGE_NONE = ("callback", "controlnet_conditioning_scale_map", "ref_image", "ref_mask", "ref_prompt",
+               "ref_prompt_embeds", "control_image", "vae_noise", "latents", "loop_noise")
 
 
 def _request_geometry(kw):
@@ -115,17 +127,18 @@ def _request_geometry(kw):
 
 
 def predraw(pipe, kw):
-    """The first two random draws of the call `pipe(**kw)`, made NOW from its generator in the call's own order: the initial
-    latents (`prepare_latents`, …inpaint.py:1005-1007; a list of generators draws one image each) and then, for an inpaint call,
-    the VAE posterior noise (`prepare_masked_image_latents`, :1079-1081; a list uses its first generator).  -> kwargs for the
-    same call with `latents=` / `vae_noise=` filled in -- bit-identical results (tests/test_pipeline_parity.py::
-    test_inpaint_pipeline_explicit_noise_equals_generator_draws), every later draw of the call still comes from its generator --
-    or None when the shapes cannot be told up front (the call then draws for itself).
+    """EVERY random draw of the call `pipe(**kw)` (`kw` in `pipe.normalize_kwargs` form), made NOW from its generator in the call's
+    own order: the initial latents (`prepare_latents`, …inpaint.py:1005-1007; a list of generators draws one image each), for an
+    inpaint call the VAE posterior noise (`prepare_masked_image_latents`, :1079-1081; a list uses its first generator), then the
+    loop's draws (eta > 0 variance noise, the mixing pipeline's re-noise: `pipeline.loop_draw_count`).  -> kwargs for the same call
+    with `latents=` / `vae_noise=` / `loop_noise=` filled in -- bit-identical results (tests/test_pipeline_parity.py::
+    test_inpaint_pipeline_explicit_noise_equals_generator_draws) -- or None when the shapes cannot be told up front or the call
+    draws something else in between (reference-only control): the call then draws for itself.
     Why: requests of a group may SHARE a generator object (`torch.manual_seed(s)` hands out the global one and the next request's
     seed re-seeds it, sam2image.py:163-167), so each request's draws are taken the moment its kwargs exist."""
     from . import host
     from .pipeline import randn_tensor
-    if kw.get("latents") is not None or kw.get("vae_noise") is not None:
+    if kw.get("latents") is not None or kw.get("vae_noise") is not None or kw.get("loop_noise") is not None or kw.get("ref_image") is not None:
         return None
     geo = _request_geometry(kw)
     if geo is None:
@@ -139,22 +152,31 @@ def predraw(pipe, kw):
         lat, g0 = torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g]), g[0]
     else:
         lat, g0 = randn_tensor(shape, g, dev), g
+    eta, alpha = float(kw.get("eta", 0.0) or 0.0), kw.get("alpha_weight")
+    n_loop = 0
+    if eta > 0 or alpha is not None:
+        if not hasattr(pipe, "loop_draws"):
+            return None
+        n_loop = pipe.loop_draws(int(kw.get("num_inference_steps", 50)), eta, alpha, kw.get("image") is not None)
     out = dict(kw, latents=lat)
     if kw.get("image") is not None:
         rows = host.prepare_image(kw["image"]).shape[0]
         out["vae_noise"] = randn_tensor((rows, 4, h // 8, w // 8), g0, dev)
+    if n_loop:
+        out["loop_noise"] = [randn_tensor(shape, g0, dev) for _ in range(n_loop)]
     return out
 
 
 def mergeable_alone(kw):
-    """Could this call be a block of rows of a merged call?  (No per-call state, no random draw beyond x_T / VAE noise.)"""
-    return not any(kw.get(k) is not None for k in _MERGE_NONE) and kw.get("eta", 0.0) == 0.0 and _request_geometry(kw) is not None
+    """Could this call be a block of rows of a merged call?  (No per-call state: callbacks, scale maps, reference-only control;
+    every random draw is one `predraw` can take.)"""
+    return not any(kw.get(k) is not None for k in _MERGE_NONE) and _request_geometry(kw) is not None
 
 
 def merge_kwargs(pipe, kws):
     """ONE kwargs dict that evaluates the PRE-DRAWN pipeline calls `kws` (`predraw` outputs) as a single batched call, or None when
-    they cannot be merged (different sizes / step counts / scales, reference-only control, mixing, eta > 0, callbacks, a
-    9-channel inpainting UNet, string prompts without a text encoder: anything whose per-call state is not a row of a batch).
+    they cannot be merged (different sizes / step counts / scales / eta / alpha weights, reference-only control, callbacks, scale
+    maps, a 9-channel inpainting UNet, string prompts without a text encoder: anything whose per-call state is not a row of a batch).
     The merged call has one row per IMAGE (num_images_per_prompt = 1): a request of b prompts x n images contributes b * n rows in
     the pipeline's own order (prompt-major, `_encode_prompt`'s repeat / `_prepare_cond_image`'s repeat_interleave), its latents
     and VAE noise are its own draws.  -> (merged kwargs, [rows per request])."""
@@ -165,7 +187,9 @@ def merge_kwargs(pipe, kws):
     for kw in kws:
         if kw is None or kw.get("latents") is None:
             return None
-        if any(kw.get(k) is not None for k in _MERGE_NONE if k not in ("latents", "vae_noise")) or kw.get("eta", 0.0) != 0.0:
+        if any(kw.get(k) is not None for k in _MERGE_NONE if k not in ("latents", "vae_noise", "loop_noise")):
+            return None
+        if len(kw.get("loop_noise") or ()) != len(k0.get("loop_noise") or ()):
             return None
         if any(kw.get(k) != k0.get(k) for k in _MERGE_SAME):
             return None
@@ -247,6 +271,8 @@ def merge_kwargs(pipe, kws):
     out["controlnet_conditioning_image"] = merged_ctl if isinstance(k0.get("controlnet_conditioning_image"), (list, tuple)) else merged_ctl[0]
     if parts["img"]:
         out.update(image=cat(parts["img"]), mask_image=cat(parts["msk"]), vae_noise=cat(parts["vn"]))
+    if k0.get("loop_noise"):
+        out["loop_noise"] = [cat([kw["loop_noise"][i] for kw in kws]) for i in range(len(k0["loop_noise"]))]
     return out, sizes
 
 
@@ -362,6 +388,7 @@ class PipelinedRunner:
             r = group[0]
             return [self.pipe.front(**(r() if callable(r) else r))], [None]
         calls, sizes, pending = [], [], []
+        norm = getattr(self.pipe, "normalize_kwargs", dict)
 
         def flush():
             merged = merge_kwargs(self.pipe, pending) if len(pending) > 1 else None
@@ -374,7 +401,7 @@ class PipelinedRunner:
                     sizes.append(None)
             del pending[:]
         for r in group:
-            kw = r() if callable(r) else r
+            kw = norm(r() if callable(r) else r)
             pd = predraw(self.pipe, kw) if mergeable_alone(kw) else None
             if pd is None:
                 flush()

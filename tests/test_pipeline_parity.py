@@ -191,8 +191,9 @@ def test_merged_requests_equal_their_own_calls(mg, tiny, overlap):
     keeps its own draws: x_T and the VAE posterior noise come from ITS generator in ITS order, serving.merge_kwargs).  Samples are
     independent in every network of the path, so each request gets the images its own call gives -- up to fp16 summation order
     (other M, other split-K plan): rel-L2 <= 1e-2 over the four steps of the tiny model (measured 3.9e-3; its tolerance against the oracle is 1.5e-2), and the 20-step full-size form is held to the oracle in
-    test_pipeline_e2e_batch4_image0_vs_fp32_oracle.  Five requests: two merged pairs + one left over; then a group that cannot be
-    merged (eta > 0 draws noise inside the loop) falls back to one call per request, bit-identical to the plain calls."""
+    test_pipeline_e2e_batch4_image0_vs_fp32_oracle.  Five requests: two merged pairs + one left over; then pairs whose LOOP draws
+    noise (eta > 0, the mixing pipeline) merged with their loop noise handed over; then a group that cannot be merged (a callback)
+    falls back to one call per request, bit-identical to the plain calls."""
     from editanything_amd import serving
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
     ukey, cns, kw0 = mg.pipe_case_kwargs("a_none", mg.pipe_inputs())
@@ -220,12 +221,31 @@ def test_merged_requests_equal_their_own_calls(mg, tiny, overlap):
             assert e <= 1e-2, (rounds, r, e)
         assert torch.equal(got[4].images, want[4]), "the left-over request runs as its own call"
     assert len(pipe._graphs) == 2, "one captured step per batch size (merged pair, single request)"
+    # eta > 0 (variance noise inside the loop) and the mixing pipeline (per-step re-noise): the loop's draws are taken with the
+    # request's other draws (serving.predraw) and handed over as `loop_noise=` -- merged too, each request on ITS noise
+    from editanything_amd.pipeline import StableDiffusionControlNetInpaintMixingPipeline
     ukey2, cns2, kwe = mg.pipe_case_kwargs("a_050_eta", mg.pipe_inputs())
-    pipe_e, seq_e = (_pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey2, cns2, True) for _ in range(2))
-    want_e = [seq_e(generator=torch.Generator("cpu").manual_seed(50 + r), **kwe).images.clone() for r in range(2)]
-    got_e = serving.PipelinedRunner(pipe_e, overlap=overlap, merge=2).run([dict(kwe, generator=torch.Generator("cpu").manual_seed(50 + r)) for r in range(2)])
+    cnsm, kwm = mg.mix_case_kwargs("mix_a05", mg.pipe_inputs())
+    for cls, uk, cn_, kwx in ((StableDiffusionControlNetInpaintPipeline, ukey2, cns2, kwe), (StableDiffusionControlNetInpaintMixingPipeline, "unet", cnsm, kwm)):
+        pipe_x, seq_x = (_pipe(cls, tiny, uk, cn_, True) for _ in range(2))
+        want_x = [seq_x(generator=torch.Generator("cpu").manual_seed(50 + r), **kwx).images.clone() for r in range(2)]
+        calls = []
+        orig_front = pipe_x.front
+        pipe_x.front = lambda **kw: (calls.append(kw), orig_front(**kw))[1]
+        got_x = serving.PipelinedRunner(pipe_x, overlap=overlap, merge=2).run([dict(kwx, generator=torch.Generator("cpu").manual_seed(50 + r)) for r in range(2)])
+        torch.cuda.synchronize()
+        assert len(calls) == 1 and calls[0]["loop_noise"] and calls[0]["latents"].shape[0] == 2 * want_x[0].shape[0], "one merged call"
+        for g_, w_ in zip(got_x, want_x):
+            assert rel_l2(g_.images, w_) <= 1e-2, (cls.__name__, rel_l2(g_.images, w_))
+        assert rel_l2(got_x[0].images, want_x[1]) > 0.1, "each request on its own noise"
+    # a request with per-call state (a callback) cannot be a row block: the group runs one call per request, bit-identical
+    seen = []
+    cb = lambda i, t, lat: seen.append(i)
+    want_c = [seq_pipe(generator=torch.Generator("cpu").manual_seed(60 + r), **reqs[r]).images.clone() for r in range(2)]
+    got_c = serving.PipelinedRunner(pipe, overlap=overlap, merge=2).run(
+        [dict(reqs[0], generator=torch.Generator("cpu").manual_seed(60), callback=cb), dict(reqs[1], generator=torch.Generator("cpu").manual_seed(61))])
     torch.cuda.synchronize()
-    assert all(torch.equal(g.images, w) for g, w in zip(got_e, want_e))
+    assert seen and all(torch.equal(g_.images, w_) for g_, w_ in zip(got_c, want_c))
     runner.close()
 
 

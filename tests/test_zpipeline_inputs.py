@@ -253,10 +253,22 @@ def test_merge_kwargs_concatenates_requests_and_keeps_each_request_its_own_draws
                                 _encode_text=lambda ps: torch.stack([torch.full((77, 8), float(len(p_))) for p_ in ps]))
     m3, _ = serving.merge_kwargs(enc, [serving.predraw(enc, kw) for kw in txt])
     assert m3["prompt_embeds"].shape == (4, 77, 8) and float(m3["negative_prompt_embeds"].abs().max()) == 0.0   # "" -> length 0
-    # unmergeable: alone (eta, mixing, reference-only ... : no predraw at all -> generator untouched) or as a group
-    for kw in (_merge_req(2, eta=0.3), dict(_merge_req(2), alpha_weight=0.5), dict(_merge_req(2), ref_image=object())):
+    # unmergeable alone: per-call state (reference-only control, callbacks, scale maps) -> no predraw at all, generator untouched
+    for kw in (dict(_merge_req(2), ref_image=object()), dict(_merge_req(2), callback=print), dict(_merge_req(2), controlnet_conditioning_scale_map=torch.zeros(1))):
         assert not serving.mergeable_alone(kw)
-    assert serving.mergeable_alone(_merge_req(1))
+    assert serving.mergeable_alone(_merge_req(1)) and serving.mergeable_alone(_merge_req(2, eta=0.3)) and serving.mergeable_alone(dict(_merge_req(2), alpha_weight=0.5))
+    # eta > 0 / mixing: the LOOP's draws are taken too, right after x_T and the VAE noise, and handed over as `loop_noise=`
+    lp = types.SimpleNamespace(unet=pipe.unet, device=pipe.device, text_encoder=None, loop_draws=lambda steps, eta, alpha, has_image: 7)
+    de = [serving.predraw(lp, _merge_req(s_, eta=0.3)) for s_ in (11, 12)]
+    g = _merge_req(11, eta=0.3)["generator"]
+    want = [randn_tensor((2, 4, 8, 8), g, "cpu") for _ in range(9)]           # x_T, VAE noise, 7 loop draws: one stream, this order
+    assert torch.equal(de[0]["latents"], want[0]) and torch.equal(de[0]["vae_noise"], want[1]) and len(de[0]["loop_noise"]) == 7
+    assert all(torch.equal(a, b) for a, b in zip(de[0]["loop_noise"], want[2:]))
+    me, sze = serving.merge_kwargs(lp, de)
+    assert sze == [2, 2] and len(me["loop_noise"]) == 7 and me["loop_noise"][3].shape == (4, 4, 8, 8) and me["eta"] == 0.3
+    assert torch.equal(me["loop_noise"][3][:2], de[0]["loop_noise"][3]) and torch.equal(me["loop_noise"][3][2:], de[1]["loop_noise"][3])
+    assert serving.predraw(pipe, _merge_req(3, eta=0.3)) is None             # (a pipeline that cannot say how many: the call draws for itself)
+    assert serving.merge_kwargs(lp, [serving.predraw(lp, _merge_req(1, eta=0.3)), serving.predraw(lp, _merge_req(2))]) is None     # eta differs
     for bad in ([_merge_req(1), dict(_merge_req(2), height=128, width=128)], [_merge_req(1), dict(_merge_req(2), num_inference_steps=5)],
                 [_merge_req(1), _merge_req(2, b=3, img_rows=2)], [_merge_req(1)]):
         assert serving.merge_kwargs(pipe, [serving.predraw(pipe, kw) for kw in bad]) is None
