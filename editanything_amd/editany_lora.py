@@ -202,8 +202,57 @@ class EditAnythingLoraModel:
             return prompt_embeds, negative_prompt_embeds
         return get_pipeline_embeds(pipe, positive, negative, self.device)
 
-    @torch.inference_mode()
-    def process(self, source_image, enable_all_generate, mask_image, control_scale, enable_auto_prompt, a_prompt,
+    def process(self, *args, **kw):
+        """`EditAnythingLoraModel.process` (editany_lora.py:609-938), same 34 arguments, same return value.  The body is
+        `_process_steps`, a generator that hands every pipeline call it wants made to its driver: here they are made one by one,
+        `process_many` makes them for several requests at once."""
+        steps = self._process_steps(False, *args, **kw)
+        with torch.inference_mode():
+            try:
+                pipe, pkw = next(steps)
+                while True:
+                    pipe, pkw = steps.send(pipe(**pkw))
+            except StopIteration as stop:
+                return stop.value
+
+    def process_many(self, requests, merge=2):
+        """Several `process` requests (dicts of its arguments) served together: the pipeline calls the requests want made at the
+        same stage -- the ControlNet(s) inpaint / mixing call, then the tile-ControlNet refinement of ITS result -- go through
+        `serving.PipelinedRunner(pipe, merge=merge)`, i.e. consecutive requests of one shape become ONE batched call (BASELINE
+        config 4 at one image per GPU: +26 % images/s with two requests per call, bench.py `c4.merged2`).  Every request draws from
+        its OWN generator, seeded like the reference seeds the global one (`torch.Generator().manual_seed(seed)` is the same stream
+        as `torch.manual_seed(seed)`), first the base stage's draws, then the refinement's: the noise `process` would use.
+        Returns `process`' return value per request, in order (images equal up to fp16 summation order)."""
+        from .serving import PipelinedRunner
+        reqs = [dict(r) for r in requests]
+        results = [None] * len(reqs)
+        with torch.inference_mode():
+            steps = [self._process_steps(True, **r) for r in reqs]
+            want = {}
+            for i, st in enumerate(steps):
+                try:
+                    want[i] = next(st)
+                except StopIteration as stop:
+                    results[i] = stop.value
+            runners = {}
+            while want:
+                pipe = want[min(want)][0]                       # one stage of one pipeline at a time, requests in order
+                members = [i for i in sorted(want) if want[i][0] is pipe]
+                kws = [want[i][1] for i in members]
+                if hasattr(pipe, "front"):
+                    runner = runners.get(id(pipe)) or runners.setdefault(id(pipe), PipelinedRunner(pipe, merge=merge))
+                    outs = runner.run(kws)
+                else:                                           # (anything callable: test stubs)
+                    outs = [pipe(**k) for k in kws]
+                for i, out in zip(members, outs):
+                    try:
+                        want[i] = steps[i].send(out)
+                    except StopIteration as stop:
+                        results[i] = stop.value
+                        del want[i]
+        return results
+
+    def _process_steps(self, _own_generator, source_image, enable_all_generate, mask_image, control_scale, enable_auto_prompt, a_prompt,
                 n_prompt, num_samples, image_resolution, detect_resolution, ddim_steps, guess_mode, scale, seed, eta,
                 enable_tile=True, refine_alignment_ratio=None, refine_image_resolution=None, alpha_weight=0.5,
                 use_scale_map=False, condition_model=None, ref_image=None, attention_auto_machine_weight=1.0,
@@ -262,16 +311,18 @@ class EditAnythingLoraModel:
         mask_image = Image.fromarray(mask_image_tmp)
 
         seed, generator = host.resolve_seed(seed)
+        if _own_generator:                     # process_many: the same stream as the global generator `resolve_seed` just seeded
+            generator = torch.Generator().manual_seed(seed)
         postive_prompt, negative_prompt = a_prompt, n_prompt
         pe, ne = self._embeds(self.pipe, postive_prompt, negative_prompt, prompt_embeds, negative_prompt_embeds)
 
         scale_map = None
         if enable_all_generate and self.extra_inpaint:
             # generation-only pipeline: `image` IS the control image (:766-779)
-            x_samples = self.pipe(prompt_embeds=pe, negative_prompt_embeds=ne, num_images_per_prompt=num_samples,
-                                  num_inference_steps=ddim_steps, generator=generator, height=H, width=W,
-                                  image=[control], controlnet_conditioning_scale=[float(control_scale)],
-                                  guidance_scale=scale, guess_mode=guess_mode).images
+            x_samples = (yield self.pipe, dict(prompt_embeds=pe, negative_prompt_embeds=ne, num_images_per_prompt=num_samples,
+                                               num_inference_steps=ddim_steps, generator=generator, height=H, width=W,
+                                               image=[control], controlnet_conditioning_scale=[float(control_scale)],
+                                               guidance_scale=scale, guess_mode=guess_mode)).images
         else:
             cond_images, cond_scales = [control], [float(control_scale)]
             if self.extra_inpaint:
@@ -293,11 +344,11 @@ class EditAnythingLoraModel:
                           gn_auto_machine_weight=gn_auto_machine_weight, style_fidelity=style_fidelity,
                           reference_attn=reference_attn, reference_adain=reference_adain,
                           ref_controlnet_conditioning_scale=ref_scales, ref_scale=ref_scale)
-            x_samples = self.pipe(image=img, mask_image=mask_image, prompt_embeds=pe, negative_prompt_embeds=ne,
-                                  num_images_per_prompt=num_samples, num_inference_steps=ddim_steps,
-                                  generator=generator, controlnet_conditioning_image=cond_images, height=H, width=W,
-                                  controlnet_conditioning_scale=cond_scales, guidance_scale=scale,
-                                  guess_mode=guess_mode, **kw).images
+            x_samples = (yield self.pipe, dict(image=img, mask_image=mask_image, prompt_embeds=pe, negative_prompt_embeds=ne,
+                                               num_images_per_prompt=num_samples, num_inference_steps=ddim_steps,
+                                               generator=generator, controlnet_conditioning_image=cond_images, height=H, width=W,
+                                               controlnet_conditioning_scale=cond_scales, guidance_scale=scale,
+                                               guess_mode=guess_mode, **kw)).images
         results = [x_samples[i] for i in range(num_samples)]
 
         results_tile = []
@@ -322,12 +373,12 @@ class EditAnythingLoraModel:
                 # one prompt row per tile, num_images_per_prompt = 1: a batch of control images must match the prompt
                 # batch (check_controlnet_conditioning_image, ...inpaint.py:782-790)
                 bcommon = dict(common, prompt_embeds=tpe.repeat(num_samples, 1, 1), negative_prompt_embeds=tne.repeat(num_samples, 1, 1))
-                results_tile = list(self.tile_pipe(image=batch, controlnet_conditioning_image=batch,
-                                                   num_images_per_prompt=1, latents=lat, vae_noise=vn,
-                                                   generator=generator, **bcommon).images)
+                results_tile = list((yield self.tile_pipe, dict(image=batch, controlnet_conditioning_image=batch,
+                                                                num_images_per_prompt=1, latents=lat, vae_noise=vn,
+                                                                generator=generator, **bcommon)).images)
             else:
                 for i in range(num_samples):
                     img_tile = Image.fromarray(tiles[i])
-                    results_tile += list(self.tile_pipe(image=img_tile, controlnet_conditioning_image=img_tile,
-                                                        num_images_per_prompt=1, generator=generator, **common).images)
+                    results_tile += list((yield self.tile_pipe, dict(image=img_tile, controlnet_conditioning_image=img_tile,
+                                                                     num_images_per_prompt=1, generator=generator, **common)).images)
         return results_tile, results, [full_segmask, mask_image], postive_prompt

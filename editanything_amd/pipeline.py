@@ -223,12 +223,10 @@ class StableDiffusionControlNetInpaintPipeline:
             prompt_embeds = torch.cat([ne, prompt_embeds])
         return prompt_embeds
 
-    def _prepare_cond_image(self, img, width, height, batch, num_images_per_prompt, do_cfg):
-        """prepare_controlnet_conditioning_image (…inpaint.py:328-388).  Tensors (or a list of tensors, concatenated)
-        pass through unscaled -- the SAM id-map control is fed as float 0..255, sam2image.py:158-177; PIL images (or a
-        list of them) are LANCZOS-resized to (width, height) and scaled to [0, 1].  One image is repeated for the whole
-        batch, a batch of images `num_images_per_prompt` times each (repeat_interleave: [c0, c0, c1, c1], the order of
-        the prompt embeddings)."""
+    def _cond_image_tensor(self, img, width, height):
+        """A conditioning image argument of any accepted kind -> float tensor [b, 3, height, width] (tensors unscaled, PIL / uint8
+        arrays LANCZOS-resized and scaled to [0, 1]): the first half of `_prepare_cond_image`, also what serving.merge_kwargs
+        concatenates."""
         if not isinstance(img, torch.Tensor):
             if hasattr(img, "convert"):
                 img = [img]
@@ -246,6 +244,15 @@ class StableDiffusionControlNetInpaintPipeline:
             img = img[None]
         if img.shape[-2:] != (height, width):
             img = F.interpolate(img, size=(height, width), mode="bilinear", align_corners=False)
+        return img
+
+    def _prepare_cond_image(self, img, width, height, batch, num_images_per_prompt, do_cfg):
+        """prepare_controlnet_conditioning_image (…inpaint.py:328-388).  Tensors (or a list of tensors, concatenated)
+        pass through unscaled -- the SAM id-map control is fed as float 0..255, sam2image.py:158-177; PIL images (or a
+        list of them) are LANCZOS-resized to (width, height) and scaled to [0, 1].  One image is repeated for the whole
+        batch, a batch of images `num_images_per_prompt` times each (repeat_interleave: [c0, c0, c1, c1], the order of
+        the prompt embeddings)."""
+        img = self._cond_image_tensor(img, width, height)
         repeat_by = batch if img.shape[0] == 1 else num_images_per_prompt
         img = img.repeat_interleave(repeat_by, dim=0)
         if img.shape[0] != batch:

@@ -101,7 +101,7 @@ def make_stream(device, priority, cu_count=0):
 _MERGE_SAME = ("height", "width", "num_inference_steps", "guidance_scale", "eta", "output_type", "return_dict",
                "controlnet_conditioning_scale", "alignment_ratio", "guess_mode", "cross_attention_kwargs", "alpha_weight")
 _MERGE_NONE = ("callback", "controlnet_conditioning_scale_map", "ref_image", "ref_mask", "ref_prompt",
-               "ref_prompt_embeds", "control_image", "vae_noise", "latents", "loop_noise")
+               "ref_prompt_embeds", "control_image")
 
 
 def _request_geometry(kw):
@@ -138,7 +138,7 @@ def predraw(pipe, kw):
     seed re-seeds it, sam2image.py:163-167), so each request's draws are taken the moment its kwargs exist."""
     from . import host
     from .pipeline import randn_tensor
-    if kw.get("latents") is not None or kw.get("vae_noise") is not None or kw.get("loop_noise") is not None or kw.get("ref_image") is not None:
+    if kw.get("ref_image") is not None:
         return None
     geo = _request_geometry(kw)
     if geo is None:
@@ -146,12 +146,16 @@ def predraw(pipe, kw):
     b, nipp, h, w = geo
     n_img, g, dev = b * nipp, kw.get("generator"), pipe.device
     shape = (n_img, 4, h // 8, w // 8)
+    # (draws the caller handed in already -- `latents=` / `vae_noise=` / `loop_noise=`, e.g. editany_lora's batched tile refinement --
+    # are kept; only the missing ones are taken, in the call's order)
     if isinstance(g, (list, tuple)):
         if len(g) != n_img:
             return None                                   # (the call itself raises: let it)
-        lat, g0 = torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g]), g[0]
+        g0 = g[0]
+        lat = kw["latents"] if kw.get("latents") is not None else torch.cat([randn_tensor((1,) + shape[1:], gi, dev) for gi in g])
     else:
-        lat, g0 = randn_tensor(shape, g, dev), g
+        g0 = g
+        lat = kw["latents"] if kw.get("latents") is not None else randn_tensor(shape, g, dev)
     eta, alpha = float(kw.get("eta", 0.0) or 0.0), kw.get("alpha_weight")
     n_loop = 0
     if eta > 0 or alpha is not None:
@@ -159,10 +163,10 @@ def predraw(pipe, kw):
             return None
         n_loop = pipe.loop_draws(int(kw.get("num_inference_steps", 50)), eta, alpha, kw.get("image") is not None)
     out = dict(kw, latents=lat)
-    if kw.get("image") is not None:
+    if kw.get("image") is not None and kw.get("vae_noise") is None:
         rows = host.prepare_image(kw["image"]).shape[0]
         out["vae_noise"] = randn_tensor((rows, 4, h // 8, w // 8), g0, dev)
-    if n_loop:
+    if n_loop and kw.get("loop_noise") is None:
         out["loop_noise"] = [randn_tensor(shape, g0, dev) for _ in range(n_loop)]
     return out
 
@@ -187,7 +191,7 @@ def merge_kwargs(pipe, kws):
     for kw in kws:
         if kw is None or kw.get("latents") is None:
             return None
-        if any(kw.get(k) is not None for k in _MERGE_NONE if k not in ("latents", "vae_noise", "loop_noise")):
+        if any(kw.get(k) is not None for k in _MERGE_NONE):
             return None
         if len(kw.get("loop_noise") or ()) != len(k0.get("loop_noise") or ()):
             return None
@@ -208,7 +212,11 @@ def merge_kwargs(pipe, kws):
         c = kw.get("controlnet_conditioning_image")
         return list(c) if isinstance(c, (list, tuple)) else [c]
     ctl = [control(kw) for kw in kws]
-    if any(len(c) != len(ctl[0]) or not all(torch.is_tensor(t) and t.dim() == 4 for t in c) for c in ctl):
+    to_tensor = getattr(pipe, "_cond_image_tensor", None)       # PIL / ndarray control images -> the tensor `front` would make of them
+    if to_tensor is not None:
+        ctl = [[t if torch.is_tensor(t) else to_tensor(t, width, height) for t in c] for c in ctl]
+    ctl = [[t[None] if torch.is_tensor(t) and t.dim() == 3 else t for t in c] for c in ctl]
+    if any(len(c) != len(ctl[0]) or not all(torch.is_tensor(t) and t.dim() == 4 and t.shape[-2:] == (height, width) for t in c) for c in ctl):
         return None
 
     def rows(t, b, nipp):

@@ -358,3 +358,58 @@ def test_gpu_mixing_pipeline_alpha_weighted_blend():
     c = mix(generator=torch.Generator().manual_seed(9), alpha_weight=1.0, **dict(kw, alignment_ratio=1.0)).images
     d = mix(generator=torch.Generator().manual_seed(9), alpha_weight=0.0, **dict(kw, alignment_ratio=1.0)).images
     assert not torch.isnan(c).any() and float((c - d).norm() / d.norm()) > 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ process_many
+def test_process_many_drives_the_same_calls_as_process_with_a_private_generator_per_request():
+    """`process_many` (round 6): the generator body of `process` handed the SAME pipeline calls in the same per-request order --
+    base stage, then the refinement of ITS result -- and every request draws from its own generator, seeded like the reference
+    seeds the global one: the noise each recorded call received equals what `process` made it receive, request by request."""
+    reqs = [dict(PROCESS_ARGS, source_image=src(seed=i), seed=100 + i, num_samples=1 + (i % 2), enable_tile=True,
+                 refine_alignment_ratio=0.9, refine_image_resolution=128) for i in range(3)]
+    one, built1, tile1 = make_model()
+    want = [one.process(**r) for r in reqs]
+    many, built2, tile2 = make_model()
+    got = many.process_many(reqs, merge=2)
+    assert len(got) == 3
+    for (rt_a, r_a, _, p_a), (rt_b, r_b, _, p_b) in zip(got, want):
+        assert p_a == p_b and len(rt_a) == len(rt_b) and len(r_a) == len(r_b)
+    # per pipeline the calls come grouped by STAGE (all base calls, then all tile calls) but each call saw its request's noise
+    base1, base2 = built1[0].calls, built2[0].calls
+    assert len(base1) == len(base2) == 3
+    for a, b in zip(base2, base1):
+        assert torch.equal(a["_lat"], b["_lat"]) and torch.equal(a["_vn"], b["_vn"]) and a["num_images_per_prompt"] == b["num_images_per_prompt"]
+    assert len(tile1.calls) == len(tile2.calls) == 3
+    for a, b in zip(tile2.calls, tile1.calls):
+        assert torch.equal(a["_lat"], b["_lat"]) and torch.equal(a["_vn"], b["_vn"])
+
+
+@pytest.mark.gpu
+def test_gpu_process_many_merges_requests_and_matches_process():
+    """BASELINE config 4's call surface with two requests per call: `process_many(merge=2)` on SD-shaped tiny networks (two
+    ControlNets, then tile refinement; one image per request = the per-GPU shape of config 4) against `process` one request at a
+    time -- same prompts, each request its own seed and source image; uint8 images within the fp16 summation-order class -- and
+    BOTH stages really went out as one merged call for the pair."""
+    inpaint, tile = _tiny_pipes()
+    g = torch.Generator().manual_seed(0)
+    pe, ne = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    mk = lambda: el.EditAnythingLoraModel(base_model_path="synthetic", lora_model_path=None, use_blip=False, sam_generator=StubSam(),
+                                          mask_predictor=StubPredictor(), tile_model=tile, pipe_factory=lambda *a: inpaint)
+    reqs = [dict(PROCESS_ARGS, source_image=src(seed=i), seed=50 + i, num_samples=1, enable_tile=True, refine_alignment_ratio=0.75,
+                 refine_image_resolution=128, prompt_embeds=pe, negative_prompt_embeds=ne) for i in range(3)]
+    want = [mk().process(**r) for r in reqs]
+    fronts = []
+    for p_ in (inpaint, tile):
+        orig = p_.front
+        p_.front = (lambda o: (lambda **kw: (fronts.append(kw["prompt_embeds"].shape[0]), o(**kw))[1]))(orig)
+    try:
+        got = mk().process_many(reqs, merge=2)
+    finally:
+        for p_ in (inpaint, tile):
+            del p_.front
+    assert fronts == [2, 1, 2, 1], fronts              # per stage: one merged pair + the left-over request
+    for r, ((rt_a, r_a, _, _), (rt_b, r_b, _, _)) in enumerate(zip(got, want)):
+        for a, b in zip(r_a + rt_a, r_b + rt_b):
+            d = np.abs(np.asarray(a, np.float32) - np.asarray(b, np.float32))
+            assert a.size == b.size and d.mean() <= 1.5 and np.percentile(d, 99) <= 8, (r, float(d.mean()), float(d.max()))
+    assert np.abs(np.asarray(got[0][1][0], np.float32) - np.asarray(got[1][1][0], np.float32)).mean() > 2, "requests differ"
