@@ -65,10 +65,18 @@ for spec in (sys.argv[1:] or ["base"]):
             e1.record()
             torch.cuda.synchronize()
             rounds.append(round(e0.elapsed_time(e1) / 10, 3))
+        # host cost of ONE replay into an idle queue (no back-pressure: the device is drained first) against its device time
+        host = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            graph.replay()
+            host.append(round((time.perf_counter() - t1) * 1e3, 3))
+            torch.cuda.synchronize()
         o = out.float().clone()
     if ref is None or ref.shape != o.shape:
         ref = o
-    print(json.dumps({"config": name, "options": opts, "images": nimg, "ms_per_eval": min(rounds), "ms_per_eval_per_image": round(min(rounds) / nimg, 3), "rounds_ms": rounds, "setup_s": setup,
+    print(json.dumps({"config": name, "options": opts, "images": nimg, "ms_per_eval": min(rounds), "host_ms_to_submit_one_replay": min(host), "ms_per_eval_per_image": round(min(rounds) / nimg, 3), "rounds_ms": rounds, "setup_s": setup,
                       "rel_l2_vs_first_config": round(float((o - ref).norm() / ref.norm()), 6), "finite": bool(torch.isfinite(o).all())}),
           flush=True)
     del graph, den
