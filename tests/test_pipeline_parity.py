@@ -347,7 +347,7 @@ def test_reference_only_per_module_banks_and_mixes_vs_reference_trace(mg, tiny):
     shows over eight independent draws of 2e-3 feature noise) -- round 5: the bound used to be 3 x ONE draw, a noisy estimate
     (the eight-draw maximum is up to 3.7 x the first draw at the ill-conditioned 4 x 4 points, 1.13 x at the median), which a
     mere change of the GELU's rounding pattern crossed at four points whose error EQUALS the reference's own movement.
-    20 of the 26 read-pass points sit below 5e-2, the worst (4 x 4 level) at 0.28."""
+    13 of the 26 read-pass points sit below 5e-2, the worst (4 x 4 level) at 0.23 (round 6 record)."""
     from editanything_amd import reference_only as ro
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintPipeline
     g = np.load(os.path.join(GOLD, "pipe_refonly.npz"))
@@ -386,6 +386,14 @@ def test_reference_only_per_module_banks_and_mixes_vs_reference_trace(mg, tiny):
         table.append((i, kind, round(err, 4), round(tol, 4)))
     print("reference-only per-point (index, kind, rel-L2, bound):", table)
     assert not bad, "\n".join(bad)
+    # aggregate guards beside the per-point bounds (round-5 advisor: the wider per-point bound must not absorb a regression): the
+    # BULK of the read-pass points and an absolute cap per kind, from the recorded per-point errors -- round 6, MI355X: banks
+    # 1.2e-3 .. 2.2e-3; read pass 13 of 26 points <= 5e-2 (8 of them <= 3e-3), median 5.4e-2, the ill-conditioned 4 x 4 / 8 x 8 points
+    # 0.10 .. 0.23 against bounds of 0.15 .. 0.33 (profiles/r06_reference_only_per_point.json)
+    reads = sorted(e for _, k_, e, _ in table if k_ != "save")
+    assert sum(1 for e in reads if e <= 5e-2) >= 12, reads
+    assert reads[len(reads) // 2] <= 7e-2, ("median of the read-pass points", reads[len(reads) // 2])
+    assert worst.get("save", 0.0) <= 1.5e-2 and max(v for k_, v in worst.items() if k_ != "save") <= 0.35, worst
     print("reference-only per-module trace:", len(trace), "points, worst rel-L2 per kind", {k: round(v, 4) for k, v in worst.items()})
     assert rel_l2(out, g["refonly_trace_latents"]) <= max(1.5e-2, 1.5 * float(sens.max()))
 
