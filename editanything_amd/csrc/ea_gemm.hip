@@ -201,7 +201,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10) ? 128 : 256;   // 3..6, 8, 13: 256 rows
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12 || g_variant == 32) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 31) ? 128 : 256;   // 3..6, 8, 13: 256 rows; 31 / 32: intra-workgroup split-K (KS = 2) on 128- / 64-row tiles
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
@@ -231,14 +231,35 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   // a +4..9 % microbenchmark.  Re-measured with tools/gemm_bench in graph replay -- how the product runs -- it is 1.65x
   // SLOWER than the two-workgroup 128-row tiles on exactly those launches (117 vs 70 us for conv3x3 B8 64x64 320->320,
   // profiles/r01x_gemm_bench.jsonl): kind 11 stays reachable through EA_GEMM2_VARIANT only.)
+#if EA_TOOLS && (EA_EXP & 256)
+  // EXPERIMENT (round 6, tools builds with EA_EXP & 256): intra-workgroup split-K (kind 32: 64-row tiles, two K streams per
+  // workgroup, ea_gemm2.h KS = 2) where the 64-row tiles give every CU at most ONE workgroup and a K stream has 8 .. 64 K tiles --
+  // the classes where the forced sweep has it ahead of the plan above (profiles/r06_intra_wg_splitk_sweep.jsonl): M = 2048 / 512
+  // linears at K = 1280, the 8 x 8 and stride-2 convolutions (with 2 - 4 K slices across workgroups on top), the 1 x 1 convolutions
+  if (g_variant == 0 && g_force_splits == 0 && !geglu && batch == 1) {
+    const long long tiles64 = (long long)((M + 63) / 64) * ((N + t.bn - 1) / t.bn);
+    if (tiles64 <= 256) {
+      int s = 1;
+      while (allow_split && tiles64 * (s * 2) <= 256 && nk / (s * 2) >= 8 && s * 2 <= 16) s *= 2;
+      if (nk / s >= 8 && nk / s <= 64) {
+        t.kind = 32; t.bm = 64;
+        t.ktiles_per_split = (nk + s - 1) / s;
+        t.splits = (nk + t.ktiles_per_split - 1) / t.ktiles_per_split;
+      }
+    }
+  }
+#endif
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
 
+// instantiations that carry the register-direct epilogue of the planned 2-stage tiles (fold / statistics / raw split-K dump)
+static bool tr_plan_kind(int k) { return k == 1 || k == 9 || (EA_TOOLS && (k == 31 || k == 32)); }
+
 // rows per GroupNorm-statistics chunk of plan t (its wave tile height), 0 = the epilogue cannot emit them: the wave
 // tiles (bm/2 x bn/2) must hold whole groups and row ranges inside one sample
 static int gn_stats_rows(const Plan2& t, int M, int N, int hw, int cpg) {
-  if (t.splits != 1 || (t.kind != 1 && t.kind != 9) || g_no_tr) return 0;
+  if (t.splits != 1 || !tr_plan_kind(t.kind) || g_no_tr) return 0;
   const int wtm = t.bm / 2, wtn = t.bn / 2;
   if (hw <= 0 || cpg < 8 || (M % hw) || (hw % wtm) || (wtn % cpg) || (N % t.bn) || (N % cpg)) return 0;
   // a workgroup tile must not straddle two samples: the launches that ask for the partials carry a per-sample row
@@ -535,7 +556,7 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
   }
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
-  const bool tr_kind = t.kind == 1 || t.kind == 9 || t.kind == 30 || (EA_TOOLS && t.kind == 24);
+  const bool tr_kind = t.kind == 1 || t.kind == 9 || t.kind == 30 || (EA_TOOLS && (t.kind == 24 || t.kind == 31 || t.kind == 32));
   const bool tr_raw = t.splits > 1 && !g_no_tr && tr_kind && (p.N & 3) == 0 && p.debug != 9;
   const bool tr = tr_raw || p.epi_fast == 3 ||
                   ((p.epi_fast == 1 || p.epi_fast == 4) && !g_no_tr && tr_kind && (((uintptr_t)p.epi.bias) & 15) == 0 &&
@@ -623,6 +644,28 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
         ea_allow_big_lds(kfn, smem);
         EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);
       }
+    } else
+#endif
+#if EA_TOOLS
+    // kinds 31 / 32 (experiment, round 6): intra-workgroup split-K -- 8 waves = two K streams with their own stage rings,
+    // accumulators summed through LDS (ea_gemm2.h KS = 2); one workgroup per CU
+    if (t.kind == 31 || t.kind == 32) {
+      if (q || p.epi_fast == 3 || p.acc_scale_kt > 0) return EA_ERR_UNSUPPORTED;
+#define EA_LAUNCH_KS2(BM_, BN_, TR_)                                                  \
+  do {                                                                                \
+    auto kfn = ea_gemm2_ks2_kernel<BM_, BN_, TR_>;                                    \
+    const int smem = 2 * 2 * (BM_ + BN_) * 128;                                       \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(512, 1, 1), smem, stream, p);                           \
+  } while (0)
+      if (t.kind == 31) {
+        if (t.bn == 160) { if (s.lnx) EA_LAUNCH_KS2(128, 160, 2); else EA_LAUNCH_KS2(128, 160, 1); }
+        else { if (s.lnx) EA_LAUNCH_KS2(128, 128, 2); else EA_LAUNCH_KS2(128, 128, 1); }
+      } else {
+        if (t.bn == 160) { if (s.lnx) EA_LAUNCH_KS2(64, 160, 2); else EA_LAUNCH_KS2(64, 160, 1); }
+        else { if (s.lnx) EA_LAUNCH_KS2(64, 128, 2); else EA_LAUNCH_KS2(64, 128, 1); }
+      }
+#undef EA_LAUNCH_KS2
     } else
 #endif
     if (t.kind == 30) {
@@ -792,7 +835,7 @@ extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
   }
 #endif
   Plan2 t = plan_fast(M, N, K, 1, 1, 0, 0);
-  return (t.splits == 1 && (t.kind == 1 || t.kind == 9) && !g_no_tr) ? 1 : 0;
+  return (t.splits == 1 && tr_plan_kind(t.kind) && !g_no_tr) ? 1 : 0;
 }
 
 extern "C" int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
@@ -801,7 +844,7 @@ extern "C" int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sa
   if (g_force_generic || g_no_tr || (g_variant != 0 && g_variant != 1 && g_variant != 9)) return 0;
   if (!gn_next_shape_ok(M, N, rows_per_sample, cpg)) return 0;
   const Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
-  return (t.splits > 1 && (t.kind == 1 || t.kind == 9)) ? 1 : 0;
+  return (t.splits > 1 && tr_plan_kind(t.kind)) ? 1 : 0;
 }
 
 extern "C" int ea_gemm_gn_stats_chunk_rows(int M, int N, int K, int conv, int rows_per_sample, int cpg) {

@@ -82,9 +82,17 @@ constexpr int ea_gemm2_occ(int bm, int bn, int nwaves, int stages) {
 // the same bytes takes 5-15 us, tools/probe_misc).  Same products and the same fp32 summation order as TR = 0.
 // The body is a device function of (problem, workgroup x index, workgroup z index) so that ONE grid can carry the tiles
 // of two problems (ea_gemm2_pair_kernel below).
-template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0>
+// KS = 2 (round 6, EXPERIMENT -- tools builds, variants 31 / 32): INTRA-WORKGROUP split-K.  The workgroup carries KS wave groups of
+// WM x WN waves; group g owns its own 2-stage ring and multiplies the K tiles g, g + KS, ... of the workgroup's K range into its own
+// accumulators (the groups share every barrier: they run the same steps on different K tiles), then the groups' accumulators are
+// summed through LDS and group 0 runs the register-direct epilogue.  What it is for: a launch whose tiles give every CU ONE 4-wave
+// workgroup has a latency-bound K loop (0.6 - 0.7 us per 64-deep K tile whatever the tile does: DMA -> barrier -> fragment reads);
+// two such workgroups per CU hide each other's latency but need split-K across workgroups -- fp32 partials through HBM and a
+// reduce launch.  With KS = 2 one workgroup has the two K streams and the reduction stays on chip.
+template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR = 0, int TR = 0, int KS = 1>
 __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int wg_x, const int wg_z) {
-  constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR);
+  constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR) * KS;
+  static_assert(KS == 1 || (KS == 2 && (TR == 1 || TR == 2) && STAGES == 2 && MT == 16 && !LDR && !ILV), "intra-workgroup split-K: register-direct 2-stage tiles");
   static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && STAGES == 2), "register-direct epilogue: the 2-stage 16x16x32 tiles");
   static_assert(!LDR || !ILV, "loader waves replace the interleaved issue");
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -102,7 +110,9 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
   const int lane = tid & 63;
   const int wave_all = ea_uniform(tid >> 6);
   const bool is_loader = LDR && wave_all >= NW;
-  const int wave = is_loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
+  const int grp = (KS > 1) ? ea_uniform(wave_all / NW) : 0;                                   // K-stream group (KS > 1)
+  const int wave = (KS > 1) ? wave_all - grp * NW : (is_loader ? wave_all - NW : wave_all);   // index among the loaders / among the compute waves
+  char* const smem_g = smem + grp * (STAGES * (BM + BN) * 128);                               // this group's stage ring
   const int wm = wave / WN, wn = wave % WN;
 
 #if !(EA_EXP & 64) && !defined(EA_EMU)
@@ -186,7 +196,8 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
   }
 
   const int ctot = p.c1 + p.c2;
-  int k_cur = kt_begin * EA_BK;  // first K element of the next tile to stage
+  int k_cur = (kt_begin + grp) * EA_BK;  // first K element of the next tile to stage (KS > 1: group g starts at its own tile)
+  const int nkg = (KS > 1) ? (nk > grp ? (nk - grp + KS - 1) / KS : 0) : nk;   // K tiles of this group
   int tap = 0, cin = 0;
   // conv: per-lane offsets for the current (tap, concat source); runs when either changes (every >= c/64 K tiles)
   auto set_voff = [&]() {
@@ -215,10 +226,10 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
   constexpr int PIECES = A_PW + B_PW;
   ea_rsrc is_rs_a = rs_a1;
   unsigned is_soff_a = 0, is_soff_b = 0;
-  char* is_sa = smem;
-  char* is_sb = smem;
+  char* is_sa = smem_g;
+  char* is_sb = smem_g;
   auto begin_issue = [&](int buf) {
-    is_sa = smem + buf * STAGE_BYTES;
+    is_sa = smem_g + buf * STAGE_BYTES;
     is_sb = is_sa + BM * 128;
     k_cur = ea_uniform(k_cur);   // loop-carried scalars: keep them provably wave-uniform (SGPR descriptors / offsets)
     cin = ea_uniform(cin);
@@ -237,6 +248,17 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     }
   };
   auto end_issue = [&]() {
+    if (KS > 1) {   // stride of KS tiles: taps / concat sources may be stepped over
+      k_cur += EA_BK * KS;
+      if (p.conv) {
+        const int tap0 = tap;
+        const bool sec0 = cin >= p.c1;
+        cin += EA_BK * KS;
+        while (cin >= ctot) { cin -= ctot; ++tap; }
+        if (tap != tap0 || (cin >= p.c1) != sec0) set_voff();
+      }
+      return;
+    }
     k_cur += EA_BK;
     if (p.conv) {
       cin += EA_BK;
@@ -310,7 +332,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
 #define EA_LOADF(ks_, slot_) load_frags(buf, (ks_), (slot_))
 #else
   auto compute_tile = [&](int buf, bool ilv_issue = false) {
-    const char* sa = smem + buf * STAGE_BYTES;
+    const char* sa = smem_g + buf * STAGE_BYTES;
     const char* sb = sa + BM * 128;
     constexpr int KSTEPS = (MT == 16) ? 2 : 4;
     constexpr int CH_PER_STEP = (MT == 16) ? 4 : 2;
@@ -444,7 +466,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
       }
     }
   } else if (STAGES == 2) {
-    if (nk > 0) issue_tile(0);
+    if (nkg > 0) issue_tile(0);
     ln_prologue();
 #ifndef EA_EMU
     // Two co-resident workgroups that start together run their DMA-issue and MFMA phases in lockstep (both contend
@@ -453,7 +475,8 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     // (measured +8..12 % on the 512-tile 64x64-level convolutions; a speed heuristic only, never correctness).
     if (!EA_DBG(8) && ((wg_x >> 8) & 1)) __builtin_amdgcn_s_sleep(10);
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
+    const int nk_steps = (KS > 1) ? (nk + KS - 1) / KS : nk;   // (KS > 1: every group walks the same number of barriers)
+    for (int kt = 0; kt < nk_steps; ++kt) {
       // waits for this wave's own LDS-DMA (vmcnt(0), emitted by the fence) and then for everyone's: tile kt is complete
       // in LDS and every wave has finished reading the buffer tile kt+1 is about to overwrite.
       if (!EA_DBG(12)) __syncthreads();                               // debug 12: compute only, no barrier either
@@ -466,7 +489,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
       __builtin_amdgcn_sched_barrier(0);
       compute_tile(kt & 1, false, true);
 #else
-      if (kt + 1 < nk && !EA_DBG(11) && !EA_DBG(12)) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
+      if (kt + 1 < nkg && !EA_DBG(11) && !EA_DBG(12)) issue_tile((kt + 1) & 1);   // debug 11: no staging after the first tile
       if (MT == 16 && p.acc_scale_kt > 0 && kt_begin + kt == p.acc_scale_kt) {
         // K-concatenated split operands (ea_epilogue.acc_scale_k): the correction products are in, scale them (exactly:
         // a power of two) before the hi x hi product is accumulated on top
@@ -477,7 +500,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] *= p.acc_scale;
       }
-      if (!EA_DBG(10)) compute_tile(kt & 1);                         // debug 10: staging only
+      if (!EA_DBG(10) && kt < nkg) compute_tile(kt & 1);             // debug 10: staging only
 #endif
     }
   } else if (ILV == 2) {
@@ -668,7 +691,29 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     //    part = (column of the wave tile) / WTN -- what the next launch's LayerNorm fold consumes.
     if constexpr (TR != 0) {
       EA_STAMP(2);
-      ea_tr_epilogue<MI, NI, TR, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem, wave);
+      if constexpr (KS > 1) {
+        // the K streams meet: group 1's accumulators go through LDS (the stage rings are free after the barrier; one 16-byte
+        // slot per lane and register quad, lane-linear: conflict-free), group 0 adds them in and owns the epilogue
+        constexpr int RED_BYTES = MI * NI * NW * 64 * 16;
+        static_assert(RED_BYTES + NW * 288 <= KS * STAGES * (BM + BN) * 128, "reduction slots + GroupNorm bins must fit the rings");
+        f32x4* red = reinterpret_cast<f32x4*>(smem);
+        __syncthreads();
+        if (grp == 1) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) red[((i * NI + j) * NW + wave) * 64 + lane] = acc[MT == 16 ? i : 0][MT == 16 ? j : 0];
+        }
+        __syncthreads();
+        if (grp != 0) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[MT == 16 ? i : 0][MT == 16 ? j : 0] += red[((i * NI + j) * NW + wave) * 64 + lane];
+        ea_tr_epilogue<MI, NI, TR, false>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem + RED_BYTES, wave);
+      } else {
+        ea_tr_epilogue<MI, NI, TR, true>(p, acc, m0 + wm * WTM, n0 + wn * WTN, m0, batch, bz, ln_mu, ln_rs, smem, wave);
+      }
       EA_STAMP(4);
     }
     return;
@@ -1054,6 +1099,13 @@ template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR =
 __global__ __launch_bounds__(WM* WN * 64 * (1 + LDR), (LDR ? (STAGES == 2 && BM == 64 ? 4 : 2) : ea_gemm2_occ(BM, BN, WM* WN, STAGES)))
 void ea_gemm2_kernel(EaGemmParams p) {
   ea_gemm2_tile<BM, BN, WM, WN, STAGES, MT, ILV, LDR, TR>(p, blockIdx.x, blockIdx.z);
+}
+
+// intra-workgroup split-K (KS = 2, round-6 experiment): 8 waves, two stage rings, one workgroup per CU
+template <int BM, int BN, int TR>
+__global__ __launch_bounds__(512, 1)
+void ea_gemm2_ks2_kernel(EaGemmParams p) {
+  ea_gemm2_tile<BM, BN, 2, 2, 2, 16, 0, 0, TR, 2>(p, blockIdx.x, blockIdx.z);
 }
 
 // TWIN launch: two problems of ONE shape and plan (same M, N, K, tile plan, split-K factor, epilogue form -- the host

@@ -17,7 +17,7 @@ def pytest_collection_modifyitems(config, items):
     """The product library carries no opt-in / experiment instantiation (EA_TOOLS builds only: the CPU emulation is one), so a
     (`gpu` backend x tools-only variant) parametrisation can never run: it is not collected at all, instead of showing up as
     119 permanent skips in every GPU run (round-5 verdict).  The emulation side of the same parametrisations stays."""
-    tools_only = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 22, 23, 24}       # = test_kernels.TOOLS_ONLY_VARIANTS
+    tools_only = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 22, 23, 24, 31, 32}       # = test_kernels.TOOLS_ONLY_VARIANTS
     keep, drop = [], []
     for it in items:
         cs = getattr(it, "callspec", None)

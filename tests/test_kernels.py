@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from emu_util import conv_src, epilogue, ptr, relerr
 
 
-TOOLS_ONLY_VARIANTS = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 22, 23, 24}   # opt-in instantiations: EA_TOOLS builds only (ea_gemm2.h; 20-23: tools/kernels/ea_gemm3.h)
+TOOLS_ONLY_VARIANTS = {2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 20, 21, 22, 23, 24, 31, 32}   # opt-in instantiations: EA_TOOLS builds only (ea_gemm2.h; 20-23: tools/kernels/ea_gemm3.h)
 
 
 def tune(kb, **fields):
@@ -891,6 +891,63 @@ def test_register_direct_epilogue(kb, M, N, K, act, res, rowvec, variant, monkey
     if res:
         ref = ref + t(R)
     assert relerr(outs[0], ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("variant", [31, 32])      # intra-workgroup split-K on 128- / 64-row tiles (ea_gemm2.h KS = 2: round-6 experiment)
+@pytest.mark.parametrize("M,N,K,act,res,rowvec,splits", [
+    (256, 320, 128, 0, True, False, 0),      # 2 K tiles: one per K stream
+    (200, 160, 192, 1, False, False, 0),     # 3 K tiles: the streams get 2 and 1 (uneven), ragged M
+    (130, 192, 64, 2, True, False, 0),       # ONE K tile: the second stream has nothing to multiply; 128-wide column tiles, ragged N
+    (256, 256, 448, 1, False, True, 0),      # 7 K tiles, per-sample row vector
+    (128, 320, 1024, 0, True, False, 2),     # split-K across workgroups on top (2 slices x 8 tiles, each walked as two streams) + reduce launch
+])
+def test_intra_workgroup_split_k(kb, variant, M, N, K, act, res, rowvec, splits):
+    """ea_gemm2.h KS = 2: a workgroup of 8 waves = two K streams (tiles g, g + 2, ... of its K range, own 2-stage ring each, shared
+    barriers), accumulators summed through LDS, epilogue by the first stream -- against torch, and against the planned instantiation
+    (another fp32 summation order: K tiles interleaved between two accumulators, so equal to fp16 rounding, not bit for bit)."""
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    rv = f32(M // 128, N) if rowvec else None
+    outs = []
+    for v in (variant, 0):
+        tune(kb, variant=v, splits=splits)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias, act=act, scale=0.75, residual=R, rowvec=rv, rows_per_group=128 if rowvec else 1)
+        ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1) + (splits or 1) * M * N * 4)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).astype(np.float32))
+    ref = t(A) @ t(W).T + t(bias)
+    if rowvec:
+        ref = ref + t(rv).repeat_interleave(128, 0)
+    ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+    assert relerr(outs[0], outs[1]) < 1e-3
+
+
+@pytest.mark.parametrize("variant", [31, 32])
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride", [
+    (2, 16, 16, 64, 0, 160, 1),        # 9 taps x 1 chunk: the streams alternate TAPS
+    (1, 16, 16, 128, 64, 160, 1),      # concat of two sources, 3 chunks per tap: a stream steps over the source boundary and over taps
+    (2, 16, 16, 64, 0, 320, 2),        # stride 2
+])
+def test_intra_workgroup_split_k_conv(kb, variant, B, H, W, c1, c2, cout, stride):
+    """... the same for the implicit-GEMM convolution: the incremental im2col state of a stream advances TWO K tiles at a time."""
+    x1 = f16(B, H, W, c1)
+    x2 = f16(B, H, W, c2) if c2 else None
+    w, bias = f16(cout, c1 + c2, 3, 3, scale=0.1), f32(cout)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    tune(kb, variant=variant)
+    src = conv_src(x1, x2, None, 3, stride, 1, 0, Ho, Wo)
+    out = kb.zeros((B * Ho * Wo, cout), np.float16)
+    e = epilogue(out, bias=bias, act=1)
+    ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(B * Ho * Wo, cout, 9 * (c1 + c2), 1))
+    assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(pack_conv_w(w)), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
+    ref = F.silu(F.conv2d(xin.permute(0, 3, 1, 2), t(w), t(bias), padding=1, stride=stride)).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert relerr(kb.down(out), ref.numpy()) < 3e-3
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout,act,res", [
