@@ -204,6 +204,8 @@ def merge_kwargs(pipe, kws):
     geos = [_request_geometry(kw) for kw in kws]
     if any(g is None or g[2:] != geos[0][2:] for g in geos):
         return None
+    if len({tuple(kw["prompt_embeds"].shape[1:]) for kw in kws if torch.is_tensor(kw.get("prompt_embeds"))}) > 1:
+        return None                                       # (different token counts: long-prompt embeddings of another length)
     height, width = geos[0][2:]
     do_cfg = float(k0.get("guidance_scale", 7.5)) > 1.0
     dev = pipe.device
@@ -251,9 +253,12 @@ def merge_kwargs(pipe, kws):
             return None
         if tuple(kw["latents"].shape) != (n_img, 4, height // 8, width // 8):
             return None
-        parts["pe"].append(rows(pe, b, nipp))
+        pe_r, ne_r = rows(pe, b, nipp), (rows(ne, b, nipp) if do_cfg else None)
+        if pe_r is None or (do_cfg and ne_r is None) or (do_cfg and ne_r.shape[1:] != pe_r.shape[1:]):
+            return None
+        parts["pe"].append(pe_r)
         if do_cfg:
-            parts["ne"].append(rows(ne, b, nipp))
+            parts["ne"].append(ne_r)
         parts["lat"].append(kw["latents"])
         for j, t in enumerate(c):
             r = rows(t, b, nipp)
@@ -265,9 +270,12 @@ def merge_kwargs(pipe, kws):
             if vn is None or img.shape[0] != msk.shape[0] or vn.shape[0] != img.shape[0] or img.shape[-2:] != (height, width) \
                     or msk.shape[-2:] != (height, width) or (img.shape[0] not in (1, n_img) and not (nipp == 1 and img.shape[0] == b)):
                 return None                               # (b images x n per prompt: `front` TILES the encoded batch; keep out)
-            parts["img"].append(rows(img, b, nipp))
-            parts["msk"].append(rows(msk, b, nipp))
-            parts["vn"].append(rows(vn, b, nipp))
+            trio = [rows(t, b, nipp) for t in (img, msk, vn)]
+            if any(t is None for t in trio):
+                return None
+            parts["img"].append(trio[0])
+            parts["msk"].append(trio[1])
+            parts["vn"].append(trio[2])
         sizes.append(n_img)
     cat = lambda ts: torch.cat([t.to(dev) for t in ts])
     out = {k: v for k, v in k0.items() if k in _MERGE_SAME}
