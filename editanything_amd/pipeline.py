@@ -770,7 +770,7 @@ class StableDiffusionControlNetInpaintPipeline:
                 step()
             restore()
             return g
-        if not ops.nondefault_priority_streams():
+        if not ops.nondefault_priority_streams() or ref is not None:      # (reference-only steps are captured per CALL: not worth 3 - 5 captures)
             return instantiate()
         # at least three instantiations, at most five; done once two of them sit within 10 % of the fastest seen (slow ones are
         # 1.3 x and more off, about one in three, and CAN be consecutive: two agreeing attempts alone prove nothing)
