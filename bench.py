@@ -17,8 +17,9 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")     # before HIP initialises: see editanything_amd/__init__.py
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

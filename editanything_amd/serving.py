@@ -70,8 +70,10 @@ def make_stream(device, priority, cu_count=0):
     hardware queues of mixed priority levels.  It hit bench.py's later captures (c4 / c5 lines -30 %, the batch sweep's network batch
     16) and would hit a server that meets a new request shape after its runner exists.  The low-priority stream stays the default
     (same-box: with_amg through the runner 10.30 vs 9.87 images/s at priority 0; headline gain 1.016 - 1.02 vs 1.005 - 1.016), and the
-    cure sits where the damage is: `pipeline._capture` validates its instantiations whenever such a stream exists
-    (`ops.note_nondefault_priority_stream`): three to five instantiations, timed, the fastest kept (profiles/r06_side_stream_priority.jsonl)."""
+    cure is at the root: the package runs the ROCm runtime with TWO hardware queues per priority level (`GPU_MAX_HW_QUEUES=2`,
+    editanything_amd/__init__.py) -- no slow instantiation at all, nothing of this path slower; as a net for deployments that set the
+    variable themselves, `pipeline._capture` validates its instantiations whenever such a stream exists
+    (`ops.note_nondefault_priority_stream`): three to five, timed, the fastest kept (profiles/r06_side_stream_priority.jsonl)."""
     import ctypes
     hip = ctypes.CDLL("libamdhip64.so")
     h = ctypes.c_void_p()

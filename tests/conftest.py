@@ -1,7 +1,8 @@
 import os
 import sys
 
-import pytest
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")     # the package's deployment default, set before anything initialises HIP
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):

@@ -65,6 +65,9 @@ with torch.no_grad():
         r = serving.PipelinedRunner(pipe, overlap=True, side_priority=prio)
         r.run([req(10 + i) for i in range(12)])
         torch.cuda.synchronize()
+        if "novalidate=1" in sys.argv:      # the raw phenomenon: pipeline._capture takes its first instantiation
+            from editanything_amd import ops as _ops
+            _ops._NONDEFAULT_PRIORITY_STREAMS[0] = 0
         if "close=1" in sys.argv:
             r.close()
         log(step="an overlapped runner served 12 requests", side_priority=prio, closed="close=1" in sys.argv)
