@@ -294,6 +294,24 @@ def merge_kwargs(pipe, kws):
     return out, sizes
 
 
+def merge_key(pipe, kw):
+    """What two calls must share to be rows of one merged call, as a hashable key (None: this call merges with nothing): the
+    `_MERGE_SAME` arguments, the geometry, inpaint or not, the number of ControlNet images, CFG on or off."""
+    kw = getattr(pipe, "normalize_kwargs", dict)(kw)
+    if not mergeable_alone(kw):
+        return None
+    geo = _request_geometry(kw)
+    c = kw.get("controlnet_conditioning_image")
+    freeze = lambda v: tuple(freeze(x) for x in v) if isinstance(v, (list, tuple)) else (tuple(sorted(v.items())) if isinstance(v, dict) else v)
+    try:
+        key = (geo[2:], kw.get("image") is not None, len(c) if isinstance(c, (list, tuple)) else 1,
+               tuple(freeze(kw.get(k)) for k in _MERGE_SAME))
+        hash(key)
+    except TypeError:
+        return None
+    return key
+
+
 def split_output(out, sizes):
     """The per-request outputs of a merged call (rows in request order)."""
     from .pipeline import StableDiffusionPipelineOutput
@@ -307,7 +325,7 @@ def split_output(out, sizes):
 
 
 class PipelinedRunner:
-    def __init__(self, pipe, overlap=False, side_stream=None, threaded=True, side_priority=1, side_cus=0, merge=1):
+    def __init__(self, pipe, overlap=False, side_stream=None, threaded=True, side_priority=1, side_cus=0, merge=1, regroup=False):
         """threaded: the side stream's stages are issued by ONE persistent worker thread while the calling thread issues
         the denoising loops.  hipGraphLaunch returns only when the launch is queued, and the 20 replays of a loop (~40 000
         packets) do not fit a hardware queue, so the thread that issues a loop is held for most of the loop's duration:
@@ -317,6 +335,7 @@ class PipelinedRunner:
         self.pipe = pipe
         self.device = pipe.device
         self.merge = int(merge)    # consecutive requests evaluated as one batched call where they can be (merge_kwargs)
+        self.regroup = bool(regroup)    # merge > 1: gather the mergeable requests of a queue by compatibility class first (run)
         self._cold = True          # no request has gone through yet: see `run`
         self.overlap = bool(overlap)
         self.threaded = threaded and self.overlap
@@ -465,7 +484,32 @@ class PipelinedRunner:
         batched call."""
         requests = list(requests)
         merge = max(1, int(self.merge if merge is None else merge))
-        units = [requests[i:i + merge] for i in range(0, len(requests), merge)]
+        gens = [g for r in requests if isinstance(r, dict) for g in (r.get("generator") if isinstance(r.get("generator"), (list, tuple)) else [r.get("generator")])]
+        private = all(g is not None for g in gens) and len({id(g) for g in gens}) == len(gens)     # (a shared / global generator fixes the order)
+        if self.regroup and merge > 1 and requests and private and all(isinstance(r, dict) for r in requests):
+            # requests of one compatibility class (`merge_key`) are served together whatever lies between them in the queue --
+            # [512^2, 768^2, 512^2, 768^2] becomes two merged pairs instead of four single calls; every request still gets ITS
+            # output, returned in the caller's order (only the order of execution changes; requests given as callables are not
+            # looked into and keep their place)
+            order, classes = [], {}
+            for i, r in enumerate(requests):
+                classes.setdefault(merge_key(self.pipe, r) or ("alone", i), []).append(i)
+            for members in classes.values():
+                order.extend(members)
+            outs = self._run_units([requests[i] for i in order], merge, [len(v) for v in classes.values()])
+            res = [None] * len(requests)
+            for i, o in zip(order, outs):
+                res[i] = o
+            return res
+        return self._run_units(requests, merge, [len(requests)])
+
+    @torch.no_grad()
+    def _run_units(self, requests, merge, class_sizes):
+        """`run` for a request list whose consecutive runs of `class_sizes` requests each form units of up to `merge`."""
+        units, lo = [], 0
+        for n_cls in class_sizes:
+            units += [requests[i:min(i + merge, lo + n_cls)] for i in range(lo, lo + n_cls, merge)]
+            lo += n_cls
         n = len(units)
         if n == 0:
             return []

@@ -276,3 +276,53 @@ def test_merge_kwargs_concatenates_requests_and_keeps_each_request_its_own_draws
                                 [serving.predraw(pipe, kw) for kw in (_merge_req(1), _merge_req(2))]) is None
     out = serving.split_output(types.SimpleNamespace(images=torch.arange(6)), [2, 1, 3])
     assert [o.images.tolist() for o in out] == [[0, 1], [2], [3, 4, 5]]
+
+
+def test_runner_regroups_a_queue_by_compatibility_class():
+    """serving.PipelinedRunner(merge=2, regroup=True): the mergeable requests of a queue are gathered by compatibility class
+    (`merge_key`: size, steps, scales, inpaint or not ...) before units are formed -- [A512, B768, A512, B768, A512] runs as
+    (A, A), (A), (B, B) -- and every request's output comes back at ITS place.  A generator object shared by two requests (or
+    `generator=None`: the global one) pins the order: no regrouping then."""
+    from editanything_amd import serving
+
+    class FakePipe:
+        device = torch.device("cpu")
+        unet = types.SimpleNamespace(cfg={"in_channels": 4})
+        text_encoder = None
+
+        def __init__(self):
+            self.fronts = []
+
+        def front(self, **kw):
+            self.fronts.append((kw["height"], kw["prompt_embeds"].shape[0]))
+            if kw.get("latents") is None:           # a call of its own draws for itself, like the pipeline
+                kw = dict(kw, latents=torch.randn((1, 4, kw["height"] // 8, kw["width"] // 8), generator=kw["generator"]))
+            return types.SimpleNamespace(kw=kw, gkey=None)
+
+        def has_graph(self, c):
+            return True
+
+        def loop(self, c):
+            c.final = c.kw["latents"][:, :1, :1, :1].flatten() + c.kw["height"]        # one number per image: its first latent + the size
+
+        def back(self, c):
+            return types.SimpleNamespace(images=c.final)
+    mk = lambda res, seed: dict(prompt_embeds=torch.zeros(1, 77, 8), negative_prompt_embeds=torch.zeros(1, 77, 8), height=res, width=res,
+                                controlnet_conditioning_image=torch.zeros(1, 3, res, res), num_inference_steps=4, guidance_scale=7.5,
+                                generator=torch.Generator().manual_seed(seed))
+    sizes = [512, 768, 512, 768, 512]
+    want = [float(torch.randn((1, 4, s // 8, s // 8), generator=torch.Generator().manual_seed(i))[0, 0, 0, 0]) + s for i, s in enumerate(sizes)]
+    pipe = FakePipe()
+    outs = serving.PipelinedRunner(pipe, merge=2, regroup=True).run([mk(s, i) for i, s in enumerate(sizes)])
+    assert pipe.fronts == [(512, 2), (512, 1), (768, 2)], pipe.fronts
+    assert np.allclose([float(o.images[0]) for o in outs], want, atol=1e-3)
+    pipe2 = FakePipe()
+    outs2 = serving.PipelinedRunner(pipe2, merge=2, regroup=False).run([mk(s, i) for i, s in enumerate(sizes)])
+    assert pipe2.fronts == [(512, 1), (768, 1), (512, 1), (768, 1), (512, 1)]          # consecutive pairs never match: own calls
+    assert np.allclose([float(o.images[0]) for o in outs2], want, atol=1e-3)
+    shared = torch.Generator().manual_seed(0)
+    pipe3 = FakePipe()
+    serving.PipelinedRunner(pipe3, merge=2, regroup=True).run([dict(mk(s, i), generator=shared) for i, s in enumerate(sizes)])
+    assert [f[0] for f in pipe3.fronts] == sizes, "a shared generator pins the order of execution"
+    assert serving.merge_key(pipe, mk(512, 0)) == serving.merge_key(pipe, mk(512, 9)) != serving.merge_key(pipe, mk(768, 0))
+    assert serving.merge_key(pipe, dict(mk(512, 0), callback=print)) is None
