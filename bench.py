@@ -283,6 +283,10 @@ def main():
                "host_ms_issuing_one_loop": host_ms, "pipelined_timeline_ms": timeline,
                "note": "sequential = SAM -> prepare -> loop -> decode of one batch after the other on one stream; latency = first "
                        "launch of a batch's SAM encode to the end of its VAE decode (device events; steady-state requests)"}
+    # the roofline leg right here -- the same kernels as the timed region, measured in the same thermal / clock state (at the END of
+    # a 20-step run with every extra the eager per-launch times read 7 - 12 % longer on the same box and build: 0.217 - 0.230 against
+    # 0.246, profiles/r06_bench_line_last_build_other_box.json -- sustained load, not the kernels)
+    roofline = roofline_leg(one_step, pipe, args) if (rank == 0 and not args.quick) else None
     # request merging (serving.PipelinedRunner(merge=2)): consecutive bs-4 requests evaluated pairwise as ONE network-batch-16 call --
     # the same `steps` batches of 4 images, every request with its own draws; reported BESIDE the headline (which stays one bs-4
     # request per evaluation, BASELINE config 2), one stream and two streams
@@ -370,7 +374,7 @@ def main():
         result.update(other_configs(args, dev, sds, pipe, sam))
         result.update(extras(args, dev, sds, pipe, sam, inp, init_image, mask_b, embeds_b, neg_b, elapsed / args.steps, phases, runner))
     if rank == 0:
-        result["roofline"] = None if args.quick else roofline_leg(one_step, pipe, args)
+        result["roofline"] = roofline
         result["cpu_baseline"] = None
         if world == 1 and not args.no_cpu_baseline and not args.quick:
             result["cpu_baseline"] = cpu_baseline(sds, args)
