@@ -285,7 +285,7 @@ def main():
                        "launch of a batch's SAM encode to the end of its VAE decode (device events; steady-state requests)"}
     # the roofline leg right here -- the same kernels as the timed region, measured in the same thermal / clock state (at the END of
     # a 20-step run with every extra the eager per-launch times read 7 - 12 % longer on the same box and build: 0.217 - 0.230 against
-    # 0.246, profiles/r06_bench_line_last_build_other_box.json -- sustained load, not the kernels)
+    # 0.246, profiles/r06_bench_line_roofline_leg_at_the_end.json -- sustained load, not the kernels)
     roofline = roofline_leg(one_step, pipe, args) if (rank == 0 and not args.quick) else None
     # request merging (serving.PipelinedRunner(merge=2)): consecutive bs-4 requests evaluated pairwise as ONE network-batch-16 call --
     # the same `steps` batches of 4 images, every request with its own draws; reported BESIDE the headline (which stays one bs-4
