@@ -222,7 +222,13 @@ int ea_groupnorm_f16(const void* x1, int c1, const void* x2, int c2, const void*
 int ea_groupnorm_apply_f16(const void* x, int C, const float* gamma, const float* beta, void* out, int B, int HW,
                            int groups, float eps, int silu, const float* partial, int nchunk, void* stream);
 
-/* ResBlock half: out = epilogue(conv3x3(silu(groupnorm(cat(x1,x2+x2_add))))) -- one call.
+/* ResBlock half: out = epilogue(conv3x3(silu(groupnorm(cat(x1,x2+x2_add))))) -- one CALL, not one kernel: the GroupNorm (+SiLU)
+ * launches write the normalised activation to `norm_out`, the convolution launch reads it back (folding the normalise + SiLU into
+ * the convolution's operand staging would evaluate it once per tap: nine exponentials per input element against one read + one
+ * write of it, DESIGN.md / profiles/HISTORY.md 8d).  What IS fused around it: the statistics of this norm come from the epilogue
+ * of the launch that produced x1 where it can emit them (`gn_stats_out`, then the norm is the normalise pass alone), the split-K
+ * reduction of a producer applies the consuming norm (`gn_next_out`), and the convolution's epilogue carries bias, the
+ * time-embedding row vector, the skip add and the NEXT norm's statistics.
  * `norm_out` is caller scratch [B*Hin*Win*(c1+c2)] fp16 for the normalised activation. */
 int ea_groupnorm_silu_conv3x3(const ea_conv_src* src, const float* gamma, const float* beta, int groups,
                               float eps, void* norm_out, const void* W, int Cout, const ea_epilogue* epi,
