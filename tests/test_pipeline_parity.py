@@ -587,11 +587,15 @@ def test_step_graphs_instantiated_beside_a_low_priority_stream_all_replay_at_ful
     for i in range(8):
         pipe._graphs.clear()
         pipe(generator=torch.Generator("cpu").manual_seed(3), **kw)          # captures (and validates)
-        pipe.trace = []
-        out = pipe(generator=torch.Generator("cpu").manual_seed(3), **kw).images
-        torch.cuda.synchronize()
-        marks, pipe.trace = dict(pipe.trace), None
-        ms.append(marks["prepare(hint,text kv)"].elapsed_time(marks["denoise loop"]) / 6)
+        best = None
+        for _ in range(3):          # a slow INSTANTIATION is slow on every replay; one slow run of a fast one is the box (seen once:
+            pipe.trace = []         # 11.05 ms among 8.46 - 8.50, gpurun_out r06flake; 200 captures of the probe since: none) -> best of 3
+            out = pipe(generator=torch.Generator("cpu").manual_seed(3), **kw).images
+            torch.cuda.synchronize()
+            marks, pipe.trace = dict(pipe.trace), None
+            t = marks["prepare(hint,text kv)"].elapsed_time(marks["denoise loop"]) / 6
+            best = t if best is None else min(best, t)
+        ms.append(best)
         lats.append(out.float().cpu())
     print("ms per evaluation of eight successive captures beside a low-priority stream:", [round(m, 2) for m in ms])
     assert max(ms) <= 1.2 * min(ms), ms

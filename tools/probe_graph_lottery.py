@@ -81,6 +81,16 @@ with torch.no_grad():
             pipe.use_graph, ops.PROFILE = True, None
             _kw.pop((B, 512))
         log(step="eager 2-step runs of bs 1 / 8 / 16 with per-launch events")
+    many = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("many=")), 0)
+    if many:                        # distribution: N successive captures of the bs-1 step
+        ms = []
+        for _ in range(many):
+            drop(1, empty=False)
+            ms.append(eval_ms(1, 512))
+        srt = sorted(ms)
+        log(step="%d successive captures of bs 1" % many, min=srt[0], median=srt[len(srt) // 2], max=srt[-1],
+            slow_over_1p15x=sum(1 for m in ms if m > 1.15 * srt[0]), all=ms, hw_queues=os.environ.get("GPU_MAX_HW_QUEUES"))
+        sys.exit(0)
     log(step="fresh process: bs 4 (headline)", ms=eval_ms(4, 512))
     log(step="bs 1 captured right after", ms=eval_ms(1, 512))
     drop(1)
