@@ -175,7 +175,7 @@ int main(int argc, char** argv) {
   }
   std::string cases_sel = "all", out_path;
   std::vector<std::string> variants = {"auto"}, debugs = {"0"}, splits_opt = {"0"};
-  int iters = 20, rounds = 3, check = 0, geglu = 80;
+  int iters = 20, rounds = 3, check = 0, geglu = 80, rotate_mb = 0;
   for (int i = 2; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--cases" && i + 1 < argc) cases_sel = argv[++i];
@@ -189,6 +189,7 @@ int main(int argc, char** argv) {
     else if (a == "--bn" && i + 1 < argc) { g_bn = atoi(argv[++i]); setenv("EA_GEMM2_BN", argv[i], 1); }
     else if (a == "--slab-epilogue") { g_no_tr = 1; setenv("EA_GEMM2_TR", "0", 1); }   // A/B: no register-direct epilogue
     else if (a == "--out" && i + 1 < argc) out_path = argv[++i];
+    else if (a == "--rotate-mb" && i + 1 < argc) rotate_mb = atoi(argv[++i]);   // weight copies worth this many MB, rotated launch by launch
   }
   std::vector<Lib> libs;
   for (auto& p : split(argv[1], ',')) {
@@ -231,6 +232,23 @@ int main(int argc, char** argv) {
       A = dev_f16((size_t)M * K, 1.0f);
     }
     void* W = dev_f16((size_t)N * K, 1.0f / sqrtf((float)K));
+    // --rotate-mb X: the graph's launches walk through copies of W worth X MB in all (one launch = one copy), so a launch never
+    // finds its weights where the previous replay left them: X between the L2s' 32 MB and the 256-MB Infinity Cache = weights
+    // in the Infinity Cache but in no L2; X well above 256 = weights from HBM, as inside a denoising step (2.5 GB of weights per
+    // evaluation); 0 = one copy, hot in every cache (what every table of rounds 2-6 was measured with).  A stays one buffer: in
+    // the step it was written by the previous launch.
+    std::vector<void*> Wrot{W};
+    if (rotate_mb > 0) {
+      const size_t wb = (size_t)N * K * 2;
+      const size_t ncopy = std::min<size_t>(400, std::max<size_t>(2, ((size_t)rotate_mb << 20) / wb + 1));   // (tiny weights: capped -- they are no traffic)
+      for (size_t i = 1; i < ncopy; ++i) {
+        void* d;
+        HIP_CHECK(hipMalloc(&d, wb));
+        HIP_CHECK(hipMemcpy(d, W, wb, hipMemcpyDeviceToDevice));
+        Wrot.push_back(d);
+      }
+    }
+    const int iters_c = rotate_mb > 0 ? (int)std::max<size_t>(iters, Wrot.size()) : iters;
     void* bias = dev_f32(N, 0.1f);
     const int Nout = c.act == EA_ACT_GEGLU ? N / 2 : N;
     void* res = c.residual ? dev_f16((size_t)M * Nout, 1.0f) : nullptr;
@@ -245,10 +263,11 @@ int main(int argc, char** argv) {
       e.residual = res; e.ldr = Nout; e.out = o; e.ldc = Nout; e.geglu_block = c.act == EA_ACT_GEGLU ? geglu : 0;
       return e;
     };
-    auto launch = [&](Lib& l, void* o) {
+    auto launch = [&](Lib& l, void* o, int wi = 0) {
       ea_epilogue e = make_epi(o);
-      return c.conv ? l.conv(&src, W, N, &e, ws, ws_bytes, stream)
-                    : l.gemm(A, K, W, K, M, N, K, 1, 0, 0, 0, 0, &e, ws, ws_bytes, stream);
+      void* Wi = Wrot[(size_t)wi % Wrot.size()];
+      return c.conv ? l.conv(&src, Wi, N, &e, ws, ws_bytes, stream)
+                    : l.gemm(A, K, Wi, K, M, N, K, 1, 0, 0, 0, 0, &e, ws, ws_bytes, stream);
     };
     std::vector<_Float16> h_ref, h_test;
     if (check) {
@@ -283,7 +302,7 @@ int main(int argc, char** argv) {
       if (cf.st != 0) continue;
       hipGraph_t graph;
       HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      for (int i = 0; i < iters; ++i) launch(libs[cf.lib], o_test);
+      for (int i = 0; i < iters_c; ++i) launch(libs[cf.lib], o_test, i);
       HIP_CHECK(hipStreamEndCapture(stream, &graph));
       HIP_CHECK(hipGraphInstantiate(&cf.exec, graph, nullptr, nullptr, 0));
       HIP_CHECK(hipGraphDestroy(graph));
@@ -299,7 +318,7 @@ int main(int argc, char** argv) {
         HIP_CHECK(hipStreamSynchronize(stream));
         float ms;
         HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-        cf.us.push_back(ms * 1000.0f / iters);
+        cf.us.push_back(ms * 1000.0f / iters_c);
         if (check && cf.debug == "0") {
           HIP_CHECK(hipMemcpy(h_test.data(), o_test, h_test.size() * 2, hipMemcpyDeviceToHost));
           for (size_t i = 0; i < h_ref.size(); ++i) {
@@ -361,9 +380,9 @@ int main(int argc, char** argv) {
         const float best = cf.us.front(), med = cf.us[cf.us.size() / 2];
         int n = snprintf(line, sizeof line,
                          "{\"case\": \"%s\", \"lib\": \"%s\", \"variant\": \"%s\", \"debug\": \"%s\", \"splits\": \"%s\", \"us\": %.2f, \"us_median\": %.2f, "
-                         "\"tflops\": %.1f, \"mfma_frac\": %.4f",
+                         "\"tflops\": %.1f, \"mfma_frac\": %.4f, \"rotate_mb\": %d, \"weight_copies\": %d",
                          c.name.c_str(), libs[cf.lib].path.c_str(), cf.variant.c_str(), cf.debug.c_str(), cf.splits.c_str(), best, med,
-                         c.flops / best * 1e-6, c.flops / best * 1e-6 / 2500.0);
+                         c.flops / best * 1e-6, c.flops / best * 1e-6 / 2500.0, rotate_mb, (int)Wrot.size());
         if (check && cf.debug == "0") n += snprintf(line + n, sizeof line - n, ", \"max_abs_diff_vs_generic\": %.5g, \"nan_outputs\": %lld", cf.maxdiff, cf.bad);
         snprintf(line + n, sizeof line - n, "}");
         HIP_CHECK(hipGraphExecDestroy(cf.exec));
@@ -372,6 +391,7 @@ int main(int argc, char** argv) {
       fflush(stdout);
       if (out) { fputs(line, out); fputc('\n', out); fflush(out); }
     }
+    for (size_t i = 1; i < Wrot.size(); ++i) HIP_CHECK(hipFree(Wrot[i]));
     for (void* p : {A, A2, W, bias, res, rowvec, o_test, o_ref})
       if (p) HIP_CHECK(hipFree(p));
   }
