@@ -201,7 +201,7 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
   t.bm = 128; t.splits = 1; t.ktiles_per_split = nk; t.kind = 1;
   const int smax = allow_split ? 16 : 1;
   // candidate instantiations: auto = {128-row, 64-row} 2-stage tiles; a forced variant restricts to its own height
-  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12 || g_variant == 32) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 31) ? 128 : 256;   // 3..6, 8, 13: 256 rows; 31 / 32: intra-workgroup split-K (KS = 2) on 128- / 64-row tiles
+  const int forced_bm = (g_variant == 0) ? 0 : (g_variant == 9 || g_variant == 11 || g_variant == 12 || g_variant == 32 || g_variant == 33) ? 64 : (g_variant <= 2 || g_variant == 7 || g_variant == 10 || g_variant == 31 || g_variant == 34) ? 128 : 256;   // 3..6, 8, 13: 256 rows; 31 / 32: intra-workgroup split-K (KS = 2) on 128- / 64-row tiles
   const int cand_bm[2] = {128, 64};
   for (int ci = 0; ci < (forced_bm ? 1 : 2); ++ci) {
     const int bm = forced_bm ? forced_bm : cand_bm[ci];
@@ -249,12 +249,22 @@ static Plan2 plan_fast(int M, int N, int K, int batch, int allow_split, int conv
     }
   }
 #endif
+#if (EA_EXP & 512)
+  // EXPERIMENT (round 6, EA_EXP & 512): the 3-stage ring (kind 33) where the 64-row plan is unsplit, gives every CU at most ONE workgroup
+  // and the K loop is short (<= 24 tiles) -- the [M <= 2048 x N x 1280] Linears / 1 x 1 convolutions of the 16 x 16 and 8 x 8 levels.
+  // Their 2-stage loop waits out every tile's memory latency, and in a denoising step the weights come from HBM (2.5 GB per
+  // evaluation): tools/gemm_bench --rotate-mb 700 has [2048 x 1280 x 1280] at 21.7 us (2-stage) against 19.9 (3-stage), with
+  // cache-hot weights 16.1 against 19.8 (profiles/r06_three_stage_tr_forced_sweep.jsonl).
+  if (g_variant == 0 && g_force_splits == 0 && !geglu && batch == 1 && t.kind == 9 && t.splits == 1 && nk >= 8 && nk <= 24 &&
+      (long long)((M + 63) / 64) * ((N + t.bn - 1) / t.bn) <= 256)
+    t.kind = 33;
+#endif
   t.tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn);
   return t;
 }
 
 // instantiations that carry the register-direct epilogue of the planned 2-stage tiles (fold / statistics / raw split-K dump)
-static bool tr_plan_kind(int k) { return k == 1 || k == 9 || (EA_TOOLS && (k == 31 || k == 32)); }
+static bool tr_plan_kind(int k) { return k == 1 || k == 9 || k == 33 || k == 34 || (EA_TOOLS && (k == 31 || k == 32)); }
 
 // rows per GroupNorm-statistics chunk of plan t (its wave tile height), 0 = the epilogue cannot emit them: the wave
 // tiles (bm/2 x bn/2) must hold whole groups and row ranges inside one sample
@@ -520,7 +530,7 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
       p.epi_fast = 4;
     // register-direct GEGLU epilogue: 32-row packing on 128-wide tiles
     if (e.act == EA_ACT_GEGLU && e.geglu_block == 32) {
-      if (!(t.bn == 128 && t.splits == 1 && (t.kind == 1 || t.kind == 9) && !e.out_f32 && !e.residual && !e.residual32 &&
+      if (!(t.bn == 128 && t.splits == 1 && (t.kind == 1 || t.kind == 9 || t.kind == 33 || t.kind == 34) && !e.out_f32 && !e.residual && !e.residual32 &&
             !e.row_scale && !e.rowvec && !e.bias_per_row && (e.N & 7) == 0 && (e.ldc & 7) == 0 && (((uintptr_t)e.out) & 15) == 0 &&
             (((uintptr_t)e.bias) & 15) == 0 && (p.strideC & 7) == 0 && span < 0x7fffffffLL && p.batch == 1))
         return EA_ERR_UNSUPPORTED;
@@ -556,7 +566,7 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
   }
   // register-direct epilogue (ea_gemm2.h TR = 1): the plain streamlined launches of the 2-stage 128- / 64-row tiles
   // split-K slices: the register-direct raw dump (N % 4 == 0 keeps the 16-byte stores aligned); the reduce kernel follows
-  const bool tr_kind = t.kind == 1 || t.kind == 9 || t.kind == 30 || (EA_TOOLS && (t.kind == 24 || t.kind == 31 || t.kind == 32));
+  const bool tr_kind = t.kind == 1 || t.kind == 9 || t.kind == 30 || t.kind == 33 || t.kind == 34 || (EA_TOOLS && (t.kind == 24 || t.kind == 31 || t.kind == 32));
   const bool tr_raw = t.splits > 1 && !g_no_tr && tr_kind && (p.N & 3) == 0 && p.debug != 9;
   const bool tr = tr_raw || p.epi_fast == 3 ||
                   ((p.epi_fast == 1 || p.epi_fast == 4) && !g_no_tr && tr_kind && (((uintptr_t)p.epi.bias) & 15) == 0 &&
@@ -568,6 +578,9 @@ static int fast_select_plan(EaGemmParams& p, Plan2 t, void* workspace, size_t ws
   // ... and so do the GroupNorm partials (callers ask ea_gemm_gn_stats_chunk_rows first)
   if (p.epi.gn_stats_out && (!tr || t.splits > 1 || p.epi_fast != 1 || p.batch != 1 || !gn_stats_rows(t, p.M, p.N, p.epi.gn_hw, p.epi.gn_cpg)))
     return EA_ERR_UNSUPPORTED;
+  // kinds 33 / 34 (the 3-stage ring of the 64- / 128-row tiles) exist with the register-direct epilogue only: a launch that
+  // needs the LDS-slab epilogue runs the 2-stage instantiation of the same tile
+  if ((t.kind == 33 || t.kind == 34) && !tr) t.kind = (t.kind == 33) ? 9 : 1;
   s.t = t;
   s.tr = tr ? 1 : 0;
   s.tr_raw = tr_raw ? 1 : 0;
@@ -612,6 +625,13 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
     EA_LAUNCH(kfn, grid, dim3(WM_ * WN_ * 64 * (1 + LD_), 1, 1), smem, stream, p);    \
   } while (0)
 #define EA_LAUNCH_G2(BM_, BN_, WM_, WN_, ST_, MT_, IL_) EA_LAUNCH_G2L(BM_, BN_, WM_, WN_, ST_, MT_, IL_, 0)
+#define EA_LAUNCH_TR3(BM_, BN_, TR_)                                                  \
+  do {                                                                                \
+    auto kfn = ea_gemm2_kernel<BM_, BN_, 2, 2, 3, 16, 0, 0, TR_>;                     \
+    const int smem = 3 * (BM_ + BN_) * 128;                                           \
+    ea_allow_big_lds(kfn, smem);                                                      \
+    EA_LAUNCH(kfn, grid, dim3(256, 1, 1), smem, stream, p);                           \
+  } while (0)
 #define EA_LAUNCH_TR(BM_, BN_, TR_)                                                   \
   do {                                                                                \
     const int smem = 2 * (BM_ + BN_) * 128;                                           \
@@ -668,7 +688,19 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
 #undef EA_LAUNCH_KS2
     } else
 #endif
-    if (t.kind == 30) {
+    if (t.kind == 33 || t.kind == 34) {
+      // 3-stage ring under the register-direct epilogue (round 6): one workgroup per CU, two K tiles in flight -- for the launches
+      // whose tiles give a CU one workgroup anyway, where the 2-stage loop waits out every tile's memory latency and the
+      // weights come from HBM
+      if (q) return EA_ERR_UNSUPPORTED;
+      if (t.kind == 34) {
+        if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR3(128, 160, 2); else EA_LAUNCH_TR3(128, 160, 1); }
+        else { if (s.lnx) EA_LAUNCH_TR3(128, 128, 2); else EA_LAUNCH_TR3(128, 128, 1); }
+      } else {
+        if (t.bn == 160) { if (s.lnx) EA_LAUNCH_TR3(64, 160, 2); else EA_LAUNCH_TR3(64, 160, 1); }
+        else { if (s.lnx) EA_LAUNCH_TR3(64, 128, 2); else EA_LAUNCH_TR3(64, 128, 1); }
+      }
+    } else if (t.kind == 30) {
       if (s.lnx || q) return EA_ERR_UNSUPPORTED;
       auto kfn = ea_gemm8_kernel<1>;
       ea_allow_big_lds(kfn, EA_G8_LDS_BYTES);
@@ -697,6 +729,7 @@ static int fast_issue(const FastSel& s, EaGemmParams& p, EaGemmParams* q, void* 
     return st_tr;                  // (unsplit launches: row statistics, if asked for, were written by the epilogue)
   }
 #undef EA_LAUNCH_TR
+#undef EA_LAUNCH_TR3
   if (q) return EA_ERR_UNSUPPORTED;   // twins run on the register-direct instantiations only (launch_pair checks first)
   switch (t.kind) {
     case 1: if (t.bn == 160) EA_LAUNCH_G2(128, 160, 2, 2, 2, 16, 0); else EA_LAUNCH_G2(128, 128, 2, 2, 2, 16, 0); break;
@@ -790,6 +823,10 @@ static int launch_pair(EaGemmParams& p, EaGemmParams& q, void* workspace, size_t
     const size_t half = (ws_bytes / 2) & ~(size_t)255;
     int st = fast_select(p, workspace, half, 0, sp);
     if (st == EA_OK) st = fast_select(q, workspace, 2 * half, half, sq);
+    if (st == EA_OK) {        // a twin grid carries twice the workgroups: the 2-stage instantiation of the planned tile
+      if (sp.t.kind == 33 || sp.t.kind == 34) sp.t.kind = (sp.t.kind == 33) ? 9 : 1;
+      if (sq.t.kind == 33 || sq.t.kind == 34) sq.t.kind = (sq.t.kind == 33) ? 9 : 1;
+    }
     if (st == EA_OK && same_launch(sp, sq) && sp.tr && (sp.t.kind == 1 || sp.t.kind == 9) && p.debug == 0 && q.debug == 0)
       return fast_issue(sp, p, &q, stream);
     if (st != EA_OK && st != EA_ERR_WORKSPACE) return st;
@@ -841,7 +878,7 @@ extern "C" int ea_gemm_ln_fold_ok(int M, int N, int K) {
 extern "C" int ea_gemm_gn_next_ok(int M, int N, int K, int conv, int rows_per_sample, int cpg) {
   if (M < 32 || N < 64 || K <= 0 || (K % EA_BK) || (N % 8)) return 0;
   read_env();
-  if (g_force_generic || g_no_tr || (g_variant != 0 && g_variant != 1 && g_variant != 9)) return 0;
+  if (g_force_generic || g_no_tr || (g_variant != 0 && g_variant != 1 && g_variant != 9 && g_variant != 33 && g_variant != 34)) return 0;
   if (!gn_next_shape_ok(M, N, rows_per_sample, cpg)) return 0;
   const Plan2 t = plan_fast(M, N, K, 1, 1, conv ? 1 : 0, 0);
   return (t.splits > 1 && tr_plan_kind(t.kind)) ? 1 : 0;

@@ -93,7 +93,7 @@ template <int BM, int BN, int WM, int WN, int STAGES, int MT, int ILV, int LDR =
 __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int wg_x, const int wg_z) {
   constexpr int NW = WM * WN, NT = NW * 64 * (1 + LDR) * KS;
   static_assert(KS == 1 || (KS == 2 && (TR == 1 || TR == 2) && STAGES == 2 && MT == 16 && !LDR && !ILV), "intra-workgroup split-K: register-direct 2-stage tiles");
-  static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && STAGES == 2), "register-direct epilogue: the 2-stage 16x16x32 tiles");
+  static_assert(!TR || (MT == 16 && ILV == 0 && !LDR && (STAGES == 2 || STAGES == 3)), "register-direct epilogue: the 2- / 3-stage 16x16x32 tiles");
   static_assert(!LDR || !ILV, "loader waves replace the interleaved issue");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / MT, NI = WTN / MT;
@@ -388,7 +388,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
     // reads are spread one per two MFMAs of step s; only the first step's reads stay exposed.  Same register count, no
     // change in arithmetic order (bit-identical results); +1..3 % on every 2-stage launch measured
     // (profiles/r01x_gemm_bench.jsonl, "exp1").  EA_EXP & 16 switches it off for A/B builds.
-    if (!ILV && !LDR && STAGES == 2) {
+    if (!ILV && !LDR && (STAGES == 2 || (STAGES == 3 && TR))) {
       constexpr int RD = MI + NI, MF = MI * NI;
       __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
@@ -629,6 +629,7 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
       if (nk > 0) issue_tile(0);
       if (nk > 1) issue_tile(1);
     }
+    if (TR) ln_prologue();      // (its loads are waited for inside: both tiles land with them; the first counted wait below is then free)
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
       if (!LDR || is_loader) {
@@ -653,6 +654,14 @@ __device__ __forceinline__ void ea_gemm2_tile(const EaGemmParams& p, const int w
         if (more) end_issue();
       } else {
         if (kt + 2 < nk) issue_tile(cur >= 1 ? cur - 1 : 2);
+        if (TR && MT == 16 && p.acc_scale_kt > 0 && kt_begin + kt == p.acc_scale_kt) {      // K-concatenated split operands: see the 2-stage loop
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[MT == 16 ? i : 0][MT == 16 ? j : 0][r] *= p.acc_scale;
+        }
         compute_tile(cur);
       }
       cur = (cur == 2) ? 0 : cur + 1;

@@ -20,6 +20,7 @@ MI355X-first data flow (not the reference's NCHW module tree):
   * all 22 (10) time-embedding projections of the ResBlocks are one GEMM per step.
 """
 import math
+import os
 
 import torch
 
@@ -721,6 +722,12 @@ class ControlledDenoiser:
     def _streams(self, ngroups):
         """[(group stream, its ControlNet side stream)] per row group; group 0 runs on the caller's stream.  Streams and
         workspaces are created here, eagerly -- never inside a capture."""
+        if ngroups > 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 4:
+            # DESIGN 8h-9: a HIP graph captured over three or more streams segfaults in hipGraphLaunch when the process has fewer
+            # than four hardware queues per priority level (ROCm 7.2); the package's default is 2 (8h-6), which the shipped
+            # two-stream step is fine with
+            raise RuntimeError("ControlledDenoiser.split > 1 runs %d streams per evaluation: set GPU_MAX_HW_QUEUES=4 before HIP initialises "
+                               "(the package default of 2 only carries the two-stream step)" % (2 * ngroups))
         while len(self._strm) < ngroups:
             g = len(self._strm)
             self._strm.append((torch.cuda.Stream() if g > 0 else None, torch.cuda.Stream()))

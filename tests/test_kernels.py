@@ -893,6 +893,75 @@ def test_register_direct_epilogue(kb, M, N, K, act, res, rowvec, variant, monkey
     assert relerr(outs[0], ref.numpy()) < 2e-3
 
 
+@pytest.mark.parametrize("variant,twin", [(33, 9), (34, 1)])      # 3-stage ring, 64- / 128-row tiles, against the 2-stage instantiation of the same tile
+@pytest.mark.parametrize("M,N,K,act,res,rowvec,splits", [
+    (256, 320, 64, 0, True, False, 0),       # ONE K tile: nothing to keep in flight
+    (200, 160, 128, 1, False, False, 0),     # 2 K tiles, ragged M
+    (130, 192, 192, 2, True, False, 0),      # 3 K tiles = one lap of the ring; 128-wide column tiles, ragged N
+    (256, 256, 448, 1, False, True, 0),      # 7 K tiles, per-sample row vector
+    (128, 320, 1280, 0, True, False, 0),     # 20 K tiles (the [M x 1280 x 1280] Linears of the 16 x 16 / 8 x 8 levels)
+    (128, 320, 1024, 0, True, False, 2),     # split-K across workgroups on top: raw register-direct dump + reduce launch
+    (128, 160, 640, 0, False, False, 4),     # 4 slices of 2 / 3 K tiles
+])
+def test_three_stage_ring_register_direct(kb, variant, twin, M, N, K, act, res, rowvec, splits):
+    """ea_gemm2.h STAGES = 3 with TR (kinds 33 / 34, round 6): two K tiles in flight under a counted vmcnt instead of one -- for the
+    launches that give a CU one workgroup, whose 2-stage loop waits out every tile's memory latency (weights from HBM inside a
+    denoising step: DESIGN 8h-8).  Same products, same K order into the same accumulators, same epilogue: BIT-identical to the
+    2-stage instantiation of the same tile, and == torch."""
+    A, W = f16(M, K), f16(N, K, scale=0.2)
+    bias = f32(N)
+    R = f16(M, N) if res else None
+    rv = f32(M // 128, N) if rowvec else None
+    outs = []
+    for v in (variant, twin):
+        tune(kb, variant=v, splits=splits)
+        out = kb.zeros((M, N), np.float16)
+        e = epilogue(out, bias=bias, act=act, scale=0.75, residual=R, rowvec=rv, rows_per_group=128 if rowvec else 1)
+        ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(M, N, K, 1) + (splits or 1) * M * N * 4)
+        assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1]), "3-stage ring differs from the 2-stage instantiation"
+    ref = t(A) @ t(W).T + t(bias)
+    if rowvec:
+        ref = ref + t(rv).repeat_interleave(128, 0)
+    ref = (F.silu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref) * 0.75
+    if res:
+        ref = ref + t(R)
+    assert relerr(outs[0], ref.numpy()) < 2e-3
+
+
+@pytest.mark.parametrize("variant,twin", [(33, 9), (34, 1)])
+@pytest.mark.parametrize("B,H,W,c1,c2,cout,stride,ups", [
+    (2, 16, 16, 64, 0, 160, 1, 0),        # 9 taps x 1 chunk: every K tile is another tap (per-lane offsets recomputed two tiles ahead)
+    (1, 16, 16, 128, 64, 160, 1, 0),      # concat of two sources, 3 chunks per tap
+    (2, 16, 16, 64, 0, 320, 2, 0),        # stride 2
+    (2, 8, 8, 64, 0, 160, 1, 1),          # nearest-neighbour up-sampling folded into the addressing
+])
+def test_three_stage_ring_register_direct_conv(kb, variant, twin, B, H, W, c1, c2, cout, stride, ups):
+    """... the same for the implicit-GEMM convolution (the incremental im2col state runs TWO tiles ahead of the multiply)."""
+    x1 = f16(B, H, W, c1)
+    x2 = f16(B, H, W, c2) if c2 else None
+    w, bias = f16(cout, c1 + c2, 3, 3, scale=0.1), f32(cout)
+    Hi, Wi = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = (Hi + 2 - 3) // stride + 1, (Wi + 2 - 3) // stride + 1
+    outs = []
+    for v in (variant, twin):
+        tune(kb, variant=v, splits=1)
+        src = conv_src(x1, x2, None, 3, stride, 1, ups, Ho, Wo)
+        out = kb.zeros((B * Ho * Wo, cout), np.float16)
+        e = epilogue(out, bias=bias, act=1)
+        ws = workspace(kb, kb.lib.ea_gemm_workspace_bytes(B * Ho * Wo, cout, 9 * (c1 + c2), 1))
+        assert kb.lib.ea_conv2d_f16(C.byref(src), ptr(pack_conv_w(w)), cout, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == 0
+        outs.append(kb.down(out).copy())
+    assert np.array_equal(outs[0], outs[1])
+    xin = t(x1) if x2 is None else torch.cat([t(x1), t(x2)], -1)
+    xin = xin.permute(0, 3, 1, 2)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.silu(F.conv2d(xin, t(w), t(bias), padding=1, stride=stride)).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert relerr(outs[0], ref.numpy()) < 3e-3
+
+
 @pytest.mark.parametrize("variant", [31, 32])      # intra-workgroup split-K on 128- / 64-row tiles (ea_gemm2.h KS = 2: round-6 experiment)
 @pytest.mark.parametrize("M,N,K,act,res,rowvec,splits", [
     (256, 320, 128, 0, True, False, 0),      # 2 K tiles: one per K stream
@@ -992,6 +1061,8 @@ def _row_stats_ref(y, parts, width):
     (200, 320, 64, False, "1"),       # 128-row tiles, ragged M
     (130, 192, 128, True, "1"),       # 128-wide column tiles: 64-column wave blocks -> 3 parts, last tile half empty
     (128, 160, 2048, True, ""),       # split-K: the epilogue cannot write them -> the fallback launch (all in part 0)
+    (256, 320, 192, True, "33"),      # 3-stage ring under the register-direct epilogue, 64-row tiles (round 6)
+    (200, 320, 256, False, "34"),     # ... 128-row tiles, ragged M
 ])
 def test_row_statistics_output(kb, M, N, K, res, variant, monkeypatch):
     """`row_stats_out`: per output row the partial (sum, sum of squares) of the finished values, one part per wave-column
@@ -1026,6 +1097,8 @@ def test_row_statistics_output(kb, M, N, K, res, variant, monkeypatch):
     (1, 16, 64, 640, 32, "1", False, False),   # cpg 20, 4 column tiles
     (2, 8, 128, 1280, 32, "9", True, True),    # cpg 40, 8x8 samples = two 32-row chunks each
     (1, 16, 64, 256, 32, "1", False, False),   # 128-wide tiles (64-column wave tiles), cpg 8: no odd column tile
+    (2, 16, 64, 320, 32, "34", True, False),   # 3-stage ring (round 6), 128-row tiles
+    (2, 8, 128, 1280, 32, "33", True, True),   # 3-stage ring, 64-row tiles
 ])
 def test_groupnorm_statistics_from_the_producing_conv(kb, B, H, cin, cout, groups, variant, emb, res):
     """`gn_stats_out`: the conv epilogue leaves the per-(sample, row chunk, group) partial (sum, sum of squares) of its
@@ -1035,7 +1108,7 @@ def test_groupnorm_statistics_from_the_producing_conv(kb, B, H, cin, cout, group
     HW, M, K = H * H, B * H * H, 9 * cin
     cpg = cout // groups
     rows = kb.lib.ea_gemm_gn_stats_chunk_rows(M, cout, K, 1, HW, cpg)
-    assert rows == (64 if variant == "1" else 32)
+    assert rows == (64 if variant in ("1", "34") else 32)
     nchunk = HW // rows
     x = f16(B, H, H, cin)
     W = f16(cout, K, scale=0.05)
@@ -1158,6 +1231,9 @@ def test_groupnorm_statistics_refused_where_they_cannot_be_emitted(kb):
     (128, 1280, 320, 3, 32, ""),      # LN3 -> GEGLU projection, 32-row packing (register-direct GEGLU epilogue)
     (256, 512, 128, 3, 32, "1"),      # GEGLU, 128-row tiles, K = 128
     (192, 256, 64, 2, 0, ""),         # GELU after the fold, 128-wide tiles
+    (256, 960, 320, 0, 0, "33"),      # 3-stage ring (round 6): the fold's loads ride under the first TWO tiles
+    (200, 320, 320, 0, 0, "34"),
+    (128, 1280, 320, 3, 32, "33"),    # ... with the register-direct GEGLU epilogue
 ])
 def test_layernorm_fold(kb, M, N, K, act, gb, variant, monkeypatch):
     """LayerNorm folded into the contraction: A = the un-normalised rows, W = gamma-folded weight, bias = W beta + b,
@@ -1207,7 +1283,7 @@ def test_layernorm_fold_refused_where_it_cannot_run(kb):
     assert kb.lib.ea_gemm_f16(ptr(A), K, ptr(W), K, M, N, K, 1, 0, 0, 0, 0, C.byref(e), ptr(ws), ws_nbytes(ws), kb.stream) == -3
 
 
-@pytest.mark.parametrize("M,N,K,variant", [(200, 256, 128, ""), (128, 640, 64, "1"), (64, 128, 192, "")])
+@pytest.mark.parametrize("M,N,K,variant", [(200, 256, 128, ""), (128, 640, 64, "1"), (64, 128, 192, ""), (200, 256, 256, "33"), (128, 640, 192, "34")])
 def test_geglu_32_register_direct(kb, M, N, K, variant, monkeypatch):
     """GEGLU with [16 value | 16 gate] weight-row packing through the register-direct epilogue (128-wide tiles)."""
     if variant:
