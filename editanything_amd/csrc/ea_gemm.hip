@@ -149,6 +149,8 @@ static bool gemm8_shape_ok(const EaGemmParams& p) {
 //        6 / 7 / 8: variants 3 / 2 / 5 with the next tile's DMA pieces interleaved between the MFMA groups
 //        9: 64 x bn, 2-stage   10 / 11 / 12: loader-wave forms   13: 256 x bn, 8 waves 4x2, 3-deep ring, PING-PONG
 //        30: ea_gemm8.h, 256 x 256, 8 waves 2x4 (wave tile 128x64), staggered 8-phase K tile (auto: gemm8_shape_ok)
+//        33 / 34: variants 9 / 1 with a 3-stage ring under the register-direct epilogue (round 6; a launch that needs the
+//                 LDS-slab epilogue, and a twin launch, run the 2-stage instantiation of the same tile)
 //        1 forced also keeps the automatic policy off ea_gemm8 (A/B)
 //   splits / bn     tuning sweeps: force the split-K factor / 128-wide column tiles
 //   no_register_direct   keep the LDS-slab epilogue where the register-direct one applies (A/B)

@@ -140,7 +140,8 @@ typedef struct ea_conv_src {
 typedef struct ea_tuning {
   int32_t force_generic;       /* 1: the register-staged generic kernel for everything */
   int32_t variant;             /* 0 auto, k: force instantiation k of the LDS-DMA kernels (1 / 9: ea_gemm2.h 128- / 64-row tiles,
-                                  30: ea_gemm8.h 256 x 256 tiles; the rest: tools builds) */
+                                  30: ea_gemm8.h 256 x 256 tiles, 33 / 34: the 64- / 128-row tiles with a 3-stage ring -- two K tiles in flight, for
+                                  weights that come from HBM; the rest: tools builds) */
   int32_t splits;              /* 0 plan's own, s: force the split-K factor */
   int32_t bn;                  /* 0 plan's own, 128: force 128-wide column tiles */
   int32_t no_register_direct;  /* 1: LDS-slab epilogue where the register-direct one would run */
