@@ -97,6 +97,7 @@ SIGNATURES = {
     "ea_silu_f32": (_i, [_vp, _vp, _ll, _vp]),
     "ea_add_f16": (_i, [_vp, _vp, _vp, _ll, _vp]),
     "ea_lincomb_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "ea_gather_rows": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
 }
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libeditanything_hip.so")

@@ -107,6 +107,39 @@ __global__ __launch_bounds__(256) void ea_lincomb_kernel(const float* s0, const 
   }
 }
 
+// One step's inputs out of per-call tables, by a DEVICE step index: segment s copies row `*index` of its table (row_bytes bytes)
+// dst_rows times into its destination, then the index advances.  ONE workgroup: the copies are a few hundred KB out of L2, and the
+// increment needs no ordering against other workgroups' reads of the index.  (Replaces, in the captured denoising step, four
+// index_select + four to eight copy nodes + an add -- a graph memcpy node costs ~10 us on this stack, profiles/r06_bench_kernel_stats.csv.)
+#define EA_GATHER_MAX 8
+struct EaGatherParams {
+  const char* table[EA_GATHER_MAX];
+  char* dst[EA_GATHER_MAX];
+  long long row_bytes[EA_GATHER_MAX];
+  int dst_rows[EA_GATHER_MAX];
+  int nseg, increment;
+  long long* index;
+};
+__global__ __launch_bounds__(1024) void ea_gather_rows_kernel(EaGatherParams p) {
+  const long long idx = *p.index;
+  for (int s = 0; s < p.nseg; ++s) {
+    const long long rb = p.row_bytes[s];
+    const char* src = p.table[s] + idx * rb;
+    char* dst = p.dst[s];
+    const bool v16 = ((rb | (long long)(uintptr_t)src | (long long)(uintptr_t)dst) & 15) == 0;
+    for (int r = 0; r < p.dst_rows[s]; ++r) {
+      char* d = dst + (long long)r * rb;
+      if (v16) {
+        for (long long i = threadIdx.x; i < (rb >> 4); i += blockDim.x) reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(src)[i];
+      } else {
+        for (long long i = threadIdx.x; i < (rb >> 2); i += blockDim.x) reinterpret_cast<unsigned*>(d)[i] = reinterpret_cast<const unsigned*>(src)[i];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && p.increment) *p.index = idx + p.increment;
+}
+
 static unsigned grid_for(long long n) {
   long long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;  // 256 CUs x 8 workgroups, grid-stride the rest
@@ -146,6 +179,28 @@ extern "C" int ea_cfg_ddim_step(const float* x, const float* eps_c, const float*
   auto kfn = ea_cfg_ddim_kernel;
   EA_LAUNCH(kfn, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_c, eps_u, noise, coef, mask, x_orig, noise_orig,
             x_prev, pred_x0, n);
+  return ea_launch_status();
+}
+
+extern "C" int ea_gather_rows(const void* const* tables, void* const* dsts, const long long* row_bytes, const int* dst_rows, int nseg,
+                              long long* index, int increment, void* stream) {
+  if (!tables || !dsts || !row_bytes || !dst_rows || !index) return EA_ERR_BAD_ARG;
+  if (nseg <= 0 || nseg > EA_GATHER_MAX) return EA_ERR_BAD_SHAPE;
+  EaGatherParams p{};
+  for (int s = 0; s < nseg; ++s) {
+    if (!tables[s] || !dsts[s]) return EA_ERR_BAD_ARG;
+    if (row_bytes[s] <= 0 || (row_bytes[s] & 3) || dst_rows[s] <= 0) return EA_ERR_BAD_SHAPE;
+    if ((((uintptr_t)tables[s]) | ((uintptr_t)dsts[s])) & 3) return EA_ERR_BAD_ARG;
+    p.table[s] = (const char*)tables[s];
+    p.dst[s] = (char*)dsts[s];
+    p.row_bytes[s] = row_bytes[s];
+    p.dst_rows[s] = dst_rows[s];
+  }
+  p.nseg = nseg;
+  p.increment = increment;
+  p.index = index;
+  auto kfn = ea_gather_rows_kernel;
+  EA_LAUNCH(kfn, dim3(1), dim3(1024), 0, stream, p);
   return ea_launch_status();
 }
 

@@ -827,6 +827,31 @@ def cfg_ddim_step(x, eps_c, eps_u, coef, noise=None, mask=None, x_orig=None, noi
     return x_prev
 
 
+def gather_rows(pairs, index, increment=1):
+    """For every (table, dst) of `pairs` (<= 8): dst <- row `index[0]` of table, repeated to fill dst (dst.numel() a multiple of the
+    row's); then index += increment.  `index`: device int64 [1].  ONE launch (ea_gather_rows): the self-advancing inputs of a captured
+    denoising step (pipeline._advance_inputs)."""
+    pairs = list(pairs)
+    if len(pairs) > 8:          # the kernel takes 8 segments: the index advances with the LAST launch
+        gather_rows(pairs[:8], index, 0)
+        return gather_rows(pairs[8:], index, increment)
+    n = len(pairs)
+    tabs, dsts, rbs, reps = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_longlong * n)(), (C.c_int * n)()
+    for k, (tab, dst) in enumerate(pairs):
+        _check_dev(tab, dst)
+        _dense(tab, dst)
+        if tab.dtype != dst.dtype:
+            raise ValueError("gather_rows: table and destination must have one dtype")
+        row = tab[0].numel()
+        if row == 0 or dst.numel() % row:
+            raise ValueError(f"gather_rows: destination of {dst.numel()} elements is not a whole number of {row}-element rows")
+        tabs[k], dsts[k], rbs[k], reps[k] = tab.data_ptr(), dst.data_ptr(), row * tab.element_size(), dst.numel() // row
+    if index.dtype != torch.int64 or index.numel() != 1:
+        raise ValueError("gather_rows: the step index is a device int64 of one element")
+    st = _lib().ea_gather_rows(tabs, dsts, rbs, reps, n, _p(index), int(increment), _stream())
+    L.check(st, "ea_gather_rows")
+
+
 def lincomb(srcs, coef, out=None, mask=None, alt=(None, None)):
     """out = sum coef[k] * srcs[k] (k < 5; None skipped) [blended: mask * that + (1 - mask) * (coef[5] * alt[0] +
     coef[6] * alt[1])].  fp32 tensors of one shape; `coef` a device fp32 tensor of 7."""

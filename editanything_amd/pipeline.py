@@ -296,16 +296,15 @@ class StableDiffusionControlNetInpaintPipeline:
     def _advance_inputs(self, st):
         """Self-advancing step (cached-graph path): the step's per-iteration inputs -- timestep, sampler coefficients, every
         ResBlock's time-embedding row -- are row `st["step"]` of tables that live in static buffers, gathered by a DEVICE
-        index, and the index is incremented at the end of the step: all of it part of the captured graph, so a denoising
+        index, which then advances (one launch, ops.gather_rows): all of it part of the captured graph, so a denoising
         loop is N back-to-back replays with no host-issued launch between them."""
-        tab, idx = st["tab"], st["step"]
-        st["t"].copy_(tab["t"].index_select(0, idx).expand_as(st["t"]))
-        st["coef"].copy_(tab["coef"].index_select(0, idx)[0])
-        for dst, tb in zip(st["embs"], tab["embs"]):
-            dst.copy_(tb.index_select(0, idx))
+        tab = st["tab"]
+        pairs = [(tab["t"], st["t"]), (tab["coef"], st["coef"])] + list(zip(tab["embs"], st["embs"]))
         if st.get("unipc") is not None:
-            st["unipc"]["coefC"].copy_(tab["coefC"].index_select(0, idx)[0])
-            st["unipc"]["coefP"].copy_(tab["coefP"].index_select(0, idx)[0])
+            pairs += [(tab["coefC"], st["unipc"]["coefC"]), (tab["coefP"], st["unipc"]["coefP"])]
+        # ONE launch: every row gathered by the device index, which then advances (round 6: was four index_select + four to six
+        # copy nodes + an add per step -- ~10 us per graph memcpy node)
+        ops.gather_rows(pairs, st["step"], increment=1)
 
     def _step(self, st):
         if st.get("tab") is not None:
@@ -327,7 +326,7 @@ class StableDiffusionControlNetInpaintPipeline:
         e_c, e_u = e_c.contiguous(), None if e_u is None else e_u.contiguous()
         if st.get("unipc") is None:
             ops.cfg_ddim_step(lat, e_c, e_u, st["coef"], noise=st["noise"], mask=st["blend_mask"], x_orig=st["x_orig"],
-                              noise_orig=st["noise_orig"], x_prev=st["lat_out"])
+                              noise_orig=st["noise_orig"], x_prev=lat)
         else:
             # UniPC (scheduler.py): CFG + x0 prediction from the fused kernel, then corrector and predictor as two
             # linear combinations whose coefficients sit in device buffers (rows copied in per step)
@@ -337,11 +336,10 @@ class StableDiffusionControlNetInpaintPipeline:
             u["m1"].copy_(u["m0"])
             u["m0"].copy_(u["m_t"])
             u["last"].copy_(u["lat_c"])
-            ops.lincomb([u["lat_c"], u["m0"], u["m1"]], u["coefP"], out=st["lat_out"], mask=st["blend_mask"],
+            ops.lincomb([u["lat_c"], u["m0"], u["m1"]], u["coefP"], out=lat, mask=st["blend_mask"],
                         alt=(st["x_orig"], st["noise_orig"]))
-        lat.copy_(st["lat_out"])
-        if st.get("tab") is not None:
-            st["step"].add_(1)
+        # (the sampler update writes the step's result straight into `lat`: both kernels are elementwise -- every element is read
+        # before it is written by the same thread -- so no second buffer and no copy node)
 
     # ------------------------------------------------------------------ __call__
     @torch.no_grad()
@@ -553,7 +551,7 @@ class StableDiffusionControlNetInpaintPipeline:
                     st["unipc"][k].zero_()
         else:
             self.denoiser.install(c.invariants, c.per_net)
-            st = dict(lat=lat.contiguous(), lat_out=torch.empty_like(lat),
+            st = dict(lat=lat.contiguous(),
                       t=torch.zeros(nb, dtype=torch.long, device=self.device), coef=c.coef_table[0].clone(), cfg=c.do_cfg,
                       extra=extra, noise=None, blend_mask=None, x_orig=None if x_orig is None else x_orig.clone(),
                       noise_orig=c.noise0 if x_orig is not None else None)

@@ -28,6 +28,7 @@
  *                             <- segment_anything TwoWayAttentionBlock (image -> token attention + norm4) and
  *                                MaskDecoder.output_upscaling + hypernetwork product (3rd party), fused per token
  *   ea_cfg_ddim_step          <- DDIMSampler.p_sample_ddim, cldm/ddim_hacked.py:187-231
+ *   ea_gather_rows            <- the per-step host work of DDIMSampler.ddim_sampling, cldm/ddim_hacked.py:137-169, 181-197
  *   ea_lincomb_f32            <- UniPCMultistepScheduler.step (diffusers, 3rd party; set at sam2image.py:42) and the
  *                                alpha-weighted latent blends of ...inpaint.py:2039-2051
  *
@@ -296,6 +297,15 @@ int ea_cfg_ddim_step(const float* x, const float* eps_c, const float* eps_u, con
 int ea_lincomb_f32(const float* s0, const float* s1, const float* s2, const float* s3, const float* s4,
                    const float* coef, const float* mask, const float* alt0, const float* alt1, float* out,
                    long long n, void* stream);
+
+/* The per-step inputs of a captured denoising step, gathered by a DEVICE step index: for s < nseg (<= 8) row `*index` of tables[s]
+ * (row_bytes[s] bytes, a multiple of 4; tables and destinations 4-byte aligned) is written dst_rows[s] times, back to back, to
+ * dsts[s]; then *index += increment.  The four arrays are HOST arrays read during the call; `index` is a device int64.  One
+ * launch for what the reference's sampler loops do on the host per step -- timestep, alpha / sigma coefficients
+ * (cldm/ddim_hacked.py:181-197: index = total_steps - i - 1, a_t / a_prev / sigma_t picked per step), and here also every
+ * ResBlock's time-embedding row (openaimodel.py:760-762, computed for all steps at once). */
+int ea_gather_rows(const void* const* tables, void* const* dsts, const long long* row_bytes, const int* dst_rows, int nseg,
+                   long long* index, int increment, void* stream);
 
 /* SAM mask post-processing in one pass (Sam.postprocess_masks + calculate_stability_score + batched_mask_to_box of
  * segment_anything, third party): low_res fp32 [n][lh][lw] logits -> mask uint8 [n][H][W] (logit > threshold at the

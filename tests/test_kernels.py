@@ -704,6 +704,51 @@ def test_lincomb(kb, blend):
     assert kb.lib.ea_lincomb_f32(ptr(srcs[0]), None, None, None, None, None, None, None, None, ptr(out), n, kb.stream) == -2
 
 
+def test_gather_rows(kb):
+    """ea_gather_rows (round 6): the self-advancing inputs of a captured denoising step in ONE launch -- row `*index` of every table,
+    repeated to fill its destination (the timestep for every sample of the batch; 16-byte and 4-byte row sizes), then the device
+    index advances; three calls walk rows 2, 3, 4.  Argument checks: more than 8 segments, a row size that is not a multiple of 4."""
+    rng = np.random.default_rng(77)            # (own generator: the module's shared stream stays as it was)
+    steps = 6
+    t_tab = np.arange(1000, 1000 + steps, dtype=np.int64)
+    coef = rng.standard_normal((steps, 5)).astype(np.float32)               # 20-byte rows: the 4-byte copy path
+    emb = rng.standard_normal((steps, 1024 * 20 + 4)).astype(np.float32)    # 80 KB rows, 16-byte path, several trips of the block
+    tabs = [kb.up(a) for a in (t_tab, coef, emb)]
+    dsts = [kb.zeros(8, np.int64), kb.zeros(5, np.float32), kb.zeros((1, emb.shape[1]), np.float32)]
+    index = kb.up(np.array([2], np.int64))
+    n = 3
+    T, D, RB, RP = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_longlong * n)(), (C.c_int * n)()
+    for k, (tab, dst, a) in enumerate(zip(tabs, dsts, (t_tab, coef, emb))):
+        T[k], D[k] = ptr(tab), ptr(dst)
+        RB[k] = a[0].nbytes if a.ndim > 1 else a.itemsize
+        RP[k] = int(np.prod(kb.down(dst).shape)) * a.itemsize // RB[k]
+    for i in range(3):
+        assert kb.lib.ea_gather_rows(T, D, RB, RP, n, ptr(index), 1, kb.stream) == 0
+        row = 2 + i
+        assert np.array_equal(kb.down(dsts[0]), np.full(8, t_tab[row]))
+        assert np.array_equal(kb.down(dsts[1]), coef[row])
+        assert np.array_equal(kb.down(dsts[2])[0], emb[row])
+        assert int(kb.down(index)[0]) == row + 1
+    assert kb.lib.ea_gather_rows(T, D, RB, RP, 9, ptr(index), 1, kb.stream) == -1          # EA_ERR_BAD_SHAPE: 8 segments at most
+    RB[1] = 18
+    assert kb.lib.ea_gather_rows(T, D, RB, RP, n, ptr(index), 1, kb.stream) == -1
+    assert kb.lib.ea_gather_rows(T, D, RB, RP, n, None, 1, kb.stream) == -2                 # EA_ERR_BAD_ARG
+
+
+def test_cfg_ddim_step_in_place(kb):
+    """The sampler update may write its result over its input latents (x_prev == x: elementwise, every element is read before the
+    same thread writes it) -- how the captured step runs it since round 6 (pipeline._step: no second buffer, no copy node)."""
+    rng = np.random.default_rng(78)
+    n = 4 * 4 * 16 * 16 + 3
+    x, ec, eu = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    coef = np.array([0.35, 0.6, 0.0, 7.5, 0.0], np.float32)
+    sep = kb.zeros(n, np.float32)
+    assert kb.lib.ea_cfg_ddim_step(ptr(x), ptr(ec), ptr(eu), None, ptr(coef), None, None, None, ptr(sep), None, n, kb.stream) == 0
+    buf = kb.up(x.copy())
+    assert kb.lib.ea_cfg_ddim_step(ptr(buf), ptr(ec), ptr(eu), None, ptr(coef), None, None, None, ptr(buf), None, n, kb.stream) == 0
+    assert np.array_equal(kb.down(buf), kb.down(sep))
+
+
 def test_layout_roundtrip(kb):
     B, Cc, H, W, Cpad = 2, 4, 5, 6, 8
     x = f32(B, Cc, H, W)
