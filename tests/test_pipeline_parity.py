@@ -221,6 +221,13 @@ def test_merged_requests_equal_their_own_calls(mg, tiny, overlap):
             assert e <= 1e-2, (rounds, r, e)
         assert torch.equal(got[4].images, want[4]), "the left-over request runs as its own call"
     assert len(pipe._graphs) == 2, "one captured step per batch size (merged pair, single request)"
+    if not overlap:     # four requests per call (bench.py `merged.one_stream_x4`: +24 % at full size): one group of four + one left over
+        pipe4 = _pipe(StableDiffusionControlNetInpaintPipeline, tiny, ukey, cns, True)
+        got4 = serving.PipelinedRunner(pipe4, merge=4).run([dict(kw, generator=torch.Generator("cpu").manual_seed(40 + r)) for r, kw in enumerate(reqs)])
+        torch.cuda.synchronize()
+        for r in range(5):
+            assert rel_l2(got4[r].images, want[r]) <= 1e-2, (r, rel_l2(got4[r].images, want[r]))
+        assert torch.equal(got4[4].images, want[4])
     # eta > 0 (variance noise inside the loop) and the mixing pipeline (per-step re-noise): the loop's draws are taken with the
     # request's other draws (serving.predraw) and handed over as `loop_noise=` -- merged too, each request on ITS noise
     from editanything_amd.pipeline import StableDiffusionControlNetInpaintMixingPipeline
