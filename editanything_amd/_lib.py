@@ -90,6 +90,11 @@ SIGNATURES = {
     "ea_relpos_tables_f16": (_i, [_vp, _i, _i, _i, _i, _ll, _ll, _vp, _vp, _vp, _vp, _vp]),
     "ea_sam_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "ea_sam_mask_postprocess_indexed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "ea_sam_mask_postprocess_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]),
+    "ea_sam_token_self_attn_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "ea_sam_fold_heads_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ea_sam_unfold_heads_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ea_sam_id_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     "ea_softmax_rows_f32_f16": (_i, [_vp, _vp, _i, _i, _f, _vp]),
     "ea_cfg_ddim_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "ea_nchw_f32_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _vp]),

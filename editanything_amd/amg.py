@@ -65,6 +65,9 @@ class _Attn:
             # the [B, 4096, C] operands
             o = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), scale=1.0 / math.sqrt(d))
             return o.transpose(1, 2).reshape(B, Nq, Ci)
+        if h == 8 and Ci == 256 and Nq <= 8 and k.shape[1] == Nq and q.is_cuda:
+            # the prompt tokens' self attention: one launch, fp32 inside (round 6)
+            return ops.sam_token_self_attn(q.contiguous(), k.contiguous(), v.contiguous(), 1.0 / math.sqrt(d))
         a = torch.matmul(sp(q).float(), sp(k).float().transpose(-2, -1)) * (1.0 / math.sqrt(d))
         o = torch.matmul(torch.softmax(a, dim=-1), sp(v).float())
         return o.transpose(1, 2).reshape(B, Nq, Ci).half()
@@ -227,9 +230,12 @@ class SamPromptDecoder:
         if not hasattr(a, "_blocks"):
             h, Ci = self.heads, a.internal
             d = Ci // h
-            a._blocks = dict(d=d, wq=a.w["q"].float().reshape(h, d, -1), wk=a.w["k"].float().reshape(h, d, -1),
+            a._blocks = dict(d=d, wq=a.w["q"].float().reshape(h, d, -1).contiguous(), wk=a.w["k"].float().reshape(h, d, -1).contiguous(),
                              wv=a.w["v"].float().reshape(h, d, -1), bq=a.b["q"].reshape(h, d), bk=a.b["k"].reshape(h, d),
-                             bv=a.b["v"].reshape(h, d), wo=a.wo.float().reshape(-1, h, d))
+                             bv=a.b["v"].reshape(h, d), wo=a.wo.float().reshape(-1, h, d),
+                             # the layouts ops.sam_fold_heads / sam_unfold_heads read: Wo as [h, d, C], Wv transposed [C, h * d]
+                             wo_hdc=a.wo.float().reshape(-1, h, d).permute(1, 2, 0).contiguous(),
+                             wv_t=a.w["v"].float().t().contiguous(), bv_flat=a.b["v"].float().contiguous())
         return a._blocks
 
     def _t2i_folded(self, a, q_in, kp, k, key_pe):
@@ -239,12 +245,20 @@ class SamPromptDecoder:
         bl = self._heads(a)
         B, n, Cc = q_in.shape
         h, d, T = self.heads, bl["d"], k.shape[-2]
-        qh = (F.linear(q_in, a.w["q"].float(), a.b["q"])).reshape(B, n, h, d)
-        G = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_in.device)
-        G[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", qh, bl["wk"]).half()
+        qh = F.linear(q_in, a.w["q"].float(), a.b["q"])                   # [B, n, h * d]
+        fused = d in (16, 32) and h == 8 and Cc == 256
+        if fused:
+            G = ops.sam_fold_heads(qh.contiguous(), bl["wk"]).reshape(B, h, 8, Cc)        # one launch (round 6), rows j >= n zero
+        else:
+            G = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_in.device)
+            G[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", qh.reshape(B, n, h, d), bl["wk"]).half()
         if T % 64 == 0:
             # one pass over the image tokens per prompt: scores, online softmax and P keys fused (ops.sam_t2i)
-            ctx = ops.sam_t2i(k, key_pe, G.reshape(B, 64, Cc), 1.0 / math.sqrt(d), B).reshape(B, h, 8, Cc)[:, :, :n]
+            ctx = ops.sam_t2i(k, key_pe, G.reshape(B, 64, Cc), 1.0 / math.sqrt(d), B)
+            if fused:
+                # ... and back through the value projection in one launch: o = Wv_h ctx_hj + bv_h
+                return F.linear(ops.sam_unfold_heads(ctx, bl["wv_t"], bl["bv_flat"], n), a.wo.float(), a.bo)
+            ctx = ctx.reshape(B, h, 8, Cc)[:, :, :n]
         elif k.dim() == 2:
             # block 0: ONE image-token tensor for every prompt -- two plain contractions over all B * 64 score rows
             S = ops.gemm(G.reshape(B * 64, Cc), kp, out_dtype=torch.float32).reshape(B, 64, T)
@@ -270,10 +284,15 @@ class SamPromptDecoder:
         scale = 1.0 / math.sqrt(d)
         kh = F.linear(q_pe, a.w["k"].float(), a.b["k"]).reshape(B, n, h, d)
         vh = F.linear(q_val, a.w["v"].float(), a.b["v"]).reshape(B, n, h, d)
-        g2 = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_pe.device)
-        g2[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", kh, bl["wq"]).half()
         cb = torch.full((B, h, 8), -1e30, dtype=torch.float32, device=q_pe.device)
         cb[:, :, :n] = torch.einsum("bjhd,hd->bhj", kh, bl["bq"]) * scale
+        if d in (16, 32) and h == 8 and Cc == 256:
+            # round 6: each operand in one launch (ops.sam_fold_heads) instead of einsum + cast + zero fill + strided copy
+            g2 = ops.sam_fold_heads(kh.reshape(B, n, h * d), bl["wq"])
+            vo = ops.sam_fold_heads(vh.reshape(B, n, h * d), bl["wo_hdc"], perm=self._vo_perm_i32(), c_major=True)
+            return ops.sam_i2t(kp, k, key_pe, g2, cb.reshape(B, 64), vo, a.bo, norm[0], norm[1], 1e-5, scale, B, want_kp)
+        g2 = torch.zeros((B, h, 8, Cc), dtype=torch.float16, device=q_pe.device)
+        g2[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", kh, bl["wq"]).half()
         # vo[b, c, s] = Wo_h v_hj for the score column (h, j) = perm[s] that storage position s holds: gather the SMALL
         # operands into that order ([B, 64, d] values, [C, 64, d] weights), one contraction writes the layout the kernel reads
         vpad = torch.zeros((B, h, 8, d), dtype=torch.float32, device=q_pe.device)
@@ -287,7 +306,12 @@ class SamPromptDecoder:
     def _vo_perm(self):
         if not hasattr(self, "_perm"):
             self._perm = ops.sam_vo_perm(self.device)
+            self._perm_i32 = self._perm.int()
         return self._perm
+
+    def _vo_perm_i32(self):
+        self._vo_perm()
+        return self._perm_i32
 
     def predict_masks(self, image_tokens, emb_hw, sparse, multimask_output=True):
         """image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
@@ -531,10 +555,15 @@ class SamAutomaticMaskGenerator:
         `host.show_anns_from_id_map` turns it into show_anns' return value."""
         sel = self._select(image, image_embedding)
         H, W = np.asarray(image).shape[:2]
-        idm = torch.zeros((H, W), dtype=torch.int16, device=self.decoder.device)
         if sel is None:
-            return idm.int(), 0
+            return torch.zeros((H, W), dtype=torch.int32, device=self.decoder.device), 0
         n = len(sel["idx"])
+        if W <= ops.SAM_ID_MAP_MAX_W:
+            # round 6: one launch walks the records per pixel from the last to the first covering one (ops.sam_id_map: the mask
+            # kernel's arithmetic, the same bit per record and pixel) -- no full-resolution mask is written or reduced
+            (inp, orig, S) = sel["geom"]
+            return ops.sam_id_map(sel["low"], inp, orig, S, self.cfg["mask_threshold"], index=sel["idx"].int()), n
+        idm = torch.zeros((H, W), dtype=torch.int16, device=self.decoder.device)
         for lo in range(0, n, 512):
             hi = min(n, lo + 512)
             m = self._masks(sel, lo, hi).ne(0)

@@ -292,6 +292,8 @@ struct MaskPostParams {
   int* stats;   // [Nm][6]: inter, union, xmin, ymin, xmax, ymax (caller-initialised to 0, 0, W, H, -1, -1)
   int lh, lw, S, in_h, in_w, H, W;
   float thr, off;
+  int* idmap;   // ea_sam_id_map_kernel: int32 [H][W]
+  int n, id_base, band;   // masks of the launch; id of slot 0 minus one; output rows per workgroup (tabled kernels)
 };
 
 __device__ __forceinline__ void ea_bilin_index(float scale, int dst, int in_size, int& i0, int& i1, float& l1) {
@@ -325,14 +327,63 @@ __device__ __forceinline__ void ea_atomic_max_i(int* p, int v) {
 #endif
 }
 
+// The value of ONE pixel of one bilinear stage from its four taps (torch's upsample_bilinear2d form): shared by every
+// kernel below, so the per-pixel kernel and the tabled one evaluate the same expression tree.
+__device__ __forceinline__ float ea_bilerp(float my, float mx, float v00, float v01, float v10, float v11) {
+  return (1.0f - my) * ((1.0f - mx) * v00 + mx * v01) + my * ((1.0f - mx) * v10 + mx * v11);
+}
+
+__device__ __forceinline__ int ea_shfl_xor_i(int v, int mask) {
+#ifdef EA_EMU
+  return ea_emu_shfl_xor<int>(v, mask);
+#else
+  return __shfl_xor(v, mask, 64);
+#endif
+}
+
+// Block reduction of the six per-thread statistics (two sums, two minima, two maxima) + the integer atomics into stats[slot]:
+// wave shuffles, then one LDS slot per wave (`red`: >= 4 * 6 ints).
+__device__ __forceinline__ void ea_mask_stats_commit(int* red, int* stats_slot, int inter, int uni, int xmin, int ymin, int xmax, int ymax) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    inter += ea_shfl_xor_i(inter, m);
+    uni += ea_shfl_xor_i(uni, m);
+    const int a = ea_shfl_xor_i(xmin, m), b = ea_shfl_xor_i(ymin, m), c = ea_shfl_xor_i(xmax, m), d = ea_shfl_xor_i(ymax, m);
+    xmin = a < xmin ? a : xmin;
+    ymin = b < ymin ? b : ymin;
+    xmax = c > xmax ? c : xmax;
+    ymax = d > ymax ? d : ymax;
+  }
+  if ((tid & 63) == 0) {
+    int* r = red + (tid >> 6) * 6;
+    r[0] = inter; r[1] = uni; r[2] = xmin; r[3] = ymin; r[4] = xmax; r[5] = ymax;
+  }
+  __syncthreads();
+  if (tid < 6) {
+    int acc = red[tid];
+    for (int w = 1; w < 4; ++w) {
+      const int v = red[w * 6 + tid];
+      if (tid < 2) acc += v;
+      else if (tid < 4) acc = v < acc ? v : acc;
+      else acc = v > acc ? v : acc;
+    }
+    int* dst = stats_slot + tid;
+    if (tid < 2) ea_atomic_add_i(dst, acc);
+    else if (tid < 4) ea_atomic_min_i(dst, acc);
+    else ea_atomic_max_i(dst, acc);
+  }
+}
+
 // One thread = one output pixel at a time (grid-stride over the mask): both bilinear resizes evaluated analytically from the
 // low-resolution logits, 16 taps that hit L1.  (Round 3 tried staging the four low-resolution rows of an output row in LDS --
 // two barriers per row for 512 pixels: 3x SLOWER than the scattered global reads it replaced; reverted.)  `index`
 // (optional) selects the masks to process out of the low-resolution tensor, `mask` may be NULL (statistics only): the
-// generator filters on the statistics and never copies logits or writes masks it will drop.
+// generator filters on the statistics and never copies logits or writes masks it will drop.  Since round 6 this is the
+// fallback for rows wider than the tabled kernel's LDS tables hold (W > 2048) and the A/B reference of that kernel.
 __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
   EA_SMEM(smem);
-  int* red = reinterpret_cast<int*>(smem);   // [256][6]
+  int* red = reinterpret_cast<int*>(smem);   // [4][6]
   const int tid = threadIdx.x;
   const int slot = blockIdx.y;
   const int m = p.index ? p.index[slot] : slot;
@@ -359,12 +410,10 @@ __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
         int x0, x1;
         float mx;
         ea_bilin_index(s1x, X[b], p.lw, x0, x1, mx);
-        const float v00 = low[y0 * p.lw + x0], v01 = low[y0 * p.lw + x1];
-        const float v10 = low[y1 * p.lw + x0], v11 = low[y1 * p.lw + x1];
-        up[a][b] = (1.0f - my) * ((1.0f - mx) * v00 + mx * v01) + my * ((1.0f - mx) * v10 + mx * v11);
+        up[a][b] = ea_bilerp(my, mx, low[y0 * p.lw + x0], low[y0 * p.lw + x1], low[y1 * p.lw + x0], low[y1 * p.lw + x1]);
       }
     }
-    const float v = (1.0f - ly) * ((1.0f - lx) * up[0][0] + lx * up[0][1]) + ly * ((1.0f - lx) * up[1][0] + lx * up[1][1]);
+    const float v = ea_bilerp(ly, lx, up[0][0], up[0][1], up[1][0], up[1][1]);
     const bool on = v > p.thr;
     if (out) out[i] = on ? 1 : 0;
     inter += (v > p.thr + p.off) ? 1 : 0;
@@ -376,49 +425,279 @@ __global__ __launch_bounds__(256) void ea_mask_post_kernel(MaskPostParams p) {
       ymax = y > ymax ? y : ymax;
     }
   }
-  red[tid * 6 + 0] = inter; red[tid * 6 + 1] = uni; red[tid * 6 + 2] = xmin;
-  red[tid * 6 + 3] = ymin; red[tid * 6 + 4] = xmax; red[tid * 6 + 5] = ymax;
+  ea_mask_stats_commit(red, p.stats + slot * 6, inter, uni, xmin, ymin, xmax, ymax);
+}
+
+// ---- the tabled form (round 6).  The per-pixel kernel spends most of its issue slots recomputing, for every pixel, index
+// arithmetic that depends on the pixel's COLUMN alone (two stage-2 taps, their stage-1 taps and weights) or on its ROW alone,
+// and reads 16 taps of which -- whenever both stage-2 taps of a pixel fall into one cell of the low-resolution grid, which is
+// every pixel of an up-by-4 / down-by-2 chain like 256 -> 1024 -> 512 -- only 4 are distinct.  Here a workgroup owns a band of
+// output rows of one mask, builds the column table (all W columns) and the band's row table in LDS ONCE with the very
+// ea_bilin_index calls of the per-pixel kernel, notes whether every column / every row of the band has coinciding taps, and
+// runs the matching one of four inner loops (4, 8, 8 or 16 loads per pixel); a pixel's value is the same ea_bilerp tree over the
+// same taps, so masks and statistics equal the per-pixel kernel's bit for bit (tests/test_kernels.py).
+struct MaskCol { int xa, xb; float mxa, mxb, lx; };   // xa = x0 | x1 << 16 of the first stage-2 tap, xb of the second
+struct MaskRow { int y0a, y1a, y0b, y1b; float mya, myb, ly; };   // row offsets (elements) into the low-resolution mask
+#define EA_MASK_MAXW 2048
+#define EA_MASK_MAXR 32
+
+__device__ __forceinline__ void ea_mask_tables(const MaskPostParams& p, int row0, int rows, int col0, int cols, int* flags, int* cxa, int* cxb,
+                                               float* cmxa, float* cmxb, float* clx, MaskRow* rtab) {
+  const int tid = threadIdx.x;
+  const float s1y = (float)p.lh / (float)p.S, s1x = (float)p.lw / (float)p.S;
+  const float s2y = (float)p.in_h / (float)p.H, s2x = (float)p.in_w / (float)p.W;
+  if (tid < 2) flags[tid] = 1;
   __syncthreads();
-  if (tid < 6) {
-    int acc = red[tid];
-    for (int t = 1; t < 256; ++t) {
-      const int v = red[t * 6 + tid];
-      if (tid < 2) acc += v;
-      else if (tid < 4) acc = v < acc ? v : acc;
-      else acc = v > acc ? v : acc;
+  for (int x = tid; x < cols; x += 256) {
+    int X0, X1, a0, a1, b0, b1;
+    float lx, ma, mb;
+    ea_bilin_index(s2x, col0 + x, p.in_w, X0, X1, lx);
+    ea_bilin_index(s1x, X0, p.lw, a0, a1, ma);
+    ea_bilin_index(s1x, X1, p.lw, b0, b1, mb);
+    cxa[x] = a0 | (a1 << 16);
+    cxb[x] = b0 | (b1 << 16);
+    cmxa[x] = ma; cmxb[x] = mb; clx[x] = lx;
+    if (a0 != b0 || a1 != b1) flags[0] = 0;
+  }
+  if (tid < rows) {
+    int Y0, Y1, a0, a1, b0, b1;
+    MaskRow r;
+    ea_bilin_index(s2y, row0 + tid, p.in_h, Y0, Y1, r.ly);
+    ea_bilin_index(s1y, Y0, p.lh, a0, a1, r.mya);
+    ea_bilin_index(s1y, Y1, p.lh, b0, b1, r.myb);
+    r.y0a = a0 * p.lw; r.y1a = a1 * p.lw; r.y0b = b0 * p.lw; r.y1b = b1 * p.lw;
+    rtab[tid] = r;
+    if (a0 != b0 || a1 != b1) flags[1] = 0;
+  }
+  __syncthreads();
+}
+
+// value of output pixel (row entry r, column x) of the low-resolution mask `low`
+template <bool SX, bool SY>
+__device__ __forceinline__ float ea_mask_value(const float* low, const MaskRow& r, int xa, int xb, float mxa, float mxb, float lx) {
+  const int x0a = xa & 0xffff, x1a = xa >> 16;
+  const float* ra0 = low + r.y0a;
+  const float* ra1 = low + r.y1a;
+  const float a00 = ra0[x0a], a01 = ra0[x1a], a10 = ra1[x0a], a11 = ra1[x1a];      // rows of tap a, columns of tap a
+  float b00 = a00, b01 = a01, b10 = a10, b11 = a11;                                 // rows of tap a, columns of tap b
+  float c00 = a00, c01 = a01, c10 = a10, c11 = a11;                                 // rows of tap b, columns of tap a
+  float d00 = a00, d01 = a01, d10 = a10, d11 = a11;                                 // rows of tap b, columns of tap b
+  if (!SX) {
+    const int x0b = xb & 0xffff, x1b = xb >> 16;
+    b00 = ra0[x0b]; b01 = ra0[x1b]; b10 = ra1[x0b]; b11 = ra1[x1b];
+    d00 = b00; d01 = b01; d10 = b10; d11 = b11;
+  }
+  if (!SY) {
+    const float* rb0 = low + r.y0b;
+    const float* rb1 = low + r.y1b;
+    c00 = rb0[x0a]; c01 = rb0[x1a]; c10 = rb1[x0a]; c11 = rb1[x1a];
+    if (!SX) {
+      const int x0b = xb & 0xffff, x1b = xb >> 16;
+      d00 = rb0[x0b]; d01 = rb0[x1b]; d10 = rb1[x0b]; d11 = rb1[x1b];
+    } else {
+      d00 = c00; d01 = c01; d10 = c10; d11 = c11;
     }
-    int* dst = p.stats + slot * 6 + tid;
-    if (tid < 2) ea_atomic_add_i(dst, acc);
-    else if (tid < 4) ea_atomic_min_i(dst, acc);
-    else ea_atomic_max_i(dst, acc);
+  }
+  const float u00 = ea_bilerp(r.mya, mxa, a00, a01, a10, a11);
+  const float u01 = ea_bilerp(r.mya, mxb, b00, b01, b10, b11);
+  const float u10 = ea_bilerp(r.myb, mxa, c00, c01, c10, c11);
+  const float u11 = ea_bilerp(r.myb, mxb, d00, d01, d10, d11);
+  return ea_bilerp(r.ly, lx, u00, u01, u10, u11);
+}
+
+template <bool SX, bool SY>
+__device__ __forceinline__ void ea_mask_band(const MaskPostParams& p, const float* low, unsigned char* out, int row0, int rows, const int* cxa,
+                                             const int* cxb, const float* cmxa, const float* cmxb, const float* clx, const MaskRow* rtab,
+                                             int& inter, int& uni, int& xmin, int& ymin, int& xmax, int& ymax) {
+  const float thr = p.thr, hi = p.thr + p.off, lo = p.thr - p.off;
+  for (int x = threadIdx.x; x < p.W; x += 256) {
+    const int xa = cxa[x], xb = cxb[x];
+    const float mxa = cmxa[x], mxb = cmxb[x], lx = clx[x];
+    bool any = false;
+    for (int j = 0; j < rows; ++j) {
+      const MaskRow r = rtab[j];
+      const float v = ea_mask_value<SX, SY>(low, r, xa, xb, mxa, mxb, lx);
+      const bool on = v > thr;
+      const int y = row0 + j;
+      if (out) out[(long long)y * p.W + x] = on ? 1 : 0;
+      inter += (v > hi) ? 1 : 0;
+      uni += (v > lo) ? 1 : 0;
+      if (on) {
+        any = true;
+        ymin = y < ymin ? y : ymin;
+        ymax = y > ymax ? y : ymax;
+      }
+    }
+    if (any) {
+      xmin = x < xmin ? x : xmin;
+      xmax = x > xmax ? x : xmax;
+    }
   }
 }
 
-extern "C" int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
-                                               int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
-                                               int* stats, void* stream);
-extern "C" int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
-                                       int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
-                                       void* stream) {
-  return ea_sam_mask_postprocess_indexed(low_res, nullptr, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, offset, mask, stats, stream);
+__global__ __launch_bounds__(256) void ea_mask_post_tab_kernel(MaskPostParams p) {
+  EA_SMEM(smem);
+  int* red = reinterpret_cast<int*>(smem);                     // [4][6] + 2 flags
+  int* flags = red + 24;
+  MaskRow* rtab = reinterpret_cast<MaskRow*>(smem + 128);      // [EA_MASK_MAXR]
+  int* cxa = reinterpret_cast<int*>(smem + 128 + EA_MASK_MAXR * (int)sizeof(MaskRow));
+  int* cxb = cxa + p.W;
+  float* cmxa = reinterpret_cast<float*>(cxb + p.W);
+  float* cmxb = cmxa + p.W;
+  float* clx = cmxb + p.W;
+  const int slot = blockIdx.y;
+  const int m = p.index ? p.index[slot] : slot;
+  const float* low = p.low + (long long)m * p.lh * p.lw;
+  unsigned char* out = p.mask ? p.mask + (long long)slot * p.H * p.W : nullptr;
+  const int row0 = blockIdx.x * p.band;
+  const int rows = p.H - row0 < p.band ? p.H - row0 : p.band;
+  ea_mask_tables(p, row0, rows, 0, p.W, flags, cxa, cxb, cmxa, cmxb, clx, rtab);
+  int inter = 0, uni = 0, xmin = p.W, ymin = p.H, xmax = -1, ymax = -1;
+  const bool sx = flags[0] != 0, sy = flags[1] != 0;
+  if (sx && sy) ea_mask_band<true, true>(p, low, out, row0, rows, cxa, cxb, cmxa, cmxb, clx, rtab, inter, uni, xmin, ymin, xmax, ymax);
+  else if (sx) ea_mask_band<true, false>(p, low, out, row0, rows, cxa, cxb, cmxa, cmxb, clx, rtab, inter, uni, xmin, ymin, xmax, ymax);
+  else if (sy) ea_mask_band<false, true>(p, low, out, row0, rows, cxa, cxb, cmxa, cmxb, clx, rtab, inter, uni, xmin, ymin, xmax, ymax);
+  else ea_mask_band<false, false>(p, low, out, row0, rows, cxa, cxb, cmxa, cmxb, clx, rtab, inter, uni, xmin, ymin, xmax, ymax);
+  __syncthreads();
+  ea_mask_stats_commit(red, p.stats + slot * 6, inter, uni, xmin, ymin, xmax, ymax);
+}
+
+// ---- show_anns' id map straight from the records' low-resolution logits (sam2image.py:92-115 over the list
+// SamAutomaticMaskGenerator.generate returns: record i paints i + 1 over its mask, later records over earlier ones, i.e. a pixel
+// carries the LARGEST record number whose mask covers it).  One thread owns a pixel and walks the records from the last to
+// the first until one covers it -- the tabled evaluation above, so the decision per (record, pixel) is the bit the mask kernel
+// writes -- instead of writing n full-resolution masks and reducing them: no mask byte exists, nothing is atomic.
+// idmap[pixel] = max(idmap[pixel], id_base + 1 + the largest covering slot).
+template <bool SX, bool SY>
+__device__ __forceinline__ int ea_id_walk(const MaskPostParams& p, const int* sidx, const MaskRow& r, int xa, int xb, float mxa, float mxb, float lx) {
+  const long long lsz = (long long)p.lh * p.lw;
+  int s = p.n - 1;
+  // four records per trip: their 4 x (4 ... 16) taps are in flight together -- the walk is a chain of dependent loads otherwise
+  for (; s >= 3; s -= 4) {
+    const float v0 = ea_mask_value<SX, SY>(p.low + sidx[s] * lsz, r, xa, xb, mxa, mxb, lx);
+    const float v1 = ea_mask_value<SX, SY>(p.low + sidx[s - 1] * lsz, r, xa, xb, mxa, mxb, lx);
+    const float v2 = ea_mask_value<SX, SY>(p.low + sidx[s - 2] * lsz, r, xa, xb, mxa, mxb, lx);
+    const float v3 = ea_mask_value<SX, SY>(p.low + sidx[s - 3] * lsz, r, xa, xb, mxa, mxb, lx);
+    if (v0 > p.thr) return s + 1;
+    if (v1 > p.thr) return s;
+    if (v2 > p.thr) return s - 1;
+    if (v3 > p.thr) return s - 2;
+  }
+  for (; s >= 0; --s)
+    if (ea_mask_value<SX, SY>(p.low + sidx[s] * lsz, r, xa, xb, mxa, mxb, lx) > p.thr) return s + 1;
+  return 0;
+}
+
+// grid (column blocks of 256, rows): one pixel per thread
+__global__ __launch_bounds__(256) void ea_sam_id_map_kernel(MaskPostParams p) {
+  EA_SMEM(smem);
+  int* flags = reinterpret_cast<int*>(smem) + 24;
+  MaskRow* rtab = reinterpret_cast<MaskRow*>(smem + 128);
+  int* cxa = reinterpret_cast<int*>(smem + 128 + EA_MASK_MAXR * (int)sizeof(MaskRow));
+  int* cxb = cxa + 256;
+  float* cmxa = reinterpret_cast<float*>(cxb + 256);
+  float* cmxb = cmxa + 256;
+  float* clx = cmxb + 256;
+  int* sidx = reinterpret_cast<int*>(clx + 256);            // [n]: the records' places in `low`
+  const int tid = threadIdx.x;
+  const int col0 = blockIdx.x * 256, y = blockIdx.y;
+  const int cols = p.W - col0 < 256 ? p.W - col0 : 256;
+  for (int s = tid; s < p.n; s += 256) sidx[s] = p.index ? p.index[s] : s;
+  ea_mask_tables(p, y, 1, col0, cols, flags, cxa, cxb, cmxa, cmxb, clx, rtab);
+  if (tid >= cols) return;
+  const bool sx = flags[0] != 0, sy = flags[1] != 0;
+  const MaskRow r = rtab[0];
+  const int xa = cxa[tid], xb = cxb[tid];
+  const float mxa = cmxa[tid], mxb = cmxb[tid], lx = clx[tid];
+  int id;
+  if (sx && sy) id = ea_id_walk<true, true>(p, sidx, r, xa, xb, mxa, mxb, lx);
+  else if (sx) id = ea_id_walk<true, false>(p, sidx, r, xa, xb, mxa, mxb, lx);
+  else if (sy) id = ea_id_walk<false, true>(p, sidx, r, xa, xb, mxa, mxb, lx);
+  else id = ea_id_walk<false, false>(p, sidx, r, xa, xb, mxa, mxb, lx);
+  if (id) {
+    int* dst = p.idmap + (long long)y * p.W + col0 + tid;
+    id += p.id_base;
+    if (id > *dst) *dst = id;
+  }
+}
+
+#define EA_ID_MAP_MAXN 8192
+static int mask_tab_lds(int W) { return 128 + EA_MASK_MAXR * (int)sizeof(MaskRow) + W * 20; }
+
+static int mask_post_fill(MaskPostParams& p, const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size, int in_h,
+                          int in_w, int H, int W, float threshold, float offset) {
+  if (n_masks <= 0 || lh <= 0 || lw <= 0 || img_size <= 0 || in_h <= 0 || in_w <= 0 || H <= 0 || W <= 0) return EA_ERR_BAD_SHAPE;
+  if (in_h > img_size || in_w > img_size || (long long)H * W > 0x3fffffffLL || lw > 4096) return EA_ERR_BAD_SHAPE;
+  p.low = low_res; p.index = index; p.mask = nullptr; p.stats = nullptr; p.idmap = nullptr;
+  p.lh = lh; p.lw = lw; p.S = img_size; p.in_h = in_h; p.in_w = in_w; p.H = H; p.W = W;
+  p.thr = threshold; p.off = offset;
+  p.n = n_masks; p.id_base = 0; p.band = 1;
+  return EA_OK;
+}
+
+extern "C" int ea_sam_mask_postprocess_ex(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size, int in_h,
+                                          int in_w, int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
+                                          int kernel, void* stream) {
+  if (!low_res || !stats) return EA_ERR_BAD_ARG;   // mask == NULL: statistics only (no mask is written)
+  if (kernel < 0 || kernel > 2) return EA_ERR_BAD_ARG;
+  MaskPostParams p;
+  const int st = mask_post_fill(p, low_res, index, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, offset);
+  if (st != EA_OK) return st;
+  p.mask = mask; p.stats = stats;
+  if (kernel == 2 && W > EA_MASK_MAXW) return EA_ERR_UNSUPPORTED;
+  if (kernel == 1 || W > EA_MASK_MAXW) {
+    int bx = (H * W + 256 * 8 - 1) / (256 * 8);      // ~8 pixels per thread
+    if (bx < 1) bx = 1;
+    if (bx > 1024) bx = 1024;
+    auto kfn = ea_mask_post_kernel;
+    EA_LAUNCH(kfn, dim3((unsigned)bx, (unsigned)n_masks), dim3(256), 128, stream, p);
+    return ea_launch_status();
+  }
+  // band height: ~16 pixels per thread, at least 1024 workgroups over the launch where the masks are few
+  int band = (16 * 256 + W - 1) / W;
+  if (band < 1) band = 1;
+  if (band > EA_MASK_MAXR) band = EA_MASK_MAXR;
+  while (band > 1 && (long long)((H + band - 1) / band) * n_masks < 1024) band = (band + 1) / 2;
+  p.band = band;
+  auto kfn = ea_mask_post_tab_kernel;
+  EA_LAUNCH(kfn, dim3((unsigned)((H + band - 1) / band), (unsigned)n_masks), dim3(256), mask_tab_lds(W), stream, p);
+  return ea_launch_status();
 }
 
 extern "C" int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
                                                int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
                                                int* stats, void* stream) {
-  if (!low_res || !stats) return EA_ERR_BAD_ARG;   // mask == NULL: statistics only (no mask is written)
-  if (n_masks <= 0 || lh <= 0 || lw <= 0 || img_size <= 0 || in_h <= 0 || in_w <= 0 || H <= 0 || W <= 0) return EA_ERR_BAD_SHAPE;
-  if (in_h > img_size || in_w > img_size || (long long)H * W > 0x3fffffffLL || lw > 4096) return EA_ERR_BAD_SHAPE;
+  return ea_sam_mask_postprocess_ex(low_res, index, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, offset, mask, stats, 0, stream);
+}
+
+extern "C" int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
+                                       int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
+                                       void* stream) {
+  return ea_sam_mask_postprocess_ex(low_res, nullptr, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, offset, mask, stats, 0, stream);
+}
+
+extern "C" int ea_sam_id_map(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
+                             int H, int W, float threshold, int id_base, int* idmap, void* stream) {
+  if (!low_res || !idmap) return EA_ERR_BAD_ARG;
+  if (id_base < 0) return EA_ERR_BAD_ARG;
   MaskPostParams p;
-  p.low = low_res; p.index = index; p.mask = mask; p.stats = stats;
-  p.lh = lh; p.lw = lw; p.S = img_size; p.in_h = in_h; p.in_w = in_w; p.H = H; p.W = W;
-  p.thr = threshold; p.off = offset;
-  int bx = (H * W + 256 * 8 - 1) / (256 * 8);      // ~8 pixels per thread
-  if (bx < 1) bx = 1;
-  if (bx > 1024) bx = 1024;
-  auto kfn = ea_mask_post_kernel;
-  EA_LAUNCH(kfn, dim3((unsigned)bx, (unsigned)n_masks), dim3(256), 256 * 6 * (int)sizeof(int), stream, p);
-  return ea_launch_status();
+  const int st = mask_post_fill(p, low_res, index, n_masks, lh, lw, img_size, in_h, in_w, H, W, threshold, 0.0f);
+  if (st != EA_OK) return st;
+  if (W > EA_MASK_MAXW || H > 65535) return EA_ERR_UNSUPPORTED;
+  if (!index && n_masks > EA_ID_MAP_MAXN) return EA_ERR_UNSUPPORTED;   // pieces need a selection to address
+  p.idmap = idmap;
+  auto kfn = ea_sam_id_map_kernel;
+  // pieces of at most EA_ID_MAP_MAXN records (their places in `low` live in LDS); a piece raises the map over the pieces before
+  for (int s0 = 0; s0 < n_masks; s0 += EA_ID_MAP_MAXN) {
+    p.n = n_masks - s0 < EA_ID_MAP_MAXN ? n_masks - s0 : EA_ID_MAP_MAXN;
+    p.index = index ? index + s0 : nullptr;
+    p.id_base = id_base + s0;
+    const int lds = 128 + EA_MASK_MAXR * (int)sizeof(MaskRow) + 256 * 20 + p.n * 4;
+    EA_LAUNCH(kfn, dim3((unsigned)((W + 255) / 256), (unsigned)H), dim3(256), lds, stream, p);
+    const int ls = ea_launch_status();
+    if (ls != EA_OK) return ls;
+  }
+  return EA_OK;
 }
 
 // ---- fused entry points (several launches on the caller's stream, one call) ----

@@ -421,6 +421,170 @@ __global__ __launch_bounds__(256, 2) void ea_sam_t2i_kernel(SamT2iParams p) {
   for (int j = 0; j < 16; ++j) *reinterpret_cast<f32x4*>(dst + 16 * j) = acc[j] * inv;
 }
 
+
+// ---- the 7-token side of the two cross attentions, folded per head (round 6).  ea_sam_t2i / ea_sam_i2t take the token side
+// as per-prompt matrices with one row per (head, token): G[h*8 + j] = Wk_h^T q_hj, G2[h*8 + j] = Wq_h^T k_hj, VO[.][s] = Wo_h v_hj.
+// Rounds 3-5 formed them with torch: a batched fp32 einsum (58 MB written for 1024 prompts), a cast, a zero fill and a strided
+// copy into the padded fp16 operand -- four launches and ~150 us per operand, seven operands per decoder pass.  Here: one
+// launch per operand, one workgroup per prompt, thread c owns output column c (its 16 weights per head in registers), the
+// [64][256] fp16 result goes through LDS so that either layout leaves in 16-byte pieces.
+struct SamFoldParams {
+  const float* x;      // [B][n][heads * d]
+  const float* w;      // [heads][d][256]
+  const int* perm;     // storage position s -> h * 8 + j, or null (identity)
+  f16* out;            // (b, s, c) at b * 64 * 256 + (cs ? c * 64 + s : s * 256 + c)
+  int B, n, d, cs;
+};
+
+constexpr int FOLD_PITCH = SAM_C + 8;   // fp16 elements per staged row
+
+template <int D>
+__global__ __launch_bounds__(256) void ea_sam_fold_kernel(SamFoldParams p) {
+  EA_SMEM(smem);
+  float* xs = reinterpret_cast<float*>(smem);                          // [8][8 * D]
+  int* inv = reinterpret_cast<int*>(smem + 8 * 8 * D * 4);             // [64]: h * 8 + j -> s
+  f16* tile = reinterpret_cast<f16*>(smem + 8 * 8 * D * 4 + 256);      // [64][FOLD_PITCH]
+  const int c = threadIdx.x, b = blockIdx.x;
+  const int row = 8 * D;
+  for (int i = c; i < 8 * row; i += 256) xs[i] = i < p.n * row ? p.x[(long long)b * p.n * row + i] : 0.0f;
+  if (c < 64) inv[p.perm ? p.perm[c] : c] = c;
+  __syncthreads();
+#pragma unroll 1
+  for (int h = 0; h < 8; ++h) {
+    float w[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) w[e] = p.w[(h * D + e) * SAM_C + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float acc = 0.0f;
+      const float* xr = xs + j * row + h * D;
+#pragma unroll
+      for (int e = 0; e < D; ++e) acc += xr[e] * w[e];
+      tile[inv[h * 8 + j] * FOLD_PITCH + c] = (f16)acc;      // rows of the absent tokens (j >= n) are zero: xs is
+    }
+  }
+  __syncthreads();
+  f16* out = p.out + (long long)b * 64 * SAM_C;
+  if (!p.cs) {
+    for (int i = c; i < 64 * (SAM_C / 8); i += 256) {
+      const int s = i / (SAM_C / 8), c8 = (i - s * (SAM_C / 8)) * 8;
+      ea_st8(out + s * SAM_C + c8, *reinterpret_cast<const f16x8*>(tile + s * FOLD_PITCH + c8));
+    }
+  } else {
+    for (int i = c; i < SAM_C * 8; i += 256) {
+      const int cc = i >> 3, s8 = (i & 7) * 8;
+      f16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[(s8 + e) * FOLD_PITCH + cc];
+      ea_st8(out + cc * 64 + s8, v);
+    }
+  }
+}
+
+// ---- and back: the token -> image attention's context rows through the value projection,
+//   out[b][j][h * d + e] = bias[h * d + e] + sum_c ctx[b][h * 8 + j][c] * w[c][h * d + e]
+// (ctx = ea_sam_t2i_f16's fp32 [B][64][256]).  One workgroup per prompt; the 64 context rows are staged in LDS, thread
+// (h, e) walks its weight row once for all of the head's tokens.
+struct SamUnfoldParams {
+  const float* ctx;    // [B][64][256]
+  const float* w;      // [256][heads * d]: the projection's weight transposed
+  const float* bias;   // [heads * d] or null
+  float* out;          // [B][n][heads * d]
+  int B, n, d;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void ea_sam_unfold_kernel(SamUnfoldParams p) {
+  EA_SMEM(smem);
+  float* cs = reinterpret_cast<float*>(smem);                          // [64][256 + 4]
+  constexpr int PITCH = SAM_C + 4;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const float* ctx = p.ctx + (long long)b * 64 * SAM_C;
+  for (int i = tid; i < 64 * (SAM_C / 4); i += 256) {
+    const int s = i / (SAM_C / 4), c4 = (i - s * (SAM_C / 4)) * 4;
+    *reinterpret_cast<f32x4*>(cs + s * PITCH + c4) = *reinterpret_cast<const f32x4*>(ctx + s * SAM_C + c4);
+  }
+  __syncthreads();
+  // 8 * D (head, e) pairs; with D = 16 the 256 threads split each pair's tokens in two halves
+  constexpr int PAIRS = 8 * D, SPLIT = 256 / PAIRS;       // D = 16: 128 pairs, 2 token groups; D = 32: 256 pairs, 1
+  const int pair = tid % PAIRS, grp = tid / PAIRS;
+  const int h = pair / D;
+  const float* wr = p.w + pair;                            // w^T: [256][heads * d], a wave reads 256 consecutive bytes per c
+  constexpr int NJ = 8 / SPLIT;                            // tokens grp, grp + SPLIT, ... of the head
+  float acc[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) acc[i] = 0.0f;
+  for (int c4 = 0; c4 < SAM_C; c4 += 4) {
+    f32x4 w4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w4[e] = wr[(c4 + e) * PAIRS];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(cs + (h * 8 + grp + SPLIT * i) * PITCH + c4);
+      acc[i] += x4[0] * w4[0] + x4[1] * w4[1] + x4[2] * w4[2] + x4[3] * w4[3];
+    }
+  }
+  const float bv = p.bias ? p.bias[pair] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const int j = grp + SPLIT * i;
+    if (j < p.n) p.out[((long long)b * p.n + j) * PAIRS + pair] = acc[i] + bv;
+  }
+}
+
+
+// ---- the tokens' self attention (TwoWayAttentionBlock.self_attn on the <= 8 prompt tokens, 8 heads): one workgroup per
+// prompt, everything in fp32 from the fp16 projections (rounds 3-5: two batched fp32 matmuls of 8192 7 x 32 x 7 problems,
+// ~95 us each, plus the casts and transposes around them).
+struct SamSelfParams {
+  const f16* q; const f16* k; const f16* v;   // [B][n][256] (row stride 256)
+  f16* out;                                   // [B][n][256]
+  int B, n;
+  float scale;
+};
+
+__global__ __launch_bounds__(256) void ea_sam_token_self_attn_kernel(SamSelfParams p) {
+  EA_SMEM(smem);
+  float* qs = reinterpret_cast<float*>(smem);      // [8][256]
+  float* ks = qs + 8 * SAM_C;
+  float* vs = ks + 8 * SAM_C;
+  float* sc = vs + 8 * SAM_C;                      // [8 heads][8][8] scores -> probabilities
+  const int tid = threadIdx.x, b = blockIdx.x, n = p.n;
+  const long long base = (long long)b * n * SAM_C;
+  for (int i = tid; i < n * SAM_C; i += 256) {
+    qs[i] = (float)p.q[base + i]; ks[i] = (float)p.k[base + i]; vs[i] = (float)p.v[base + i];
+  }
+  __syncthreads();
+  for (int i = tid; i < 8 * n * n; i += 256) {
+    const int h = i / (n * n), r = i - h * n * n, qi = r / n, kj = r - qi * n;
+    const float* a = qs + qi * SAM_C + h * 32;
+    const float* c = ks + kj * SAM_C + h * 32;
+    float acc = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 32; ++e) acc += a[e] * c[e];
+    sc[(h * 8 + qi) * 8 + kj] = acc * p.scale;
+  }
+  __syncthreads();
+  if (tid < 8 * n) {
+    const int h = tid / n, qi = tid - h * n;
+    float* row = sc + (h * 8 + qi) * 8;
+    float m = row[0];
+    for (int j = 1; j < n; ++j) m = fmaxf(m, row[j]);
+    float sum = 0.0f;
+    for (int j = 0; j < n; ++j) { const float e = expf(row[j] - m); row[j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < n; ++j) row[j] *= inv;
+  }
+  __syncthreads();
+  const int h = tid >> 5;                            // thread = output channel h * 32 + e
+  for (int qi = 0; qi < n; ++qi) {
+    const float* row = sc + (h * 8 + qi) * 8;
+    float acc = 0.0f;
+    for (int j = 0; j < n; ++j) acc += row[j] * vs[j * SAM_C + tid];
+    p.out[base + qi * SAM_C + tid] = (f16)acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int ea_sam_vo_perm(int s) { return (s & ~31) + sam_perm32(s & 31); }
@@ -473,5 +637,52 @@ extern "C" int ea_sam_t2i_f16(const void* k, long long k_sb, const void* pe, con
   auto kfn = ea_sam_t2i_kernel;
   ea_allow_big_lds(kfn, smem);
   EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p);
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_fold_heads_f16(const float* x, const float* w, const int* perm, void* out, int B, int n, int heads, int d_head,
+                                     int C, int c_major, void* stream) {
+  if (!x || !w || !out) return EA_ERR_BAD_ARG;
+  if (C != SAM_C || heads != 8 || (d_head != 16 && d_head != 32)) return EA_ERR_UNSUPPORTED;
+  if (B <= 0 || n <= 0 || n > 8) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return EA_ERR_BAD_ARG;
+  SamFoldParams p;
+  p.x = x; p.w = w; p.perm = perm; p.out = (f16*)out; p.B = B; p.n = n; p.d = d_head; p.cs = c_major ? 1 : 0;
+  const int smem = 8 * 8 * d_head * 4 + 256 + 64 * FOLD_PITCH * 2;
+  if (d_head == 16) { auto kfn = ea_sam_fold_kernel<16>; EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p); }
+  else { auto kfn = ea_sam_fold_kernel<32>; EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p); }
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_unfold_heads_f32(const float* ctx, const float* w, const float* bias, float* out, int B, int n, int heads,
+                                       int d_head, int C, void* stream) {
+  if (!ctx || !w || !out) return EA_ERR_BAD_ARG;
+  if (C != SAM_C || heads != 8 || (d_head != 16 && d_head != 32)) return EA_ERR_UNSUPPORTED;
+  if (B <= 0 || n <= 0 || n > 8) return EA_ERR_BAD_SHAPE;
+  if (((uintptr_t)ctx | (uintptr_t)w) & 15) return EA_ERR_BAD_ARG;
+  SamUnfoldParams p;
+  p.ctx = ctx; p.w = w; p.bias = bias; p.out = out; p.B = B; p.n = n; p.d = d_head;
+  const int smem = 64 * (SAM_C + 4) * 4;
+  if (d_head == 16) {
+    auto kfn = ea_sam_unfold_kernel<16>;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p);
+  } else {
+    auto kfn = ea_sam_unfold_kernel<32>;
+    ea_allow_big_lds(kfn, smem);
+    EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), smem, stream, p);
+  }
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_token_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int n, int heads, int C,
+                                          float scale, void* stream) {
+  if (!q || !k || !v || !out) return EA_ERR_BAD_ARG;
+  if (C != SAM_C || heads != 8) return EA_ERR_UNSUPPORTED;
+  if (B <= 0 || n <= 0 || n > 8) return EA_ERR_BAD_SHAPE;
+  SamSelfParams p;
+  p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.out = (f16*)out; p.B = B; p.n = n; p.scale = scale;
+  auto kfn = ea_sam_token_self_attn_kernel;
+  EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), (3 * 8 * SAM_C + 8 * 64) * 4, stream, p);
   return ea_launch_status();
 }

@@ -704,9 +704,10 @@ def relpos_tables(q, heads, dim_head, S, rel_h, rel_w):
     return bh, bw
 
 
-def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, offset, want_masks=True, index=None):
+def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, offset, want_masks=True, index=None, kernel=0):
     """low fp32 [n, lh, lw] -> (mask uint8 [k, H, W] or None, stats int32 [k, 6] = inter, union, xmin, ymin, xmax, ymax);
-    k = n, or len(index) when `index` (int32 device tensor) selects the masks to process."""
+    k = n, or len(index) when `index` (int32 device tensor) selects the masks to process.  kernel: 0 = the library's choice,
+    1 / 2 = the per-pixel / the tabled kernel (same bits; tools)."""
     _check_dev(low)
     _dense(low, index)
     n, lh, lw = low.shape
@@ -717,11 +718,34 @@ def sam_mask_postprocess(low, input_size, original_size, img_size, threshold, of
     if k == 0:
         return mask, stats
     ev = _prof_begin()
-    st = _lib().ea_sam_mask_postprocess_indexed(_p(low), _p(index), k, lh, lw, img_size, input_size[0], input_size[1], H, W,
-                                                float(threshold), float(offset), _p(mask), _p(stats), _stream())
+    st = _lib().ea_sam_mask_postprocess_ex(_p(low), _p(index), k, lh, lw, img_size, input_size[0], input_size[1], H, W,
+                                           float(threshold), float(offset), _p(mask), _p(stats), int(kernel), _stream())
     _prof_end(ev, 0.0, f"sam-mask-post n{k} {H}x{W}")
     L.check(st, "ea_sam_mask_postprocess")
     return mask, stats
+
+
+SAM_ID_MAP_MAX_W = 2048
+
+
+def sam_id_map(low, input_size, original_size, img_size, threshold, index=None, id_base=0, out=None):
+    """show_anns' id map from the records' low-resolution logits (ea_sam_id_map): out int32 [H, W] (zeros when not given)
+    becomes max(out, id_base + 1 + the largest slot whose post-processed mask covers the pixel); slot i = low[index[i]]."""
+    _check_dev(low)
+    _dense(low, index, out)
+    n, lh, lw = low.shape
+    k = n if index is None else int(index.shape[0])
+    H, W = original_size
+    if out is None:
+        out = torch.zeros((H, W), dtype=torch.int32, device=low.device)
+    if k == 0:
+        return out
+    ev = _prof_begin()
+    st = _lib().ea_sam_id_map(_p(low), _p(index), k, lh, lw, img_size, input_size[0], input_size[1], H, W, float(threshold),
+                              int(id_base), _p(out), _stream())
+    _prof_end(ev, 0.0, f"sam-id-map n{k} {H}x{W}")
+    L.check(st, "ea_sam_id_map")
+    return out
 
 
 def sam_vo_perm(device):
@@ -754,6 +778,48 @@ def sam_t2i(k, pe, g, scale, B):
     st = _lib().ea_sam_t2i_f16(_p(k), 0 if k.dim() == 2 else T * Cc, _p(pe), _p(g), float(scale), _p(ctx), B, T, Cc, _stream())
     L.check(st, "ea_sam_t2i_f16")
     return ctx
+
+
+def sam_token_self_attn(q, k, v, scale):
+    """The prompt tokens' self attention core (ea_sam_token_self_attn_f16): q / k / v fp16 [B, n <= 8, 256] -> fp16 [B, n, 256],
+    8 heads, fp32 inside."""
+    _check_dev(q, k, v)
+    _dense(q, k, v)
+    B, n, Cc = q.shape
+    out = torch.empty((B, n, Cc), dtype=torch.float16, device=q.device)
+    st = _lib().ea_sam_token_self_attn_f16(_p(q), _p(k), _p(v), _p(out), B, n, 8, Cc, float(scale), _stream())
+    L.check(st, "ea_sam_token_self_attn_f16")
+    return out
+
+
+def sam_fold_heads(x, w, perm=None, c_major=False):
+    """The token side of a cross attention folded per head (ea_sam_fold_heads_f16): x fp32 [B, n <= 8, 8 * d], w fp32
+    [8, d, 256] -> fp16 [B, 64, 256] (row h * 8 + j = W_h^T x_hj; rows of absent tokens zero), or [B, 256, 64] with
+    column s = row perm[s] when c_major (perm: int32 [64] device tensor)."""
+    _check_dev(x, w)
+    _dense(x, w, perm)
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    B, n, hd = x.shape
+    heads, d, Cc = w.shape
+    assert heads * d == hd
+    out = torch.empty((B, Cc, 64) if c_major else (B, 64, Cc), dtype=torch.float16, device=x.device)
+    st = _lib().ea_sam_fold_heads_f16(_p(x), _p(w), _p(perm), _p(out), B, n, heads, d, Cc, 1 if c_major else 0, _stream())
+    L.check(st, "ea_sam_fold_heads_f16")
+    return out
+
+
+def sam_unfold_heads(ctx, wt, bias, n):
+    """ea_sam_t2i_f16's context rows through the value projection (ea_sam_unfold_heads_f32): ctx fp32 [B, 64, 256], wt fp32
+    [256, 8 * d] (the projection weight transposed), bias fp32 [8 * d] -> fp32 [B, n, 8 * d]."""
+    _check_dev(ctx, wt)
+    _dense(ctx, wt, bias)
+    assert ctx.dtype == torch.float32 and wt.dtype == torch.float32
+    B, _, Cc = ctx.shape
+    hd = wt.shape[1]
+    out = torch.empty((B, n, hd), dtype=torch.float32, device=ctx.device)
+    st = _lib().ea_sam_unfold_heads_f32(_p(ctx), _p(wt), _p(bias), _p(out), B, n, 8, hd // 8, Cc, _stream())
+    L.check(st, "ea_sam_unfold_heads_f32")
+    return out
 
 
 def sam_upscale_tail(u0, ln_g, ln_b, eps, w1, b1, hyper, B, h, w, m0=0, nm=4, out=None):

@@ -321,6 +321,20 @@ int ea_sam_mask_postprocess(const float* low_res, int n_masks, int lh, int lw, i
 int ea_sam_mask_postprocess_indexed(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size,
                                     int in_h, int in_w, int H, int W, float threshold, float offset, unsigned char* mask,
                                     int* stats, void* stream);
+/* The same with the kernel named (tests / tools: A/B of the two forms, which agree bit for bit): 0 = the library's choice,
+ * 1 = the per-pixel kernel (any width), 2 = the tabled kernel (column / row tables of the two resizes in LDS, taps that
+ * coincide read once; W <= 2048, else EA_ERR_UNSUPPORTED). */
+int ea_sam_mask_postprocess_ex(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size, int in_h,
+                               int in_w, int H, int W, float threshold, float offset, unsigned char* mask, int* stats,
+                               int kernel, void* stream);
+/* show_anns' id map (sam2image.py:92-115 over SamAutomaticMaskGenerator.generate's list, sam2image.py:117-120) from the
+ * records' low-resolution logits, without their full-resolution masks:
+ *     idmap[y][x] = max(idmap[y][x], id_base + 1 + max{ s < n_masks : postprocessed mask s covers (y, x) })
+ * with mask s = ea_sam_mask_postprocess_indexed's mask of slot s (same arithmetic, same bit per pixel); a pixel no mask covers
+ * keeps its value.  idmap: device int32 [H][W], initialised by the caller (zeros for a whole list; id_base = the number of
+ * records already painted when a list is processed in pieces).  W <= 2048. */
+int ea_sam_id_map(const float* low_res, const int* index, int n_masks, int lh, int lw, int img_size, int in_h, int in_w,
+                  int H, int W, float threshold, int id_base, int* idmap, void* stream);
 
 /* SAM mask decoder, image-token side (segment_anything TwoWayAttentionBlock / MaskDecoder, third party; reference call
  * sites sam2image.py:71,118, editany_lora.py:523-543), fused per token (csrc/ea_sam.hip).
@@ -342,6 +356,24 @@ int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_s
  * arbitrary), k fp16 [B][T][256] (k_sb = 0: shared), pe fp16 [T][256], ctx fp32 [B][64][256].  T % 64 == 0, C = 256. */
 int ea_sam_t2i_f16(const void* k, long long k_sb, const void* pe, const void* g, float scale, float* ctx, int B, int T, int C,
                    void* stream);
+/* The 7-token side of those two attentions (round 6; TwoWayAttentionBlock's q / k / v / out projections of the token
+ * side, segment_anything modeling/transformer.py, third party), one launch per operand instead of einsum + cast + pad:
+ * ea_sam_fold_heads_f16: out[b][s][c] = sum_e x[b][j][h * d_head + e] * w[h][e][c] with h * 8 + j = perm ? perm[s] : s, zero
+ *   rows for the absent tokens j >= n.  x fp32 [B][n][heads * d_head], w fp32 [heads][d_head][C], perm int32 [64] on the
+ *   device or NULL; out fp16 [B][64][C] (c_major = 0: ea_sam_t2i_f16's g, ea_sam_i2t_f16's g2) or [B][C][64] (c_major = 1:
+ *   ea_sam_i2t_f16's vo with perm = ea_sam_vo_perm and w[h][e][c] = Wo[c][h * d_head + e]).  heads = 8, C = 256, d_head 16 | 32.
+ * ea_sam_unfold_heads_f32: out[b][j][h * d_head + e] = bias[h * d_head + e] + sum_c ctx[b][h * 8 + j][c] * wt[c][h * d_head + e]:
+ *   ea_sam_t2i_f16's ctx fp32 [B][64][C] through the value projection (wt = its weight transposed, fp32 [C][heads * d_head];
+ *   bias fp32 or NULL) -> out fp32 [B][n][heads * d_head]. */
+/* ea_sam_token_self_attn_f16: TwoWayAttentionBlock.self_attn's core on the prompt tokens: out[b] = per head
+ * softmax(scale * q_h k_h^T) v_h over the n <= 8 tokens of prompt b, fp32 arithmetic on the fp16 projections q / k / v
+ * [B][n][256] (dense) -> out fp16 [B][n][256].  heads = 8, C = 256 (head width 32). */
+int ea_sam_token_self_attn_f16(const void* q, const void* k, const void* v, void* out, int B, int n, int heads, int C,
+                               float scale, void* stream);
+int ea_sam_fold_heads_f16(const float* x, const float* w, const int* perm, void* out, int B, int n, int heads, int d_head, int C,
+                          int c_major, void* stream);
+int ea_sam_unfold_heads_f32(const float* ctx, const float* wt, const float* bias, float* out, int B, int n, int heads, int d_head,
+                            int C, void* stream);
 /* ea_sam_upscale_tail_f16: MaskDecoder.output_upscaling from the first transposed conv's output on (u0 fp16 [B*h*w*4][64],
  * rows ordered (b, y, x, dy, dx)): LayerNorm2d(64, eps) + GELU, ConvTranspose2d(64 -> 32, k 2, s 2) as a per-row product
  * with w1 fp16 [128][64] (row (ddy * 2 + ddx) * 32 + c) + b1, GELU, and the product with the hypernetwork outputs

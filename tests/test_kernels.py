@@ -56,7 +56,7 @@ def _cases_added_in_round_6_draw_from_their_own_stream(request):
     exactly as it was."""
     name = request.node.name
     params = getattr(getattr(request.node, "callspec", None), "params", {})
-    own = "three_stage" in name or str(params.get("variant", "")) in ("33", "34")
+    own = "three_stage" in name or "mask_tabled" in name or "id_map" in name or "fold_heads" in name or "token_self" in name or str(params.get("variant", "")) in ("33", "34")
     _OWN_RNG[0] = np.random.default_rng(abs(hash(name)) % (1 << 31)) if own else None
     yield
     _OWN_RNG[0] = None
@@ -480,6 +480,110 @@ def test_sam_mask_postprocess(kb, hw, lres, S):
         else:
             assert got_s[i, 2:].tolist() == [xs.min(), ys.min(), xs.max(), ys.max()]
     assert not got_m[3].any()
+
+
+MASK_GEOMETRIES = [((64, 64), 32, 128), ((50, 72), 32, 128), ((37, 29), 16, 64), ((150, 200), 16, 64), ((96, 300), 24, 96),
+                   ((33, 520), 16, 64)]
+
+
+def _mask_geometry(hw, S):
+    H, W = hw
+    scale = S / max(H, W)
+    return int(H * scale + 0.5), int(W * scale + 0.5)
+
+
+@pytest.mark.parametrize("hw,lres,S", MASK_GEOMETRIES)
+def test_sam_mask_tabled_kernel_equals_per_pixel_kernel(kb, hw, lres, S):
+    """Round 6: the tabled mask post-processing kernel (column / row tables of the two resizes built once per workgroup,
+    coinciding taps read once) writes the masks and statistics of the per-pixel kernel BIT FOR BIT -- down-sampling chains
+    (every tap pair in one cell: the 4-load loop), up-sampling and odd sizes (the 8- and 16-load loops), more than one column
+    per thread, ragged last band, an index selection, statistics only."""
+    H, W = hw
+    in_h, in_w = _mask_geometry(hw, S)
+    n = 7
+    low = f32(n, lres, lres, scale=2.0)
+    low[2] = -5.0
+    low[5] = 6.0
+    index = np.array([6, 0, 2, 5, 3], np.int32)
+    thr, off = 0.1, 0.7
+    got = {}
+    for kernel in (1, 2, 0):
+        for idx in (None, index):
+            k = n if idx is None else len(idx)
+            mask = kb.zeros((k, H, W), np.uint8)
+            stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (k, 1)))
+            st = kb.lib.ea_sam_mask_postprocess_ex(ptr(low), None if idx is None else ptr(idx), k, lres, lres, S, in_h, in_w, H, W, thr, off,
+                                                   ptr(mask), ptr(stats), kernel, kb.stream)
+            assert st == 0
+            got[kernel, idx is None] = (kb.down(mask).copy(), kb.down(stats).copy())
+            stats2 = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (k, 1)))
+            assert kb.lib.ea_sam_mask_postprocess_ex(ptr(low), None if idx is None else ptr(idx), k, lres, lres, S, in_h, in_w, H, W, thr,
+                                                     off, None, ptr(stats2), kernel, kb.stream) == 0
+            assert np.array_equal(kb.down(stats2), got[kernel, idx is None][1])          # statistics only: the same statistics
+    for whole in (True, False):
+        m1, s1 = got[1, whole]
+        for kernel in (2, 0):
+            m2, s2 = got[kernel, whole]
+            assert np.array_equal(m1, m2) and np.array_equal(s1, s2)
+    assert np.array_equal(got[2, False][0], got[2, True][0][index])
+    assert got[2, True][0][5].all() and not got[2, True][0][2].any()
+
+
+@pytest.mark.parametrize("hw,lres,S", MASK_GEOMETRIES[:4])
+def test_sam_id_map_equals_painting_the_masks_in_order(kb, hw, lres, S):
+    """ea_sam_id_map == show_anns over the records' masks (sam2image.py:92-115: record i paints i + 1, later records over
+    earlier ones): the largest covering slot + 1 per pixel, from the low-resolution logits alone; a list painted in two
+    pieces (id_base) gives the map of the whole list; uncovered pixels keep what the map held."""
+    H, W = hw
+    in_h, in_w = _mask_geometry(hw, S)
+    n = 9
+    low = f32(n, lres, lres, scale=2.0) - 1.5           # sparse masks: most pixels walk several records
+    low[4] = -9.0
+    index = np.array([8, 1, 4, 0, 7, 3, 2], np.int32)
+    thr = 0.0
+    k = len(index)
+    mask = kb.zeros((k, H, W), np.uint8)
+    stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (k, 1)))
+    assert kb.lib.ea_sam_mask_postprocess_indexed(ptr(low), ptr(index), k, lres, lres, S, in_h, in_w, H, W, thr, 1.0, ptr(mask),
+                                                  ptr(stats), kb.stream) == 0
+    m = kb.down(mask).astype(np.int32)
+    want = (m * np.arange(1, k + 1, dtype=np.int32)[:, None, None]).max(0)
+    assert (want == 0).any() and len(np.unique(want)) >= 4
+    idm = kb.zeros((H, W), np.int32)
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(index), k, lres, lres, S, in_h, in_w, H, W, thr, 0, ptr(idm), kb.stream) == 0
+    assert np.array_equal(kb.down(idm), want)
+    # in two pieces, on a map that already holds something
+    first = index[:3].copy()
+    rest = index[3:].copy()
+    idm2 = kb.up(np.full((H, W), -7, np.int32))
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(first), 3, lres, lres, S, in_h, in_w, H, W, thr, 0, ptr(idm2), kb.stream) == 0
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(rest), k - 3, lres, lres, S, in_h, in_w, H, W, thr, 3, ptr(idm2), kb.stream) == 0
+    assert np.array_equal(kb.down(idm2), np.where(want == 0, -7, want))
+    # identity selection
+    idm3 = kb.zeros((H, W), np.int32)
+    assert kb.lib.ea_sam_id_map(ptr(low), None, n, lres, lres, S, in_h, in_w, H, W, thr, 0, ptr(idm3), kb.stream) == 0
+    mask9 = kb.zeros((n, H, W), np.uint8)
+    stats9 = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (n, 1)))
+    assert kb.lib.ea_sam_mask_postprocess(ptr(low), n, lres, lres, S, in_h, in_w, H, W, thr, 1.0, ptr(mask9), ptr(stats9), kb.stream) == 0
+    assert np.array_equal(kb.down(idm3), (kb.down(mask9).astype(np.int32) * np.arange(1, n + 1, dtype=np.int32)[:, None, None]).max(0))
+
+
+def test_sam_id_map_list_longer_than_one_piece(kb):
+    """More records than one launch keeps in LDS (8192): the entry point walks the list in pieces, each raising the map."""
+    H, W, lres, S = 16, 16, 8, 32
+    n = 8192 + 37
+    low = f32(n, lres, lres, scale=2.0) - 3.0
+    index = _rng().permutation(n).astype(np.int32)
+    mask = kb.zeros((n, H, W), np.uint8)
+    stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (n, 1)))
+    assert kb.lib.ea_sam_mask_postprocess_indexed(ptr(low), ptr(index), n, lres, lres, S, S, S, H, W, 0.0, 1.0, ptr(mask), ptr(stats),
+                                                  kb.stream) == 0
+    want = (kb.down(mask).astype(np.int32) * np.arange(1, n + 1, dtype=np.int32)[:, None, None]).max(0)
+    assert want.min() < 8192 < want.max()
+    idm = kb.zeros((H, W), np.int32)
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(index), n, lres, lres, S, S, S, H, W, 0.0, 0, ptr(idm), kb.stream) == 0
+    assert np.array_equal(kb.down(idm), want)
+    assert kb.lib.ea_sam_id_map(ptr(low), None, n, lres, lres, S, S, S, H, W, 0.0, 0, ptr(idm), kb.stream) == -3   # pieces need a selection
 
 
 def test_layernorm_rows_and_gather_add(kb):
@@ -1815,6 +1919,52 @@ def test_sam_t2i_fused(kb, B, T, shared):
     ref = torch.einsum("bqt,btc->bqc", P, kk)
     assert relerr(kb.down(ctx), ref.numpy()) < 3e-3
     assert kb.lib.ea_sam_t2i_f16(ptr(k), 0, ptr(pe), ptr(g), 0.25, ptr(ctx), B, 100, Cc, kb.stream) != 0     # T % 64
+
+
+@pytest.mark.parametrize("B,n,d", [(3, 7, 16), (2, 8, 16), (2, 5, 32)])
+def test_sam_fold_heads_and_unfold_heads(kb, B, n, d):
+    """Round 6: the token side of the decoder's cross attentions in one launch per operand.  ea_sam_fold_heads_f16 ==
+    einsum("bjhd,hdc->bhjc") cast to fp16 into the zero-padded [B, 64, 256] operand (row-major for g / g2; column-major in
+    ea_sam_vo_perm's order for vo); ea_sam_unfold_heads_f32 == the value projection of ea_sam_t2i's context rows."""
+    h, Cc = 8, 256
+    x = f32(B, n, h * d)
+    w = f32(h, d, Cc, scale=0.3)
+    want = torch.zeros(B, h, 8, Cc)
+    want[:, :, :n] = torch.einsum("bjhd,hdc->bhjc", t(x).reshape(B, n, h, d), t(w))
+    want = want.reshape(B, 64, Cc)
+    out = kb.up(np.full((B, 64, Cc), 7.0, np.float16))
+    assert kb.lib.ea_sam_fold_heads_f16(ptr(x), ptr(w), None, ptr(out), B, n, h, d, Cc, 0, kb.stream) == 0
+    got = kb.down(out).astype(np.float32)
+    assert np.abs(got - want.numpy()).max() <= 2e-3 * np.abs(want.numpy()).max()
+    assert not got.reshape(B, h, 8, Cc)[:, :, n:].any()
+    perm = np.array([kb.lib.ea_sam_vo_perm(s) for s in range(64)], np.int32)
+    assert sorted(perm.tolist()) == list(range(64))
+    out_c = kb.up(np.full((B, Cc, 64), 7.0, np.float16))
+    assert kb.lib.ea_sam_fold_heads_f16(ptr(x), ptr(w), ptr(perm), ptr(out_c), B, n, h, d, Cc, 1, kb.stream) == 0
+    assert np.array_equal(kb.down(out_c), np.ascontiguousarray(kb.down(out)[:, perm].transpose(0, 2, 1)))     # the same numbers, vo's layout
+    # and back
+    ctx = f32(B, 64, Cc)
+    wv = f32(h * d, Cc, scale=0.2)
+    bv = f32(h * d)
+    o = kb.up(np.full((B, n, h * d), 7.0, np.float32))
+    assert kb.lib.ea_sam_unfold_heads_f32(ptr(ctx), ptr(np.ascontiguousarray(wv.T)), ptr(bv), ptr(o), B, n, h, d, Cc, kb.stream) == 0
+    ref = torch.einsum("bhjc,hdc->bjhd", t(ctx).reshape(B, h, 8, Cc)[:, :, :n], t(wv).reshape(h, d, Cc)) + t(bv).reshape(h, d)
+    assert relerr(kb.down(o), ref.reshape(B, n, h * d).numpy()) < 1e-5
+    assert kb.lib.ea_sam_fold_heads_f16(ptr(x), ptr(w), None, ptr(out), B, 9, h, d, Cc, 0, kb.stream) != 0
+    assert kb.lib.ea_sam_unfold_heads_f32(ptr(ctx), ptr(wv), None, ptr(o), B, n, h, 24, Cc, kb.stream) != 0
+
+
+@pytest.mark.parametrize("B,n", [(3, 7), (2, 8), (2, 3)])
+def test_sam_token_self_attn(kb, B, n):
+    """ea_sam_token_self_attn_f16 == softmax(q k^T / sqrt(32)) v per head on the prompt tokens, fp32 inside."""
+    q, k, v = f16(B, n, 256), f16(B, n, 256), f16(B, n, 256)
+    out = kb.zeros((B, n, 256), np.float16)
+    scale = 32 ** -0.5
+    assert kb.lib.ea_sam_token_self_attn_f16(ptr(q), ptr(k), ptr(v), ptr(out), B, n, 8, 256, scale, kb.stream) == 0
+    sp = lambda a: t(a).reshape(B, n, 8, 32).transpose(1, 2)
+    ref = (torch.softmax(sp(q) @ sp(k).transpose(-2, -1) * scale, -1) @ sp(v)).transpose(1, 2).reshape(B, n, 256)
+    assert np.abs(kb.down(out).astype(np.float32) - ref.numpy()).max() < 2e-3
+    assert kb.lib.ea_sam_token_self_attn_f16(ptr(q), ptr(k), ptr(v), ptr(out), B, 9, 8, 256, scale, kb.stream) != 0
 
 
 # ---------------------------------------------------------------------------------------------- twin launches

@@ -20,9 +20,28 @@ g0 = amg.SamAutomaticMaskGenerator(None, dec, pred_iou_thresh=-1e9, stability_sc
 sc = np.sort([r["stability_score"] for r in g0.generate(img, image_embedding=emb)])
 gen = amg.SamAutomaticMaskGenerator(None, dec, pred_iou_thresh=-1e9, stability_score_thresh=float(sc[-300]))
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-gen.generate_id_map(img, image_embedding=emb)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(REPS):
-    idm, n = gen.generate_id_map(img, image_embedding=emb)
-torch.cuda.synchronize()
-print(f"generate_id_map: {(time.perf_counter() - t0) / REPS * 1e3:.2f} ms per image, {n} records")
+
+
+def run(tag):
+    gen.generate_id_map(img, image_embedding=emb)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(REPS):
+        idm, n = gen.generate_id_map(img, image_embedding=emb)
+    torch.cuda.synchronize()
+    print(f"generate_id_map [{tag}]: {(time.perf_counter() - t0) / REPS * 1e3:.2f} ms per image, {n} records", flush=True)
+    return idm
+
+
+if "ab" in sys.argv[2:]:
+    # round 6 A/B: the per-pixel post-processing kernel + masks painted by torch (rounds 3-5) against the tabled kernel + ea_sam_id_map
+    import json
+    new_map = run("tabled kernel + id-map kernel")
+    post, max_w = ops.sam_mask_postprocess, ops.SAM_ID_MAP_MAX_W
+    ops.sam_mask_postprocess = lambda *a, **k: post(*a, **dict(k, kernel=1))
+    ops.SAM_ID_MAP_MAX_W = 0
+    old_map = run("per-pixel kernel + painted masks")
+    ops.sam_mask_postprocess, ops.SAM_ID_MAP_MAX_W = post, max_w
+    run("tabled kernel + id-map kernel, again")
+    print(json.dumps({"id_maps_identical": bool(torch.equal(new_map, old_map)), "labels": int(new_map.max())}))
+else:
+    run("shipped")
