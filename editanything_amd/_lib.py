@@ -91,6 +91,7 @@ SIGNATURES = {
     "ea_sam_mask_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "ea_sam_mask_postprocess_indexed": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "ea_sam_mask_postprocess_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _i, _vp]),
+    "ea_sam_upscale_f16": (_i, [_vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ea_sam_token_self_attn_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "ea_sam_fold_heads_f16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ea_sam_unfold_heads_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

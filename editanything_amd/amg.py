@@ -353,6 +353,13 @@ class SamPromptDecoder:
         nh = len(self.hyper)
         m0, nm = (1, nh - 1) if multimask_output else (0, 1)             # MaskDecoder.forward's slice, written densely
         masks = torch.empty((B, nm, 4 * h, 4 * w), dtype=torch.float32, device=k.device)
+        if T % 16 == 0 and C == 256 and self.c0 == 64 and self.c1 == 32:
+            # round 6: output_upscaling whole in ONE pass over the image tokens (the first transposed conv's [B*T*4, 64] output --
+            # 2 GB for the 1024 grid prompts -- is never stored)
+            ops.sam_upscale(k.reshape(B * T, C), self.up0_w, self.up0_b, self.up_ln[0], self.up_ln[1], 1e-6, self.up1_w, self.up1_b,
+                            hyper, B, h, w, m0, nm, out=masks)
+            iou = self._mlp3(self.iou_head, iou_tok)
+            return masks, iou[:, m0:m0 + nm]
         step = max(1, (1 << 30) // (T * C * 2))                          # operands of one launch stay under the 2-GiB buffer range
         for b0 in range(0, B, step):
             b1 = min(B, b0 + step)

@@ -287,6 +287,135 @@ __global__ __launch_bounds__(256, 2) void ea_sam_upscale_tail_kernel(SamTailPara
   }
 }
 
+// ---- output_upscaling in ONE pass (round 6): first transposed conv + everything ea_sam_upscale_tail does.  Rounds 3-5 ran the
+// first ConvTranspose2d(256 -> 64, 2, 2) as a plain contraction that wrote u0 = [B*T*4][64] fp16 (2.1 GB for 1024 prompts) for
+// the tail kernel to read back: 1.4 + 2.5 ms per image, the largest item of the mask decoder.  Here its [256 x 256] weight
+// lives in LDS as ready-made MFMA fragments (128 KB, loaded once per persistent workgroup), a wave (eight per workgroup, two per SIMD: one's matrix work under the other's GELUs) takes 16 image tokens,
+// multiplies them through (128 MFMAs), and runs the tail on the accumulators -- four sub-pixels x (LayerNorm2d + GELU, second
+// transposed conv, GELU, hypernetwork product) -- without u0 ever existing.  The accumulator layout (lane (c16, q4) holds
+// channels 16 j + 4 q4 + r of token c16) is not the K order of the second product's fragments; the contraction does not care
+// about K order, so the second weight's fragments (and the LayerNorm affine terms) are gathered in the order the lanes hold.
+struct SamUpParams {
+  const f16* k;                       // [B*T][256] image tokens after the transformer
+  const f16* w0; const float* b0;     // [256][256] (row (dy * 2 + dx) * 64 + c), [256]
+  const float* ln_g; const float* ln_b; float eps;   // [64]
+  const f16* w1; const float* b1;     // [128][64], [128]
+  const float* hyper;                 // [B][4][32]
+  float* masks;                       // [B][nm][4h][4w]
+  int B, h, w, m0, nm;
+};
+
+constexpr int UP_W0_LDS = 16 * 8 * 64 * 16;     // 128 KB: fragment (j, ks) of lane l at ((j * 8 + ks) * 64 + l) * 16
+
+__global__ __launch_bounds__(512, 1) void ea_sam_upscale_fused_kernel(SamUpParams p) {
+  EA_SMEM(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c16 = lane & 15, q4 = lane >> 4;
+  const int T = p.h * p.w;
+  for (int f = tid; f < 16 * 8 * 64; f += 512) {
+    const int l = f & 63, ks = (f >> 6) & 7, j = f >> 9;
+    *reinterpret_cast<f16x8*>(smem + f * 16) = ea_ld8(p.w0 + (16 * j + (l & 15)) * SAM_C + 32 * ks + 8 * (l >> 4));
+  }
+  // second product's weight fragments in the accumulators' channel order: K position (ks, q4, e) = channel 16 (2 ks + (e >> 2)) + 4 q4 + (e & 3)
+  f16x8 fw[8][2];
+  float lg[2][8], lb[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int ch = 16 * (2 * ks + hf) + 4 * q4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f16x4 w4 = *reinterpret_cast<const f16x4*>(p.w1 + (16 * j + c16) * 64 + ch);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fw[j][ks][4 * hf + r] = w4[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lg[ks][4 * hf + r] = p.ln_g[ch + r]; lb[ks][4 * hf + r] = p.ln_b[ch + r]; }
+    }
+  }
+  __syncthreads();
+  const long long ntiles = (long long)p.B * T / 16;
+  const int W4 = 4 * p.w;
+  for (long long tile = (long long)blockIdx.x * 8 + wave; tile < ntiles; tile += (long long)gridDim.x * 8) {
+    const long long t0 = tile * 16;
+    const int b = (int)(t0 / T);
+    f16x8 fk[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) fk[ks] = ea_ld8(p.k + (t0 + c16) * SAM_C + 32 * ks + 8 * q4);
+    const int tok = (int)(t0 - (long long)b * T) + c16;
+    const int y = tok / p.w, xx = tok - y * p.w;
+    const float* hy = p.hyper + (long long)b * 4 * 32;
+#pragma unroll 1
+    for (int sub = 0; sub < 4; ++sub) {
+      // ---- first transposed conv, the 64 channels of sub-pixel `sub`: u[jj][r] = channel 16 jj + 4 q4 + r of token c16
+      f32x4 u[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * sub + jj;
+        u[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          u[jj] = ea_mfma_16x16x32(*reinterpret_cast<const f16x8*>(smem + ((j * 8 + ks) * 64 + lane) * 16), fk[ks], u[jj]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[jj][r] = (float)(f16)(u[jj][r] + p.b0[16 * j + 4 * q4 + r]);   // the unfused form stores u0 in fp16
+      }
+      // ---- LayerNorm2d over the 64 channels (fp32, eps 1e-6) + exact GELU -> fragments of the second product
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s1 += u[jj][r]; s2 += u[jj][r] * u[jj][r]; }
+      s1 += ea_shfl_xor(s1, 16); s2 += ea_shfl_xor(s2, 16);
+      s1 += ea_shfl_xor(s1, 32); s2 += ea_shfl_xor(s2, 32);
+      const float mean = s1 * (1.0f / 64.0f);
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 * (1.0f / 64.0f) - mean * mean, 0.f) + p.eps);
+      f16x8 fa[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[ks][e] = (f16)ea_gelu_erf((u[2 * ks + (e >> 2)][e & 3] - mean) * rstd * lg[ks][e] + lb[ks][e]);
+      // ---- second transposed conv as a [16 x 64] x [64 x 128] product, + bias, GELU
+      f32x4 acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc[j] = ea_mfma_16x16x32(fw[j][ks], fa[ks], acc[j]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = ea_gelu_erf(acc[j][r] + p.b1[16 * j + 4 * q4 + r]);
+      }
+      // ---- product with the hypernetwork outputs (as in ea_sam_upscale_tail_kernel)
+      float out[4][4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        float h8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h8[r] = hy[m * 32 + 4 * q4 + r]; h8[4 + r] = hy[m * 32 + 16 + 4 * q4 + r]; }
+#pragma unroll
+        for (int s2i = 0; s2i < 4; ++s2i) {
+          float a = 0.f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a += acc[2 * s2i][r] * h8[r] + acc[2 * s2i + 1][r] * h8[4 + r];
+          a += ea_shfl_xor(a, 16);
+          a += ea_shfl_xor(a, 32);
+          out[m][s2i] = a;
+        }
+      }
+      const int Y = 4 * y + 2 * (sub >> 1), X = 4 * xx + 2 * (sub & 1);
+      float o[4];
+#pragma unroll
+      for (int s2i = 0; s2i < 4; ++s2i) o[s2i] = q4 == 0 ? out[0][s2i] : q4 == 1 ? out[1][s2i] : q4 == 2 ? out[2][s2i] : out[3][s2i];
+      const int mo = q4 - p.m0;
+      if (mo >= 0 && mo < p.nm) {
+        float* dst = p.masks + (((long long)b * p.nm + mo) * (4 * p.h) + Y) * W4 + X;
+        *reinterpret_cast<f32x2*>(dst) = f32x2{o[0], o[1]};
+        *reinterpret_cast<f32x2*>(dst + W4) = f32x2{o[2], o[3]};
+      }
+    }
+  }
+}
+
 
 // ------------------------------------------------------------------------------------------------ token -> image
 //  ctx[b] = softmax_rows(scale * g[b] (k[b] + pe)^T) k[b]          g [64 x 256] (one row per (head, token)), k [T x 256]
@@ -684,5 +813,24 @@ extern "C" int ea_sam_token_self_attn_f16(const void* q, const void* k, const vo
   p.q = (const f16*)q; p.k = (const f16*)k; p.v = (const f16*)v; p.out = (f16*)out; p.B = B; p.n = n; p.scale = scale;
   auto kfn = ea_sam_token_self_attn_kernel;
   EA_LAUNCH(kfn, dim3((unsigned)B), dim3(256), (3 * 8 * SAM_C + 8 * 64) * 4, stream, p);
+  return ea_launch_status();
+}
+
+extern "C" int ea_sam_upscale_f16(const void* k, const void* w0, const float* b0, const float* ln_g, const float* ln_b, float eps,
+                                  const void* w1, const float* b1, const float* hyper, float* masks, int B, int h, int w, int m0, int nm,
+                                  void* stream) {
+  if (!k || !w0 || !b0 || !ln_g || !ln_b || !w1 || !b1 || !hyper || !masks) return EA_ERR_BAD_ARG;
+  if (B <= 0 || h <= 0 || w <= 0 || m0 < 0 || nm <= 0 || m0 + nm > 4) return EA_ERR_BAD_SHAPE;
+  if ((h * w) % 16) return EA_ERR_UNSUPPORTED;          // a wave's 16 tokens belong to one prompt
+  if (((uintptr_t)k | (uintptr_t)w0 | (uintptr_t)w1 | (uintptr_t)masks) & 15) return EA_ERR_BAD_ARG;
+  SamUpParams p;
+  p.k = (const f16*)k; p.w0 = (const f16*)w0; p.b0 = b0; p.ln_g = ln_g; p.ln_b = ln_b; p.eps = eps; p.w1 = (const f16*)w1; p.b1 = b1;
+  p.hyper = hyper; p.masks = masks; p.B = B; p.h = h; p.w = w; p.m0 = m0; p.nm = nm;
+  const long long ntiles = (long long)B * h * w / 16;
+  long long grid = (ntiles + 7) / 8;
+  if (grid > 256) grid = 256;                            // persistent: one workgroup (8 waves) per CU holds the first weight in LDS
+  auto kfn = ea_sam_upscale_fused_kernel;
+  ea_allow_big_lds(kfn, UP_W0_LDS);
+  EA_LAUNCH(kfn, dim3((unsigned)grid), dim3(512), UP_W0_LDS, stream, p);
   return ea_launch_status();
 }

@@ -780,6 +780,19 @@ def sam_t2i(k, pe, g, scale, B):
     return ctx
 
 
+def sam_upscale(k, w0, b0, ln_g, ln_b, eps, w1, b1, hyper, B, h, w, m0=0, nm=4, out=None):
+    """MaskDecoder.output_upscaling whole + hypernetwork product (ea_sam_upscale_f16): image tokens k fp16 [B*h*w, 256] ->
+    mask logits fp32 [B, nm, 4h, 4w]; the first transposed conv's output is never stored."""
+    _check_dev(k, w0, w1, hyper)
+    _dense(k, w0, w1, hyper)
+    masks = out if out is not None else torch.empty((B, nm, 4 * h, 4 * w), dtype=torch.float32, device=k.device)
+    _dense(masks)
+    st = _lib().ea_sam_upscale_f16(_p(k), _p(w0), _p(b0), _p(ln_g), _p(ln_b), float(eps), _p(w1), _p(b1), _p(hyper), _p(masks), B, h, w,
+                                   m0, nm, _stream())
+    L.check(st, "ea_sam_upscale_f16")
+    return masks
+
+
 def sam_token_self_attn(q, k, v, scale):
     """The prompt tokens' self attention core (ea_sam_token_self_attn_f16): q / k / v fp16 [B, n <= 8, 256] -> fp16 [B, n, 256],
     8 heads, fp32 inside."""

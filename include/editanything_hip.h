@@ -356,6 +356,12 @@ int ea_sam_i2t_f16(const void* kp, long long kp_sb, const void* k, long long k_s
  * arbitrary), k fp16 [B][T][256] (k_sb = 0: shared), pe fp16 [T][256], ctx fp32 [B][64][256].  T % 64 == 0, C = 256. */
 int ea_sam_t2i_f16(const void* k, long long k_sb, const void* pe, const void* g, float scale, float* ctx, int B, int T, int C,
                    void* stream);
+/* ea_sam_upscale_f16 (round 6): MaskDecoder.output_upscaling WHOLE -- ConvTranspose2d(256 -> 64, k 2, s 2) as a per-token
+ * product with w0 fp16 [256][256] (row (dy * 2 + dx) * 64 + c) + b0 fp32 [256], then exactly ea_sam_upscale_tail_f16 -- from the
+ * image tokens k fp16 [B*h*w][256] to the mask logits, the intermediate [B*h*w*4][64] tensor never stored.  h * w % 16 == 0. */
+int ea_sam_upscale_f16(const void* k, const void* w0, const float* b0, const float* ln_g, const float* ln_b, float eps,
+                       const void* w1, const float* b1, const float* hyper, float* masks, int B, int h, int w, int m0, int nm,
+                       void* stream);
 /* The 7-token side of those two attentions (round 6; TwoWayAttentionBlock's q / k / v / out projections of the token
  * side, segment_anything modeling/transformer.py, third party), one launch per operand instead of einsum + cast + pad:
  * ea_sam_fold_heads_f16: out[b][s][c] = sum_e x[b][j][h * d_head + e] * w[h][e][c] with h * 8 + j = perm ? perm[s] : s, zero

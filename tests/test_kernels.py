@@ -56,7 +56,7 @@ def _cases_added_in_round_6_draw_from_their_own_stream(request):
     exactly as it was."""
     name = request.node.name
     params = getattr(getattr(request.node, "callspec", None), "params", {})
-    own = "three_stage" in name or "mask_tabled" in name or "id_map" in name or "fold_heads" in name or "token_self" in name or str(params.get("variant", "")) in ("33", "34")
+    own = "three_stage" in name or "mask_tabled" in name or "id_map" in name or "fold_heads" in name or "token_self" in name or "upscale_whole" in name or str(params.get("variant", "")) in ("33", "34")
     _OWN_RNG[0] = np.random.default_rng(abs(hash(name)) % (1 << 31)) if own else None
     yield
     _OWN_RNG[0] = None
@@ -1898,6 +1898,50 @@ def test_sam_upscale_tail_fused(kb):
     x = F.gelu(F.conv_transpose2d(x, t(wt), t(b1), stride=2))
     ref = torch.einsum("bmc,bchw->bmhw", t(hyper), x)
     assert relerr(kb.down(masks), ref.numpy()) < 3e-3
+
+
+@pytest.mark.parametrize("B,h,w", [(2, 4, 8), (3, 8, 6)])
+def test_sam_upscale_whole_in_one_pass(kb, B, h, w):
+    """Round 6: ea_sam_upscale_f16 == MaskDecoder.output_upscaling (ConvTranspose2d(256 -> 64, 2, 2), LayerNorm2d, GELU,
+    ConvTranspose2d(64 -> 32, 2, 2), GELU) + the hypernetwork product, from the image tokens -- and == the two-launch form
+    (contraction + ea_sam_upscale_tail_f16) it replaces."""
+    Cc, c0, c1 = 256, 64, 32
+    keys = f16(B * h * w, Cc)
+    wt0 = f16(Cc, c0, 2, 2, scale=0.08)                            # ConvTranspose2d weights [cin, cout, 2, 2]
+    b0 = f32(c0, scale=0.1)
+    g, bt = (1.0 + 0.1 * _rng().standard_normal(c0)).astype(np.float32), f32(c0, scale=0.1)
+    wt1 = f16(c0, c1, 2, 2, scale=0.3)
+    b1 = f32(c1, scale=0.1)
+    hyper = f32(B, 4, c1)
+    w0 = np.ascontiguousarray(np.transpose(wt0, (2, 3, 1, 0)).reshape(4 * c0, Cc))
+    w1 = np.ascontiguousarray(np.transpose(wt1, (2, 3, 1, 0)).reshape(4 * c1, c0))
+    b0r, b1r = np.tile(b0, 4), np.tile(b1, 4)
+    masks = kb.zeros((B, 4, 4 * h, 4 * w), np.float32)
+    assert kb.lib.ea_sam_upscale_f16(ptr(keys), ptr(w0), ptr(b0r), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(b1r), ptr(hyper), ptr(masks), B, h, w,
+                                     0, 4, kb.stream) == 0
+    m3 = kb.zeros((B, 3, 4 * h, 4 * w), np.float32)
+    assert kb.lib.ea_sam_upscale_f16(ptr(keys), ptr(w0), ptr(b0r), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(b1r), ptr(hyper), ptr(m3), B, h, w,
+                                     1, 3, kb.stream) == 0
+    assert np.array_equal(kb.down(m3), kb.down(masks)[:, 1:])
+    x = t(keys).reshape(B, h, w, Cc).permute(0, 3, 1, 2)
+    x = F.conv_transpose2d(x, t(wt0), t(b0), stride=2).half().float()
+    mu, var = x.mean(1, keepdim=True), x.var(1, keepdim=True, unbiased=False)
+    x = (x - mu) / torch.sqrt(var + 1e-6) * t(g)[None, :, None, None] + t(bt)[None, :, None, None]
+    x = F.gelu(x).half().float()
+    x = F.gelu(F.conv_transpose2d(x, t(wt1), t(b1), stride=2))
+    ref = torch.einsum("bmc,bchw->bmhw", t(hyper), x)
+    assert relerr(kb.down(masks), ref.numpy()) < 3e-3
+    # the two-launch form
+    u0 = kb.zeros((B * h * w, 4 * c0), np.float16)
+    ws = workspace(kb, 1 << 16)
+    ep = epilogue(u0, bias=b0r)
+    assert kb.lib.ea_gemm_f16(ptr(keys), Cc, ptr(w0), Cc, B * h * w, 4 * c0, Cc, 1, 0, 0, 0, 0, C.byref(ep),
+                              ptr(ws), ws_nbytes(ws), kb.stream) == 0
+    two = kb.zeros((B, 4, 4 * h, 4 * w), np.float32)
+    assert kb.lib.ea_sam_upscale_tail_f16(ptr(u0), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(b1r), ptr(hyper), ptr(two), B, h, w, 0, 4, kb.stream) == 0
+    assert relerr(kb.down(masks), kb.down(two)) < 1e-3
+    assert kb.lib.ea_sam_upscale_f16(ptr(keys), ptr(w0), ptr(b0r), ptr(g), ptr(bt), 1e-6, ptr(w1), ptr(b1r), ptr(hyper), ptr(masks), 1, 3, 5,
+                                     0, 4, kb.stream) == -3                               # 15 tokens: not a multiple of a wave's 16
 
 
 @pytest.mark.parametrize("B,T,shared", [(2, 128, False), (2, 192, True)])
