@@ -499,6 +499,8 @@ def test_sam_mask_tabled_kernel_equals_per_pixel_kernel(kb, hw, lres, S):
     (every tap pair in one cell: the 4-load loop), up-sampling and odd sizes (the 8- and 16-load loops), more than one column
     per thread, ragged last band, an index selection, statistics only."""
     H, W = hw
+    if kb.name == "emu" and hw in ((37, 29), (96, 300)):
+        pytest.skip("the emulator runs four of the six geometries (each loop form, one ragged band): minutes per case on fibers")
     in_h, in_w = _mask_geometry(hw, S)
     n = 7
     low = f32(n, lres, lres, scale=2.0)
@@ -574,11 +576,12 @@ def test_sam_id_map_list_longer_than_one_piece(kb):
     n = 8192 + 37
     low = f32(n, lres, lres, scale=2.0) - 3.0
     index = _rng().permutation(n).astype(np.int32)
-    mask = kb.zeros((n, H, W), np.uint8)
-    stats = kb.up(np.tile(np.array([0, 0, W, H, -1, -1], np.int32), (n, 1)))
-    assert kb.lib.ea_sam_mask_postprocess_indexed(ptr(low), ptr(index), n, lres, lres, S, S, S, H, W, 0.0, 1.0, ptr(mask), ptr(stats),
-                                                  kb.stream) == 0
-    want = (kb.down(mask).astype(np.int32) * np.arange(1, n + 1, dtype=np.int32)[:, None, None]).max(0)
+    # expected: the list painted in two explicit pieces of one launch each (a piece == painting its masks: the test above)
+    want_d = kb.zeros((H, W), np.int32)
+    head, tail = index[:5000].copy(), index[5000:].copy()
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(head), 5000, lres, lres, S, S, S, H, W, 0.0, 0, ptr(want_d), kb.stream) == 0
+    assert kb.lib.ea_sam_id_map(ptr(low), ptr(tail), n - 5000, lres, lres, S, S, S, H, W, 0.0, 5000, ptr(want_d), kb.stream) == 0
+    want = kb.down(want_d).copy()
     assert want.min() < 8192 < want.max()
     idm = kb.zeros((H, W), np.int32)
     assert kb.lib.ea_sam_id_map(ptr(low), ptr(index), n, lres, lres, S, S, S, H, W, 0.0, 0, ptr(idm), kb.stream) == 0
