@@ -115,6 +115,8 @@ class SamPromptDecoder:
         self.hyper = [mlp(f"{md}output_hypernetworks_mlps.{i}.") for i in range(self.out_tokens.shape[0] - 1)]
         self.iou_head = mlp(md + "iou_prediction_head.")
         self._pe_cache = {}
+        self._graphs = {}          # predict_masks_graph: (shapes, scratch tag) -> (graph, static inputs, outputs, scratch refs)
+        self.graph_ok = True       # cleared for good if a capture ever fails (the eager path is the same arithmetic)
 
     # ------------------------------------------------------------------ prompt encoder
     def _pe(self, coords01):
@@ -313,6 +315,41 @@ class SamPromptDecoder:
         self._vo_perm()
         return self._perm_i32
 
+    @torch.no_grad()
+    def predict_masks_graph(self, image_tokens, emb_hw, sparse, multimask_output=True):
+        """`predict_masks` replayed from a HIP graph captured once per (shapes, scratch tag): the automatic generator decodes
+        the SAME 1024 grid prompts for every image -- ~270 launches, two thirds of them small torch ops of the 7-token side,
+        become one replay (like sam.ImageEncoderViT.forward_graph: thread-local capture, the entry owns the scratch it
+        addresses).  The returned tensors are the graph's own outputs: valid until the next call with the same shapes."""
+        if not self.graph_ok or not image_tokens.is_cuda:
+            return self.predict_masks(image_tokens, emb_hw, sparse, multimask_output)
+        key = (tuple(image_tokens.shape), tuple(emb_hw), tuple(sparse.shape), bool(multimask_output), ops.aux_tag())
+        ent = self._graphs.get(key)
+        if ent is None:
+            tok_s, sp_s = image_tokens.clone(), sparse.clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.predict_masks(tok_s, emb_hw, sp_s, multimask_output)      # warm-up outside capture (lazy caches, library handles)
+            cur.wait_stream(side)
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self.predict_masks(tok_s, emb_hw, sp_s, multimask_output)
+            except Exception as exc:                                           # noqa: BLE001 -- any capture failure: eager from now on
+                import warnings
+                warnings.warn(f"SamPromptDecoder: graph capture of the mask decoder failed ({exc}); running it eagerly")
+                self.graph_ok = False
+                torch.cuda.synchronize()
+                return self.predict_masks(image_tokens, emb_hw, sparse, multimask_output)
+            ent = self._graphs[key] = (g, tok_s, sp_s, out, ops.workspace_refs())
+        g, tok_s, sp_s, out = ent[:4]
+        tok_s.copy_(image_tokens)
+        sp_s.copy_(sparse)
+        g.replay()
+        return out
+
     def predict_masks(self, image_tokens, emb_hw, sparse, multimask_output=True):
         """image_tokens: fp16 [h*w, C] (encoder output + no-mask dense embedding, NHWC order); sparse fp32 [B, Np, C].
         -> low-res mask logits fp32 [B, 3|1, 4h, 4w], iou predictions fp32 [B, 3|1].
@@ -456,12 +493,14 @@ class SamAutomaticMaskGenerator:
     `editanything_amd.sam.ImageEncoderViT`, `decoder` a `SamPromptDecoder`; keyword arguments override upstream's
     defaults under their upstream names."""
 
-    def __init__(self, encoder, decoder, decode_batch=None, **overrides):
+    def __init__(self, encoder, decoder, decode_batch=None, use_graph=True, **overrides):
         """decode_batch: prompts per decoder call (default DECODE_BATCH = 1024: the whole 32 x 32 grid at once, ~13 GB of
         activations).  It is this implementation's memory knob; upstream's `points_per_batch` is honoured as a LOWER bound of
         it only (prompts are independent: neither changes a result) -- pass decode_batch=64 on a small device."""
         self.encoder, self.decoder = encoder, decoder
         self.decode_batch = DECODE_BATCH if decode_batch is None else max(1, int(decode_batch))
+        self.use_graph = bool(use_graph)     # the grid's decoder pass as one HIP-graph replay (SamPromptDecoder.predict_masks_graph)
+        self._sparse_cache = {}
         self.cfg = dict(AMG_DEFAULTS)
         unknown = set(overrides) - set(self.cfg)
         if unknown:
@@ -507,9 +546,17 @@ class SamAutomaticMaskGenerator:
         step = max(int(c["points_per_batch"]), self.decode_batch) if self.decode_batch >= DECODE_BATCH else self.decode_batch
         lows, ious, ptss = [], [], []
         for s in range(0, len(pts_all), step):
-            p = torch.as_tensor(pts_all[s:s + step], dtype=torch.float32, device=dev)
-            sparse = dec.embed_points((p * scale)[:, None, :], torch.ones(len(p), 1))
-            low, iou = dec.predict_masks(st["tokens"], st["emb_hw"], sparse, True)
+            ck = (H, W, in_h, in_w, int(c["points_per_side"]), s, step)
+            if ck not in self._sparse_cache:                 # the grid's prompts depend on the image SIZE only
+                if len(self._sparse_cache) > 16:
+                    self._sparse_cache.clear()
+                p = torch.as_tensor(pts_all[s:s + step], dtype=torch.float32, device=dev)
+                self._sparse_cache[ck] = (p, dec.embed_points((p * scale)[:, None, :], torch.ones(len(p), 1)))
+            p, sparse = self._sparse_cache[ck]
+            decode = dec.predict_masks_graph if self.use_graph and hasattr(dec, "predict_masks_graph") else dec.predict_masks
+            low, iou = decode(st["tokens"], st["emb_hw"], sparse, True)
+            if len(pts_all) > step and decode is not dec.predict_masks:
+                low, iou = low.clone(), iou.clone()          # a replay's outputs are overwritten by the next chunk's replay
             lows.append(low.flatten(0, 1)); ious.append(iou.flatten(0, 1)); ptss.append(p.repeat_interleave(3, dim=0))
         low = lows[0] if len(lows) == 1 else torch.cat(lows)          # the candidates' logits stay where the decoder wrote them:
         iou = ious[0] if len(ious) == 1 else torch.cat(ious)          # every filter below works on an index list

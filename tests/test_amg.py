@@ -268,6 +268,30 @@ def test_device_id_map_equals_show_anns_of_the_records(device_decoder):
 
 
 @gpu
+def test_decoder_graph_replay_equals_eager_launches(device_decoder):
+    """Round 6: the generator decodes its grid prompts by replaying ONE captured graph of `predict_masks` per shape
+    (`SamPromptDecoder.predict_masks_graph`; prompts cached per image size).  Same records and id map as the eager launches,
+    bit for bit -- on a second image through the cached graph too, and with the grid decoded in chunks (a chunk's outputs are
+    copied out before the next replay overwrites them)."""
+    from editanything_amd.amg import SamAutomaticMaskGenerator
+    dec = device_decoder
+    img = np.zeros((96, 128, 3), np.uint8)
+    kw = dict(points_per_side=8, pred_iou_thresh=-1e9, stability_score_thresh=-1.0, stability_score_offset=0.002, box_nms_thresh=1.1)
+    for decode_batch in (None, 16):
+        eager = SamAutomaticMaskGenerator(None, dec, decode_batch=decode_batch, use_graph=False, **kw)
+        graph = SamAutomaticMaskGenerator(None, dec, decode_batch=decode_batch, use_graph=True, **kw)
+        for seed in (4, 5, 6):
+            emb = torch.randn(1, 256, 16, 16, generator=torch.Generator().manual_seed(seed)).cuda()
+            a, na = eager.generate_id_map(img, image_embedding=emb)
+            b, nb = graph.generate_id_map(img, image_embedding=emb)
+            assert na == nb and na > 0 and torch.equal(a, b)
+            ra, rb = eager.generate(img, image_embedding=emb), graph.generate(img, image_embedding=emb)
+            assert len(ra) == len(rb) and all(x["predicted_iou"] == y["predicted_iou"] and np.array_equal(x["segmentation"], y["segmentation"])
+                                               for x, y in zip(ra, rb))
+    assert dec.graph_ok and len(dec._graphs) >= 2
+
+
+@gpu
 def test_process_many_equals_process_one_at_a_time():
     """`Demo.process_many` (requests software-pipelined over two streams, SAM + AMG + control of request i+1 issued by the side
     thread under the loop of request i) returns, request by request, exactly what `Demo.process` returns."""

@@ -42,6 +42,10 @@ if "ab" in sys.argv[2:]:
     old_map = run("per-pixel kernel + painted masks")
     ops.sam_mask_postprocess, ops.SAM_ID_MAP_MAX_W = post, max_w
     run("tabled kernel + id-map kernel, again")
+    gen.use_graph = False
+    eager_map = run("shipped kernels, decoder launched eagerly (no graph replay)")
+    gen.use_graph = True
+    print(json.dumps({"graph_replay_equals_eager": bool(torch.equal(new_map, eager_map)), "graph_ok": bool(dec.graph_ok)}))
     print(json.dumps({"id_maps_identical": bool(torch.equal(new_map, old_map)), "labels": int(new_map.max())}))
 else:
     run("shipped")
