@@ -209,6 +209,34 @@ def test_the_sam_mask_decoder_is_bit_stable_beside_a_busy_second_stream():
     _stable("SAM mask decoder", run, 6, self_fn=run2)
 
 
+def test_the_mask_post_processing_and_the_id_map_are_bit_stable_beside_a_busy_second_stream():
+    """Round 6's kernels behind the decoder: the tabled post-processing pass (statistics + masks: integer atomics), the id-map walk,
+    and the decoder's pass replayed from its captured graph (SamPromptDecoder.predict_masks_graph: fold / unfold / token self
+    attention / fused upscaling kernels and the small torch launches around them, as one replay)."""
+    from editanything_amd.amg import SamPromptDecoder
+    g = torch.Generator("cpu").manual_seed(5)
+    low = (torch.randn(384, 256, 256, generator=g) * 2.0 - 1.0).to(DEV)
+    idx = torch.randperm(384, generator=g)[:300].int().to(DEV)
+
+    def post():
+        mask, stats = ops.sam_mask_postprocess(low, (1024, 1024), (512, 512), 1024, 0.0, 1.0, index=idx)
+        idm = ops.sam_id_map(low, (1024, 1024), (512, 512), 1024, 0.0, index=idx)
+        return mask, stats, idm
+    _stable("SAM mask post-processing + id map", post, 6, self_fn=post)
+    sd = synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), 9)
+    dec, dec2 = SamPromptDecoder(sd, DEV), SamPromptDecoder(sd, DEV)
+    emb = (torch.randn(1, 256, 64, 64, generator=g) * 0.5).to(DEV)
+    pts = (torch.rand(256, 1, 2, generator=g) * 1024).to(DEV)
+    lab = torch.ones(256, 1, device=DEV)
+    with torch.no_grad():
+        tokens, sparse = dec.image_tokens(emb), dec.embed_points(pts, lab)
+        tokens2, sparse2 = dec2.image_tokens(emb), dec2.embed_points(pts, lab)
+        want = _clone(dec.predict_masks(tokens, (64, 64), sparse, True))
+        assert _same(dec.predict_masks_graph(tokens, (64, 64), sparse, True), want) and dec.graph_ok
+    _stable("SAM mask decoder, graph replay", lambda: dec.predict_masks_graph(tokens, (64, 64), sparse, True), 6,
+            self_fn=lambda: dec2.predict_masks(tokens2, (64, 64), sparse2, True))
+
+
 @pytest.mark.parametrize("heads,d,n", [(8, 40, 9216), (8, 80, 2304), (8, 160, 576)])
 def test_the_config4_attention_instantiations_are_bit_stable_beside_a_busy_second_stream(heads, d, n):
     """SD1.5 head dimensions at 96 x 96 latents (BASELINE config 4): self-attention and the 77-token cross-attention."""
