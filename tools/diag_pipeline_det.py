@@ -94,10 +94,26 @@ if opts.get("stress"):
             sam_ref = sam.forward_graph(sam_x).clone()
             assert torch.equal(sam.forward_graph(sam_x), sam_ref)
         plain_call = call
+        amg_gen = None
+        if opts.get("amg"):
+            # amg=1 (round 6, last session): ... and generates the id map of one image from a fixed embedding -- the mask decoder
+            # replayed from its captured graph, the tabled post-processing pass, the NMS round trip to the host, the id-map walk
+            from editanything_amd import amg as eamg, arch, synth
+            amg_dec = eamg.SamPromptDecoder(synth.synth_state_dict_torch(arch.sam_decoder_param_shapes(), 12), torch.device(dev))
+            amg_emb = torch.randn(1, 256, 64, 64, generator=torch.Generator("cpu").manual_seed(7)).to(dev)
+            amg_img = np.zeros((512, 512, 3), np.uint8)
+            g0 = eamg.SamAutomaticMaskGenerator(None, amg_dec, pred_iou_thresh=-1e9, stability_score_thresh=-1.0, box_nms_thresh=1.1)
+            sc = np.sort([r_["stability_score"] for r_ in g0.generate(amg_img, image_embedding=amg_emb)])
+            amg_gen = eamg.SamAutomaticMaskGenerator(None, amg_dec, pred_iou_thresh=-1e9, stability_score_thresh=float(sc[-300]))
+            amg_ref = amg_gen.generate_id_map(amg_img, image_embedding=amg_emb)[0].clone()
+            assert int(amg_ref.max()) > 100, int(amg_ref.max())
+            assert torch.equal(amg_gen.generate_id_map(amg_img, image_embedding=amg_emb)[0], amg_ref), "id map not reproducible undisturbed"
 
         def call(seed):            # noqa: F811 -- the request as a callable: SAM encode first, then the pipeline's kwargs
             def make():
                 sam_flags.append((sam.forward_graph(sam_x) != sam_ref).any())     # no host sync here: summed after the loop
+                if amg_gen is not None:
+                    sam_flags.append((amg_gen.generate_id_map(amg_img, image_embedding=amg_emb)[0] != amg_ref).any())
                 return plain_call(seed)
             return make
     with torch.no_grad():
